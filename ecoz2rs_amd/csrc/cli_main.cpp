@@ -1,0 +1,152 @@
+// cli_main.cpp -- `ecoz2 vq {learn,quantize,show}` front-end over libecoz2vq.so.
+// Mirrors the reference's clap option structs for this path
+// (/root/reference/src/vq/mod.rs:38-96 VqLearnOpts / VqQuantizeOpts, :120-133 VqShowOpts)
+// and its mains (:151-216): same flag names, defaults, file-list resolution and messages.
+// Like the reference (src/vq/mod.rs:146-148) errors are printed and the exit code stays 0
+// unless the arguments themselves are unusable.
+#include "../../include/ecoz2_vq.h"
+#include "vq_io.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+static void callback(void*, int M, double avg, double sigma, double inertia)
+{
+    // Ecoz2ObserverRef::step, src/ecoz2_lib/mod.rs:61-69
+    printf("   Ecoz2ObserverRef.step: M=%d avg_distortion=%g sigma=%g inertia=%g\n", M, avg, sigma, inertia);
+}
+
+static int usage()
+{
+    fprintf(stderr,
+            "usage:\n"
+            "  ecoz2 vq learn [-B <codebook>] [-P <P>] [-e <eps>] [--class-name <class>] [--exp-key <k>]\n"
+            "                 --predictors <files|dirs|tt.csv>...\n"
+            "  ecoz2 vq quantize --codebook <cbook> --predictors <files|dirs|tt.csv>...\n"
+            "                 [--predictors-dir-template <t>] [--tt <TRAIN|TEST>] [--class-name <class>] [-s]\n"
+            "  ecoz2 vq show [-f <from>] [-t <to>] <codebook>\n"
+            "  ecoz2 cversion\n");
+    return 2;
+}
+
+static bool is_flag(const char* a) { return a[0] == '-' && a[1] != 0 && !(a[1] >= '0' && a[1] <= '9'); }
+
+static std::vector<const char*> cptrs(const std::vector<std::string>& v)
+{
+    std::vector<const char*> p;
+    for (const auto& s : v) p.push_back(s.c_str());
+    return p;
+}
+
+static int vq_learn(int argc, char** argv)
+{
+    std::string base, cls, exp_key;
+    int P = -1;
+    double eps = 0.05;
+    std::vector<std::string> predictors;
+    for (int i = 0; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&](const char* name) -> const char* {
+            if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", name); exit(2); }
+            return argv[++i];
+        };
+        if (a == "-B" || a == "--base-codebook") base = val("-B");
+        else if (a == "-P" || a == "--prediction-order") P = atoi(val("-P"));
+        else if (a == "-e" || a == "--epsilon") eps = atof(val("-e"));
+        else if (a == "--class-name") cls = val("--class-name");
+        else if (a == "--exp-key") exp_key = val("--exp-key");
+        else if (a == "--predictors") { while (i + 1 < argc && !is_flag(argv[i + 1])) predictors.push_back(argv[++i]); }
+        else if (!is_flag(argv[i])) predictors.push_back(a);
+        else return usage();
+    }
+    if (!base.empty() && P >= 0) {  // src/vq/mod.rs:161-163
+        printf("Only one of base codebook or prediction order expected\n");
+        return 0;
+    }
+    if (base.empty() && P < 0) return usage();
+    const std::string codebook_class = cls.empty() ? "_" : cls;
+    std::vector<std::string> files;
+    const bool tt_list = predictors.size() == 1 && predictors[0].size() > 4 &&
+                         predictors[0].compare(predictors[0].size() - 4, 4, ".csv") == 0;
+    int rc = tt_list ? e2vq_io::files_from_csv(predictors[0], "TRAIN", cls, "predictors", ".prd", nullptr, files)
+                     : e2vq_io::resolve_filenames(predictors, ".prd", files);
+    if (!rc && files.empty()) { printf("No predictors given\n"); return 0; }
+    if (rc) { printf("%s\n", e2vq_last_error()); return 0; }
+    printf("vq_learn: base_codebook_opt=%s prediction_order=%d, epsilon=%g codebook_class_name=%s predictor_filenames: %zu\n",
+           base.empty() ? "None" : base.c_str(), P, eps, codebook_class.c_str(), files.size());
+    auto ptrs = cptrs(files);
+    if (!base.empty())
+        ecoz2_vq_learn_using_base_codebook(base.c_str(), eps, ptrs.data(), (int)ptrs.size(), nullptr, callback);
+    else
+        ecoz2_vq_learn(P, eps, codebook_class.c_str(), ptrs.data(), (int)ptrs.size(), nullptr, callback);
+    return 0;
+}
+
+static int vq_quantize(int argc, char** argv)
+{
+    std::string codebook, tmpl = "data/predictors", tt, cls;
+    bool show = false;
+    std::vector<std::string> predictors;
+    for (int i = 0; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&](const char* name) -> const char* {
+            if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", name); exit(2); }
+            return argv[++i];
+        };
+        if (a == "--codebook") codebook = val("--codebook");
+        else if (a == "--predictors-dir-template") tmpl = val("--predictors-dir-template");
+        else if (a == "--tt") tt = val("--tt");
+        else if (a == "--class-name") cls = val("--class-name");
+        else if (a == "-s" || a == "--show-filenames") show = true;
+        else if (a == "--predictors") { while (i + 1 < argc && !is_flag(argv[i + 1])) predictors.push_back(argv[++i]); }
+        else if (!is_flag(argv[i])) predictors.push_back(a);
+        else return usage();
+    }
+    if (codebook.empty() || predictors.empty()) return usage();
+    std::vector<std::string> files;
+    const bool tt_list = predictors.size() == 1 && predictors[0].size() > 4 &&
+                         predictors[0].compare(predictors[0].size() - 4, 4, ".csv") == 0;
+    int rc = tt_list ? e2vq_io::files_from_csv(predictors[0], tt, cls, "", ".prd", &tmpl, files)
+                     : e2vq_io::resolve_filenames(predictors, ".prd", files);
+    if (rc) { printf("%s\n", e2vq_last_error()); return 0; }
+    printf("number of predictor files: %zu\n", files.size());  // src/vq/mod.rs:211
+    printf("nom_raas = %s\n", codebook.c_str());               // src/ecoz2_lib/mod.rs:326
+    auto ptrs = cptrs(files);
+    ecoz2_vq_quantize(codebook.c_str(), ptrs.data(), (int)ptrs.size(), show ? 1 : 0);
+    return 0;
+}
+
+static int vq_show(int argc, char** argv)
+{
+    int from = -1, to = -1;
+    std::string codebook;
+    for (int i = 0; i < argc; ++i) {
+        const std::string a = argv[i];
+        if ((a == "-f" || a == "--from") && i + 1 < argc) from = atoi(argv[++i]);
+        else if ((a == "-t" || a == "--to") && i + 1 < argc) to = atoi(argv[++i]);
+        else if (a == "--codebook" && i + 1 < argc) codebook = argv[++i];
+        else codebook = a;
+    }
+    if (codebook.empty()) return usage();
+    printf("codebook_filename = %s\n", codebook.c_str());  // src/ecoz2_lib/mod.rs:361
+    ecoz2_vq_show(codebook.c_str(), from, to);
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc >= 2 && !strcmp(argv[1], "cversion")) {
+        printf("%s\n", ecoz2_version());
+        return 0;
+    }
+    if (argc < 3 || strcmp(argv[1], "vq") != 0) return usage();
+    const std::string cmd = argv[2];
+    if (cmd == "learn") return vq_learn(argc - 3, argv + 3);
+    if (cmd == "quantize") return vq_quantize(argc - 3, argv + 3);
+    if (cmd == "show") return vq_show(argc - 3, argv + 3);
+    return usage();
+}

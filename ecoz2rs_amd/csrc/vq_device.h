@@ -1,0 +1,45 @@
+// vq_device.h -- device-side interface of the VQ kernels (internal; the C-ABI is include/ecoz2_vq.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define E2VQ_MAX_P 200          // CHANGELOG.md:183 of the reference: "increased maximum prediction order (200)"
+#define E2VQ_LDS_BYTES 163840   // 160 KiB per CU on gfx950
+
+namespace e2vq {
+
+struct DevScalars {
+    double maxabs;  // max |x| over the whole training set (all ranks)
+    double Q;       // exact sum of squares of the training set (all ranks)
+    int sh_r;       // frame fixed-point shift   29 - ilogb(maxabs)
+    int sh_q;       // square fixed-point shift  28 - 2*ilogb(maxabs)
+};
+
+inline int row_stride(int NC) { return (2 * NC + 5 + 7) & ~7; }
+inline int cb_pad(int NC) { return (NC + 7) & ~7; }
+
+int frames_per_lane(int NC);       // F of the kernel that will serve this NC (block = 64*F frames)
+bool has_register_kernel(int NC);
+int lds_mode_max_M(int NC);        // largest M whose accumulator table fits LDS
+
+void launch_blockify(const double* aos, long T, int NC, int FB, double* blk, long nblocks, hipStream_t s);
+void launch_maxabs(const double* blk, long count, unsigned long long* out_bits, int* bad, hipStream_t s);
+void launch_finish_scalars(const unsigned long long* maxabs_bits, DevScalars* sc, hipStream_t s);
+void launch_global_sums(const double* blk, long nblocks, int NC, int FB, const DevScalars* sc, long long* stats,
+                        hipStream_t s);
+// mode 0 assign only, 1 LDS accumulators, 2 global atomics
+int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const double* cbq, int M,
+                const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
+                long long* rows, hipStream_t s);
+void launch_rows_stats(const long long* rows, int M, int NC, const DevScalars* sc, double* S, double* within,
+                       long long* lstats, hipStream_t s);
+void launch_centroids(const long long* rows, const double* S, int M, int NC, double* reflections, long long* lstats,
+                      hipStream_t s);
+void launch_finish_q(const long long* stats, int NC, DevScalars* sc, hipStream_t s);
+void launch_init_codebook(const long long* stats, int NC, const DevScalars* sc, double* reflections, int* status,
+                          hipStream_t s);
+void launch_grow(const double* old_refl, int M, int NC, double* new_refl, hipStream_t s);
+void launch_codebook_prepare(const double* reflections, int M, int NC, double* cbq, unsigned long long* l1max_bits,
+                             hipStream_t s);
+
+}  // namespace e2vq

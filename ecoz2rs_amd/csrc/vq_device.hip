@@ -1,0 +1,645 @@
+// vq_device.hip -- hand-written HIP kernels (gfx950 / CDNA4) for the ecoz2 VQ hot path.
+//
+// Replaces the arithmetic of the reference's absent C library behind
+// ecoz2_vq_learn / ecoz2_vq_quantize (/root/reference/src/ecoz2_lib/mod.rs:96-122):
+//   K1  sweep      per frame argmin_m d(r, c_m),  d = r0*c0 + 2*sum r[n]*c[n]   
+//   K2  accumulate per cell exact fixed-point sums of member vectors (order-free)
+//   K3  centroids  Levinson-Durbin per cell (lpca_r, src/lpc/lpca_r_rs.rs:8-43)
+//   K4  codebook   reflections -> raas -> pre-doubled codewords; M -> 2M split
+//
+// Design notes (measured on MI355X):
+//  * FP64-FMA bound at M >= 64.  Lane = frame; a frame's P+1 coefficients live in VGPRs
+//    for the whole sweep; codewords are wave-uniform and stream through SGPRs
+//    (s_load_dwordx16 from a 64B-aligned padded row), so each v_fmac_f64 takes its
+//    codeword operand from an SGPR pair: no LDS/VGPR bandwidth for the broadcast.
+//  * Training frames are resident in HBM in a blocked-transposed layout
+//    [block][n][64*F] so a wave's loads are fully coalesced 16 B/lane.
+//  * All sums are exact integers (two signed 32-bit limbs per value, 64-bit
+//    accumulators), so LDS/global atomics in any order, any grid, any GPU count give
+//    bit-identical cell sums; RCCL all-reduce runs on int64.
+//
+// Compiled with -ffp-contract=off: every FMA below is explicit.
+#include "vq_device.h"
+#include "vq_fixed.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef const double __attribute__((address_space(4))) cdouble_k;
+typedef long long i64;
+typedef unsigned long long u64;
+
+namespace e2vq {
+
+__device__ __forceinline__ i64 wave_sum_i64(i64 v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// layout: AoS frames [t][NC] -> blocked [b][n][64*F]  (tail block zero padded)
+// ------------------------------------------------------------------------------------------
+__global__ void k_blockify(const double* __restrict__ aos, long T, int NC, int FB, double* __restrict__ blk,
+                           long nblocks)
+{
+    const long total = nblocks * (long)NC * FB;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const long b = o / ((long)NC * FB);
+        const int rem = (int)(o - b * (long)NC * FB);
+        const int n = rem / FB, l = rem - n * FB;
+        const long t = b * FB + l;
+        blk[o] = t < T ? aos[t * NC + n] : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// data statistics: max |x| (bit pattern max), then global sums + sum of squares (exact)
+// ------------------------------------------------------------------------------------------
+__global__ void k_maxabs(const double* __restrict__ blk, long count, u64* __restrict__ out_bits, int* __restrict__ bad)
+{
+    u64 m = 0;
+    int b = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const double v = fabs(blk[i]);
+        if (!(v <= 1.7976931348623157e308)) b = 1;
+        const u64 bits = (u64)__double_as_longlong(v);
+        m = bits > m ? bits : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 o = __shfl_xor(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, m);
+    if (b) atomicOr(bad, 1);
+}
+
+// stats layout (i64): [2*n+limb] n<NC global cell sums, [2*NC], [2*NC+1] = sum of squares limbs
+__global__ void k_global_sums(const double* __restrict__ blk, long nblocks, int NC, int FB,
+                              const DevScalars* __restrict__ sc, i64* __restrict__ stats)
+{
+    const int sh_r = sc->sh_r, sh_q = sc->sh_q;
+    // one (block, n) row of FB contiguous doubles per wave iteration
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const long rows = nblocks * NC;
+    for (long rrow = wave; rrow < rows; rrow += nwaves) {
+        const int n = (int)(rrow % NC);
+        const double* p = blk + rrow * FB;
+        i64 sh = 0, sl = 0, qh = 0, ql = 0;
+        for (int l = lane; l < FB; l += 64) {
+            const double x = p[l];
+            int hi, lo;
+            fix2(x, sh_r, hi, lo);
+            sh += hi;
+            sl += lo;
+            fix2(x * x, sh_q, hi, lo);
+            qh += hi;
+            ql += lo;
+        }
+        sh = wave_sum_i64(sh);
+        sl = wave_sum_i64(sl);
+        qh = wave_sum_i64(qh);
+        ql = wave_sum_i64(ql);
+        if (lane == 0) {
+            atomicAdd((u64*)&stats[2 * n], (u64)sh);
+            atomicAdd((u64*)&stats[2 * n + 1], (u64)sl);
+            atomicAdd((u64*)&stats[2 * NC], (u64)qh);
+            atomicAdd((u64*)&stats[2 * NC + 1], (u64)ql);
+        }
+    }
+}
+
+// maxabs bits -> shifts (runs after the MAX all-reduce)
+__global__ void k_finish_scalars(const u64* __restrict__ maxabs_bits, DevScalars* __restrict__ sc)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double maxabs = __longlong_as_double((i64)*maxabs_bits);
+        sc->maxabs = maxabs;
+        const int e = ilogb(maxabs);
+        sc->sh_r = 29 - e;
+        sc->sh_q = 28 - 2 * e;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1 + K2: sweep + accumulate
+// ------------------------------------------------------------------------------------------
+//   NC    coefficients per frame (P+1), compile time so the frame sits in registers
+//   F     frames per lane
+//   MODE  0: assignment only (quantize)     1: LDS accumulators (small M)
+//         2: global atomics through an LDS transposition (large M)
+constexpr int TPB = 256;
+constexpr int IMG_STRIDE_PAD = 3;  // image row stride 2*NC+5+pad: 82 dwords for NC=37 (conflict-free b64 writes)
+
+template <int NC, int F, int MODE>
+__global__ __launch_bounds__(TPB) void k_pass(const double* __restrict__ blk, long T, long nblocks,
+                                              const double* cbq_, int M, const DevScalars* __restrict__ sc,
+                                              const u64* __restrict__ l1max_bits, unsigned short* __restrict__ sym,
+                                              double* __restrict__ dmin, i64* __restrict__ rows)
+{
+    constexpr int NPAD = (NC + 7) & ~7;
+    constexpr int RS = (2 * NC + 5 + 7) & ~7;
+    constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
+    constexpr int FB = 64 * F;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cdouble_k* cbq = (cdouble_k*)cbq_;
+
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const long wave = (long)blockIdx.x * (TPB >> 6) + wib;
+    const long nwaves = (long)gridDim.x * (TPB >> 6);
+
+    int sh_r = 0, sh_d = 0, sh_d2 = 0;
+    if constexpr (MODE != 0) {
+        sh_r = sc->sh_r;
+        const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
+        sh_d = 30 - Ed;
+        sh_d2 = 30 - 2 * Ed;
+    }
+    i64* lacc = (i64*)smem;   // MODE 1: [M][RS]
+    int* img = (int*)smem + wib * (32 * IMG);  // MODE 2: per-wave [32][IMG]
+    if constexpr (MODE == 1) {
+        for (int i = threadIdx.x; i < M * RS; i += TPB) lacc[i] = 0;
+        __syncthreads();
+    }
+
+    for (long b = wave; b < nblocks; b += nwaves) {
+        // ---- load the wave's frames: coalesced, lane-major --------------------------------
+        double r[F][NC];
+        const double* fb = blk + b * (long)(NC * FB);
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+#pragma unroll
+            for (int f = 0; f < F; ++f) r[f][n] = fb[n * FB + lane * F + f];
+
+        // ---- sweep: canonical chain, ascending codeword index, strict '<' -----------------
+        double best[F];
+        int bi[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            best[f] = __builtin_inf();
+            bi[f] = 0;
+        }
+        for (int m = 0; m < M; ++m) {
+            cdouble_k* c = cbq + (long)m * NPAD;
+            double d[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) d[f] = r[f][0] * c[0];
+#pragma unroll
+            for (int n = 1; n < NC; ++n)
+#pragma unroll
+                for (int f = 0; f < F; ++f) d[f] = __builtin_fma(r[f][n], c[n], d[f]);
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const bool lt = d[f] < best[f];
+                best[f] = lt ? d[f] : best[f];
+                bi[f] = lt ? m : bi[f];
+            }
+        }
+
+        // ---- outputs ------------------------------------------------------------------------
+        const long t0 = b * FB + lane * F;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            if (t0 + f < T) {
+                if (sym) sym[t0 + f] = (unsigned short)bi[f];
+                if (dmin) dmin[t0 + f] = best[f];
+            }
+        }
+
+        // ---- accumulate -----------------------------------------------------------------------
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                if (t0 + f < T) {
+                    i64* row = lacc + bi[f] * RS;
+#pragma unroll
+                    for (int n = 0; n < NC; ++n) {
+                        int hi, lo;
+                        fix2(r[f][n], sh_r, hi, lo);
+                        atomicAdd((u64*)&row[2 * n], (u64)(i64)hi);
+                        atomicAdd((u64*)&row[2 * n + 1], (u64)(i64)lo);
+                    }
+                    const double e = best[f] - 1.0;
+                    int hi, lo;
+                    atomicAdd((u64*)&row[2 * NC], 1ull);
+                    fix2(e, sh_d, hi, lo);
+                    atomicAdd((u64*)&row[2 * NC + 1], (u64)(i64)hi);
+                    atomicAdd((u64*)&row[2 * NC + 2], (u64)(i64)lo);
+                    fix2(e * e, sh_d2, hi, lo);
+                    atomicAdd((u64*)&row[2 * NC + 3], (u64)(i64)hi);
+                    atomicAdd((u64*)&row[2 * NC + 4], (u64)(i64)lo);
+                }
+            }
+        } else if constexpr (MODE == 2) {
+            // transposition: 32 frames at a time become int32 row images [frame][2n+limb | count,d,d2],
+            // then the wave adds each image to its cell row with lanes = row elements
+            // (contiguous 8 B/lane atomics: 512 B + 120 B per frame).
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const bool mine = (lane >> 5) == half;
+                    if (mine) {
+                        int* my = img + (lane & 31) * IMG;
+#pragma unroll
+                        for (int n = 0; n < NC; ++n) {
+                            int hi, lo;
+                            fix2(r[f][n], sh_r, hi, lo);
+                            *(int2*)&my[2 * n] = make_int2(hi, lo);
+                        }
+                        const double e = best[f] - 1.0;
+                        int hi, lo;
+                        my[2 * NC] = 1;
+                        fix2(e, sh_d, hi, lo);
+                        my[2 * NC + 1] = hi;
+                        my[2 * NC + 2] = lo;
+                        fix2(e * e, sh_d2, hi, lo);
+                        my[2 * NC + 3] = hi;
+                        my[2 * NC + 4] = lo;
+                    }
+                    // same wave wrote and reads: program order + lgkmcnt make the image visible
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (int j = 0; j < 32; ++j) {
+                        const int src = half * 32 + j;
+                        const long tj = b * FB + (long)src * F + f;
+                        if (tj >= T) break;  // wave-uniform
+                        const int cell = __builtin_amdgcn_readlane(bi[f], src);
+                        i64* row = rows + (long)cell * RS;
+                        const int* im = img + j * IMG;
+                        constexpr int NE = 2 * NC + 5;
+                        if (lane < NE) {
+                            const int v0 = im[lane];
+                            atomicAdd((u64*)&row[lane], (u64)(i64)v0);
+                        }
+                        if (NE > 64 && lane < NE - 64) {
+                            const int v1 = im[64 + lane];
+                            atomicAdd((u64*)&row[64 + lane], (u64)(i64)v1);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+        }
+    }
+
+    if constexpr (MODE == 1) {
+        __syncthreads();
+        // flush the workgroup's table: contiguous 8 B/lane atomics
+        for (int i = threadIdx.x; i < M * RS; i += TPB) {
+            const i64 v = lacc[i];
+            if (v != 0) atomicAdd((u64*)&rows[i], (u64)v);
+        }
+    }
+}
+
+// generic (any P) fallback: frame coefficients re-read from global/L1 per codeword.
+// Correct for every P <= E2VQ_MAX_P; only the instantiated NC values get the register kernel.
+template <int MODE>
+__global__ __launch_bounds__(TPB) void k_pass_generic(const double* __restrict__ blk, long T, long nblocks, int NC,
+                                                      const double* __restrict__ cbq, int M,
+                                                      const DevScalars* __restrict__ sc,
+                                                      const u64* __restrict__ l1max_bits,
+                                                      unsigned short* __restrict__ sym, double* __restrict__ dmin,
+                                                      i64* __restrict__ rows)
+{
+    const int NPAD = (NC + 7) & ~7;
+    const int RS = (2 * NC + 5 + 7) & ~7;
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (TPB >> 6) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (TPB >> 6);
+    int sh_r = 0, sh_d = 0, sh_d2 = 0;
+    if (MODE != 0) {
+        sh_r = sc->sh_r;
+        const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
+        sh_d = 30 - Ed;
+        sh_d2 = 30 - 2 * Ed;
+    }
+    for (long b = wave; b < nblocks; b += nwaves) {
+        const double* fb = blk + b * (long)(NC * 64);
+        double best = __builtin_inf();
+        int bi = 0;
+        for (int m = 0; m < M; ++m) {
+            const double* c = cbq + (long)m * NPAD;
+            double d = fb[lane] * c[0];
+            for (int n = 1; n < NC; ++n) d = __builtin_fma(fb[n * 64 + lane], c[n], d);
+            const bool lt = d < best;
+            best = lt ? d : best;
+            bi = lt ? m : bi;
+        }
+        const long t = b * 64 + lane;
+        if (t < T) {
+            if (sym) sym[t] = (unsigned short)bi;
+            if (dmin) dmin[t] = best;
+            if (MODE != 0) {
+                i64* row = rows + (long)bi * RS;
+                for (int n = 0; n < NC; ++n) {
+                    int hi, lo;
+                    fix2(fb[n * 64 + lane], sh_r, hi, lo);
+                    atomicAdd((u64*)&row[2 * n], (u64)(i64)hi);
+                    atomicAdd((u64*)&row[2 * n + 1], (u64)(i64)lo);
+                }
+                const double e = best - 1.0;
+                int hi, lo;
+                atomicAdd((u64*)&row[2 * NC], 1ull);
+                fix2(e, sh_d, hi, lo);
+                atomicAdd((u64*)&row[2 * NC + 1], (u64)(i64)hi);
+                atomicAdd((u64*)&row[2 * NC + 2], (u64)(i64)lo);
+                fix2(e * e, sh_d2, hi, lo);
+                atomicAdd((u64*)&row[2 * NC + 3], (u64)(i64)hi);
+                atomicAdd((u64*)&row[2 * NC + 4], (u64)(i64)lo);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-level statistics from the (all-reduced) rows
+// ------------------------------------------------------------------------------------------
+// lstats (i64): [0] dist_hi [1] dist_lo [2] dist2_hi [3] dist2_lo [4] empty cells [5] failed cells
+__global__ void k_rows_stats(const i64* __restrict__ rows, int M, int NC, const DevScalars* __restrict__ sc,
+                             double* __restrict__ S, double* __restrict__ within, i64* __restrict__ lstats)
+{
+    const int RS = (2 * NC + 5 + 7) & ~7;
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const i64* row = rows + (long)m * RS;
+    const int sh_r = sc->sh_r;
+    atomicAdd((u64*)&lstats[0], (u64)row[2 * NC + 1]);
+    atomicAdd((u64*)&lstats[1], (u64)row[2 * NC + 2]);
+    atomicAdd((u64*)&lstats[2], (u64)row[2 * NC + 3]);
+    atomicAdd((u64*)&lstats[3], (u64)row[2 * NC + 4]);
+    const i64 cnt = row[2 * NC];
+    if (cnt == 0) {
+        atomicAdd((u64*)&lstats[4], 1ull);
+        within[m] = 0.0;
+        return;
+    }
+    double ss = 0.0;
+    for (int n = 0; n < NC; ++n) {
+        const double s = unfix(row[2 * n], row[2 * n + 1], sh_r);
+        S[(long)m * NC + n] = s;
+        ss += s * s;
+    }
+    within[m] = ss / (double)cnt;
+}
+
+// Levinson-Durbin from autocorrelation; src/lpc/lpca_r_rs.rs:8-43.  a[] is scratch.
+__device__ int lpca_r(int P, const double* r, double* rc, double* a)
+{
+    const double r0 = r[0];
+    if (0.0 == r0) return 1;
+    double pe = r0;
+    a[0] = 1.0;
+    for (int k = 1; k <= P; ++k) {
+        double sum = 0.0;
+        for (int i = 1; i <= k; ++i) sum -= a[k - i] * r[i];
+        const double akk = sum / pe;
+        rc[k] = akk;
+        a[k] = akk;
+        for (int i = 1; i <= (k >> 1); ++i) {
+            const double ai = a[i];
+            const double aj = a[k - i];
+            a[i] = ai + akk * aj;
+            a[k - i] = aj + akk * ai;
+        }
+        pe *= 1.0 - akk * akk;
+        if (pe <= 0.0) return 2;
+    }
+    return 0;
+}
+
+// K3: cell sums -> reflections (non-empty cells whose recursion succeeds; others keep theirs)
+__global__ void k_centroids(const i64* __restrict__ rows, const double* __restrict__ S, int M, int NC,
+                            double* __restrict__ reflections, i64* __restrict__ lstats)
+{
+    const int RS = (2 * NC + 5 + 7) & ~7;
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    if (rows[(long)m * RS + 2 * NC] == 0) return;
+    double rc[E2VQ_MAX_P + 1], a[E2VQ_MAX_P + 1];
+    const int P = NC - 1;
+    if (lpca_r(P, S + (long)m * NC, rc, a) != 0) {
+        atomicAdd((u64*)&lstats[5], 1ull);
+        return;
+    }
+    double* dst = reflections + (long)m * NC;
+    dst[0] = 0.0;
+    for (int n = 1; n <= P; ++n) dst[n] = rc[n];
+}
+
+// the M = 1 codeword from the global sums
+__global__ void k_init_codebook(const i64* __restrict__ stats, int NC, const DevScalars* __restrict__ sc,
+                                double* __restrict__ reflections, int* __restrict__ status)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double S[E2VQ_MAX_P + 1], rc[E2VQ_MAX_P + 1], a[E2VQ_MAX_P + 1];
+    for (int n = 0; n < NC; ++n) S[n] = unfix(stats[2 * n], stats[2 * n + 1], sc->sh_r);
+    const int st = lpca_r(NC - 1, S, rc, a);
+    *status = st;
+    if (st != 0) return;
+    reflections[0] = 0.0;
+    for (int n = 1; n < NC; ++n) reflections[n] = rc[n];
+}
+
+// sum-of-squares limbs -> Q (runs after the SUM all-reduce of the data statistics)
+__global__ void k_finish_q(const i64* __restrict__ stats, int NC, DevScalars* __restrict__ sc)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) sc->Q = unfix(stats[2 * NC], stats[2 * NC + 1], sc->sh_q);
+}
+
+// K4a: M -> 2M split, in place from the top (new[2i] = old[i]*0.99, new[2i+1] = old[i]*1.01)
+__global__ void k_grow(const double* __restrict__ old_refl, int M, int NC, double* __restrict__ new_refl)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * NC) return;
+    const int m = i / NC, n = i - m * NC;
+    const double v = old_refl[i];
+    new_refl[(long)(2 * m) * NC + n] = n == 0 ? 0.0 : v * 0.99;
+    new_refl[(long)(2 * m + 1) * NC + n] = n == 0 ? 0.0 : v * 1.01;
+}
+
+// K4b: reflections -> predictor (step-up) -> raas -> pre-doubled padded codeword rows; L1 max
+__global__ void k_codebook_prepare(const double* __restrict__ reflections, int M, int NC, double* __restrict__ cbq,
+                                   u64* __restrict__ l1max_bits)
+{
+    const int NPAD = (NC + 7) & ~7;
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int P = NC - 1;
+    double a[E2VQ_MAX_P + 1];
+    const double* rc = reflections + (long)m * NC;
+    a[0] = 1.0;
+    for (int k = 1; k <= P; ++k) {
+        const double akk = rc[k];
+        a[k] = akk;
+        for (int i = 1; i <= (k >> 1); ++i) {
+            const double ai = a[i];
+            const double aj = a[k - i];
+            a[i] = ai + akk * aj;
+            a[k - i] = aj + akk * ai;
+        }
+    }
+    double* dst = cbq + (long)m * NPAD;
+    double l1 = 0.0;
+    for (int n = 0; n <= P; ++n) {
+        double s = 0.0;
+        for (int i = 0; i <= P - n; ++i) s += a[i] * a[i + n];
+        const double c = n == 0 ? s : 2.0 * s;
+        dst[n] = c;
+        l1 += fabs(c);
+    }
+    for (int n = NC; n < NPAD; ++n) dst[n] = 0.0;
+    atomicMax(l1max_bits, (u64)__double_as_longlong(l1));
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+
+static inline int grid_for(long work_items, int per_block, int cap)
+{
+    long g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+void launch_blockify(const double* aos, long T, int NC, int FB, double* blk, long nblocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_blockify, dim3(grid_for(nblocks * NC * FB, 256, 8192)), dim3(256), 0, s, aos, T, NC, FB, blk,
+                       nblocks);
+}
+
+void launch_maxabs(const double* blk, long count, u64* out_bits, int* bad, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_maxabs, dim3(grid_for(count, 256 * 8, 4096)), dim3(256), 0, s, blk, count, out_bits, bad);
+}
+
+void launch_finish_scalars(const u64* maxabs_bits, DevScalars* sc, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_finish_scalars, dim3(1), dim3(64), 0, s, maxabs_bits, sc);
+}
+
+void launch_global_sums(const double* blk, long nblocks, int NC, int FB, const DevScalars* sc, i64* stats,
+                        hipStream_t s)
+{
+    hipLaunchKernelGGL(k_global_sums, dim3(grid_for(nblocks * NC, 4, 4096)), dim3(256), 0, s, blk, nblocks, NC, FB, sc,
+                       stats);
+}
+
+int frames_per_lane(int NC)
+{
+    return NC == 37 ? 2 : 1;
+}
+
+bool has_register_kernel(int NC)
+{
+    return NC == 37 || NC == 13 || NC == 17 || NC == 21 || NC == 25;
+}
+
+int lds_mode_max_M(int NC)
+{
+    const int RS = (2 * NC + 5 + 7) & ~7;
+    return (int)((E2VQ_LDS_BYTES - 1024) / ((long)RS * 8));
+}
+
+template <int NC, int F>
+static int launch_pass_t(int mode, const double* blk, long T, long nblocks, const double* cbq, int M,
+                         const DevScalars* sc, const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows,
+                         hipStream_t s)
+{
+    constexpr int RS = (2 * NC + 5 + 7) & ~7;
+    constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
+    const int waves_per_block = TPB / 64;
+    if (mode == 0) {
+        const int grid = grid_for(nblocks, waves_per_block, 2048);
+        hipLaunchKernelGGL((k_pass<NC, F, 0>), dim3(grid), dim3(TPB), 0, s, blk, T, nblocks, cbq, M, sc, l1max_bits,
+                           sym, dmin, rows);
+    } else if (mode == 1) {
+        const size_t lds = (size_t)M * RS * 8;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)k_pass<NC, F, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      E2VQ_LDS_BYTES);
+            attr_set = true;
+        }
+        // persistent: few workgroups so the per-workgroup table flush stays small
+        const int grid = grid_for(nblocks, waves_per_block, 512);
+        hipLaunchKernelGGL((k_pass<NC, F, 1>), dim3(grid), dim3(TPB), lds, s, blk, T, nblocks, cbq, M, sc, l1max_bits,
+                           sym, dmin, rows);
+    } else {
+        const size_t lds = (size_t)waves_per_block * 32 * IMG * 4;
+        const int grid = grid_for(nblocks, waves_per_block, 2048);
+        hipLaunchKernelGGL((k_pass<NC, F, 2>), dim3(grid), dim3(TPB), lds, s, blk, T, nblocks, cbq, M, sc, l1max_bits,
+                           sym, dmin, rows);
+    }
+    return 0;
+}
+
+int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const double* cbq, int M,
+                const DevScalars* sc, const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows,
+                hipStream_t s)
+{
+    switch (NC) {
+        case 37: return launch_pass_t<37, 2>(mode, blk, T, nblocks, cbq, M, sc, l1max_bits, sym, dmin, rows, s);
+        case 13: return launch_pass_t<13, 1>(mode, blk, T, nblocks, cbq, M, sc, l1max_bits, sym, dmin, rows, s);
+        case 17: return launch_pass_t<17, 1>(mode, blk, T, nblocks, cbq, M, sc, l1max_bits, sym, dmin, rows, s);
+        case 21: return launch_pass_t<21, 1>(mode, blk, T, nblocks, cbq, M, sc, l1max_bits, sym, dmin, rows, s);
+        case 25: return launch_pass_t<25, 1>(mode, blk, T, nblocks, cbq, M, sc, l1max_bits, sym, dmin, rows, s);
+        default: break;
+    }
+    // generic: 64 frames per block, global atomics for the accumulation
+    const int grid = grid_for(nblocks, TPB / 64, 2048);
+    if (mode == 0)
+        hipLaunchKernelGGL((k_pass_generic<0>), dim3(grid), dim3(TPB), 0, s, blk, T, nblocks, NC, cbq, M, sc,
+                           l1max_bits, sym, dmin, rows);
+    else
+        hipLaunchKernelGGL((k_pass_generic<2>), dim3(grid), dim3(TPB), 0, s, blk, T, nblocks, NC, cbq, M, sc,
+                           l1max_bits, sym, dmin, rows);
+    return 0;
+}
+
+void launch_rows_stats(const i64* rows, int M, int NC, const DevScalars* sc, double* S, double* within, i64* lstats,
+                       hipStream_t s)
+{
+    hipLaunchKernelGGL(k_rows_stats, dim3((M + 63) / 64), dim3(64), 0, s, rows, M, NC, sc, S, within, lstats);
+}
+
+void launch_centroids(const i64* rows, const double* S, int M, int NC, double* reflections, i64* lstats,
+                      hipStream_t s)
+{
+    hipLaunchKernelGGL(k_centroids, dim3((M + 63) / 64), dim3(64), 0, s, rows, S, M, NC, reflections, lstats);
+}
+
+void launch_finish_q(const i64* stats, int NC, DevScalars* sc, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_finish_q, dim3(1), dim3(64), 0, s, stats, NC, sc);
+}
+
+void launch_init_codebook(const i64* stats, int NC, const DevScalars* sc, double* reflections, int* status,
+                          hipStream_t s)
+{
+    hipLaunchKernelGGL(k_init_codebook, dim3(1), dim3(64), 0, s, stats, NC, sc, reflections, status);
+}
+
+void launch_grow(const double* old_refl, int M, int NC, double* new_refl, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_grow, dim3((M * NC + 255) / 256), dim3(256), 0, s, old_refl, M, NC, new_refl);
+}
+
+void launch_codebook_prepare(const double* reflections, int M, int NC, double* cbq, u64* l1max_bits, hipStream_t s)
+{
+    (void)hipMemsetAsync(l1max_bits, 0, sizeof(u64), s);
+    hipLaunchKernelGGL(k_codebook_prepare, dim3((M + 63) / 64), dim3(64), 0, s, reflections, M, NC, cbq, l1max_bits);
+}
+
+}  // namespace e2vq

@@ -1,0 +1,702 @@
+// vq_host.cpp -- host side of libecoz2vq.so: resident-data session, LBG driver and the
+// reference's entry points (include/ecoz2_vq.h).  All arithmetic of the hot path runs in
+// the HIP kernels of vq_device.hip; the host only sequences launches, reads a few scalars
+// per pass to take the convergence decision the reference takes on the CPU
+// (loop shape: /root/reference/notes.md:122-153), and does file I/O.
+#include "../../include/ecoz2_vq.h"
+#include "vq_device.h"
+#include "vq_fixed.h"
+#include "vq_io.h"
+
+#include <hip/hip_runtime.h>
+
+#include <float.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+using e2vq::DevScalars;
+typedef long long i64;
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+int e2vq_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "ecoz2vq: ERROR: %s\n", g_err);
+    return 1;
+}
+
+extern "C" const char* e2vq_last_error(void) { return g_err; }
+
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return e2vq_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char* ecoz2_version(void) { return "ecoz2vq-mi355x 0.1.0 (HIP gfx950)"; }
+
+extern "C" int e2vq_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// session
+// ------------------------------------------------------------------------------------------
+struct e2vq_session {
+    int device = 0, P = 0, NC = 0, F = 1, FB = 64, RS = 0, NPAD = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // training set (blocked layout)
+    double* d_blk = nullptr;
+    i64 T = 0, nblocks = 0, T_total = 0;
+    bool prepared = false;
+    // codebook
+    int M = 0, M_cap = 0;
+    double* d_refl = nullptr;      // current reflections [M][NC]
+    double* d_refl_next = nullptr; // grow target
+    double* d_cbq = nullptr;       // [M][NPAD] pre-doubled raas rows
+    u64* d_l1max = nullptr;
+    // statistics
+    DevScalars* d_sc = nullptr;
+    DevScalars h_sc{};
+    u64* d_maxabs = nullptr;
+    int* d_flags = nullptr;   // [0] bad data, [1] init status
+    i64* d_stats = nullptr;   // [2NC+3]: global sums, sum sq limbs, T
+    i64* d_rows = nullptr;    // [M][RS]
+    double* d_S = nullptr;    // [M][NC]
+    double* d_within = nullptr;
+    i64* d_lstats = nullptr;  // [8]
+    bool stats_valid = false;
+    e2vq_level_stats last{};
+    double DDprv = DBL_MAX / 1e5;  // "e+303" in notes.md:128
+    // quantize scratch
+    double* d_qaos = nullptr;
+    double* d_qblk = nullptr;
+    unsigned short* d_qsym = nullptr;
+    double* d_qdmin = nullptr;
+    i64 q_cap = 0;
+    // collective hook
+    e2vq_allreduce_fn allreduce = nullptr;
+    void* ar_user = nullptr;
+    int rank = 0, world = 1;
+};
+
+static int ensure_codebook_capacity(e2vq_session* s, int M)
+{
+    if (M <= s->M_cap) return 0;
+    int cap = std::max(M, std::max(2 * s->M_cap, 64));
+    HIPCHK(hipSetDevice(s->device));
+    double *refl, *refl_next, *cbq, *S, *within;
+    i64* rows;
+    HIPCHK(hipMalloc(&refl, (size_t)cap * s->NC * 8));
+    HIPCHK(hipMalloc(&refl_next, (size_t)cap * s->NC * 8));
+    HIPCHK(hipMalloc(&cbq, (size_t)cap * s->NPAD * 8 + 512));
+    HIPCHK(hipMalloc(&S, (size_t)cap * s->NC * 8));
+    HIPCHK(hipMalloc(&within, (size_t)cap * 8));
+    HIPCHK(hipMalloc(&rows, (size_t)cap * s->RS * 8));
+    if (s->M > 0) {
+        HIPCHK(hipMemcpyAsync(refl, s->d_refl, (size_t)s->M * s->NC * 8, hipMemcpyDeviceToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(cbq, s->d_cbq, (size_t)s->M * s->NPAD * 8, hipMemcpyDeviceToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    (void)hipFree(s->d_refl);
+    (void)hipFree(s->d_refl_next);
+    (void)hipFree(s->d_cbq);
+    (void)hipFree(s->d_S);
+    (void)hipFree(s->d_within);
+    (void)hipFree(s->d_rows);
+    s->d_refl = refl;
+    s->d_refl_next = refl_next;
+    s->d_cbq = cbq;
+    s->d_S = S;
+    s->d_within = within;
+    s->d_rows = rows;
+    s->M_cap = cap;
+    return 0;
+}
+
+extern "C" int e2vq_session_create(int device, int prediction_order, e2vq_session** out)
+{
+    *out = nullptr;
+    if (prediction_order < 1 || prediction_order > E2VQ_MAX_P)
+        return e2vq_set_error("prediction order %d out of range [1, %d]", prediction_order, E2VQ_MAX_P);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return e2vq_set_error("no HIP device available (%s); this library has no CPU path",
+                              e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return e2vq_set_error("device %d not in [0, %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    e2vq_session* s = new e2vq_session();
+    s->device = device;
+    s->P = prediction_order;
+    s->NC = prediction_order + 1;
+    s->F = e2vq::frames_per_lane(s->NC);
+    s->FB = 64 * s->F;
+    s->RS = e2vq::row_stride(s->NC);
+    s->NPAD = e2vq::cb_pad(s->NC);
+    HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    s->stream = s->own_stream;
+    HIPCHK(hipMalloc(&s->d_sc, sizeof(DevScalars)));
+    HIPCHK(hipMalloc(&s->d_maxabs, 8));
+    HIPCHK(hipMalloc(&s->d_l1max, 8));
+    HIPCHK(hipMalloc(&s->d_flags, 2 * sizeof(int)));
+    HIPCHK(hipMalloc(&s->d_stats, (size_t)(2 * s->NC + 3) * 8));
+    HIPCHK(hipMalloc(&s->d_lstats, 8 * 8));
+    HIPCHK(hipMemset(s->d_sc, 0, sizeof(DevScalars)));
+    *out = s;
+    return 0;
+}
+
+extern "C" void e2vq_session_destroy(e2vq_session* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    void* ptrs[] = {s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
+                    s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
+                    s->d_qdmin};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+    delete s;
+}
+
+extern "C" int e2vq_set_stream(e2vq_session* s, void* hip_stream)
+{
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+    return 0;
+}
+
+extern "C" int e2vq_set_allreduce(e2vq_session* s, e2vq_allreduce_fn fn, void* user, int rank, int world)
+{
+    s->allreduce = fn;
+    s->ar_user = user;
+    s->rank = rank;
+    s->world = fn ? world : 1;
+    return 0;
+}
+
+extern "C" int e2vq_synchronize(e2vq_session* s)
+{
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+static int reduce(e2vq_session* s, void* buf, i64 count, int op)
+{
+    if (s->world <= 1 || !s->allreduce) return 0;
+    const int rc = s->allreduce(s->ar_user, buf, count, op, (void*)s->stream);
+    if (rc != 0) return e2vq_set_error("all-reduce hook failed (%d)", rc);
+    return 0;
+}
+
+// ---- training set ------------------------------------------------------------------------
+
+extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames, int64_t T)
+{
+    if (T < 1) return e2vq_set_error("empty training set");
+    HIPCHK(hipSetDevice(s->device));
+    if (s->d_blk) HIPCHK(hipFree(s->d_blk));
+    s->d_blk = nullptr;
+    s->T = T;
+    s->nblocks = (T + s->FB - 1) / s->FB;
+    HIPCHK(hipMalloc(&s->d_blk, (size_t)s->nblocks * s->NC * s->FB * 8));
+    e2vq::launch_blockify((const double*)device_frames, T, s->NC, s->FB, s->d_blk, s->nblocks, s->stream);
+    HIPCHK(hipGetLastError());
+    s->prepared = false;
+    s->stats_valid = false;
+    return 0;
+}
+
+extern "C" int e2vq_set_frames_host(e2vq_session* s, const double* frames, int64_t T)
+{
+    if (T < 1) return e2vq_set_error("empty training set");
+    HIPCHK(hipSetDevice(s->device));
+    double* tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, (size_t)T * s->NC * 8));
+    HIPCHK(hipMemcpyAsync(tmp, frames, (size_t)T * s->NC * 8, hipMemcpyHostToDevice, s->stream));
+    int rc = e2vq_set_frames_device(s, tmp, T);
+    hipError_t e = hipStreamSynchronize(s->stream);
+    (void)hipFree(tmp);
+    if (rc) return rc;
+    if (e != hipSuccess) return e2vq_set_error("upload failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int e2vq_prepare(e2vq_session* s)
+{
+    if (!s->d_blk) return e2vq_set_error("no training set");
+    HIPCHK(hipSetDevice(s->device));
+    const long count = (long)s->nblocks * s->NC * s->FB;
+    HIPCHK(hipMemsetAsync(s->d_maxabs, 0, 8, s->stream));
+    HIPCHK(hipMemsetAsync(s->d_flags, 0, 2 * sizeof(int), s->stream));
+    e2vq::launch_maxabs(s->d_blk, count, s->d_maxabs, s->d_flags, s->stream);
+    if (reduce(s, s->d_maxabs, 1, 1)) return 1;
+    e2vq::launch_finish_scalars(s->d_maxabs, s->d_sc, s->stream);
+    HIPCHK(hipMemsetAsync(s->d_stats, 0, (size_t)(2 * s->NC + 3) * 8, s->stream));
+    e2vq::launch_global_sums(s->d_blk, s->nblocks, s->NC, s->FB, s->d_sc, s->d_stats, s->stream);
+    const i64 Tl = s->T;
+    HIPCHK(hipMemcpyAsync(s->d_stats + 2 * s->NC + 2, &Tl, 8, hipMemcpyHostToDevice, s->stream));
+    if (reduce(s, s->d_stats, 2 * s->NC + 3, 0)) return 1;
+    e2vq::launch_finish_q(s->d_stats, s->NC, s->d_sc, s->stream);
+    int flags[2];
+    i64 Ttot = 0;
+    HIPCHK(hipMemcpyAsync(flags, s->d_flags, sizeof flags, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(&Ttot, s->d_stats + 2 * s->NC + 2, 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(&s->h_sc, s->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipGetLastError());
+    if (flags[0]) return e2vq_set_error("training set contains NaN or infinite values");
+    if (!(s->h_sc.maxabs > 0.0)) return e2vq_set_error("training set is all zeros");
+    s->T_total = Ttot;
+    s->prepared = true;
+    s->DDprv = DBL_MAX / 1e5;
+    return 0;
+}
+
+// ---- codebook ----------------------------------------------------------------------------
+
+static int codebook_prepare(e2vq_session* s)
+{
+    e2vq::launch_codebook_prepare(s->d_refl, s->M, s->NC, s->d_cbq, s->d_l1max, s->stream);
+    HIPCHK(hipGetLastError());
+    s->stats_valid = false;
+    return 0;
+}
+
+extern "C" int e2vq_set_codebook(e2vq_session* s, const double* reflections, int M)
+{
+    if (M < 1 || M > 65536) return e2vq_set_error("codebook size %d out of range", M);
+    HIPCHK(hipSetDevice(s->device));
+    if (ensure_codebook_capacity(s, M)) return 1;
+    HIPCHK(hipMemcpyAsync(s->d_refl, reflections, (size_t)M * s->NC * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->M = M;
+    return codebook_prepare(s);
+}
+
+extern "C" int e2vq_get_codebook(e2vq_session* s, double* reflections, int* M)
+{
+    HIPCHK(hipSetDevice(s->device));
+    if (M) *M = s->M;
+    if (reflections && s->M > 0) {
+        HIPCHK(hipMemcpyAsync(reflections, s->d_refl, (size_t)s->M * s->NC * 8, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    return 0;
+}
+
+extern "C" int e2vq_init_codebook(e2vq_session* s)
+{
+    if (!s->prepared) return e2vq_set_error("e2vq_prepare has not run");
+    HIPCHK(hipSetDevice(s->device));
+    if (ensure_codebook_capacity(s, 2)) return 1;
+    e2vq::launch_init_codebook(s->d_stats, s->NC, s->d_sc, s->d_refl, s->d_flags + 1, s->stream);
+    int st = 0;
+    HIPCHK(hipMemcpyAsync(&st, s->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (st != 0) return e2vq_set_error("Levinson recursion failed on the global centroid (status %d)", st);
+    s->M = 1;
+    return codebook_prepare(s);
+}
+
+extern "C" int e2vq_grow(e2vq_session* s)
+{
+    if (s->M < 1) return e2vq_set_error("no codebook to grow");
+    if (2 * s->M > 65536) return e2vq_set_error("codebook size limit (u16 symbols) reached");
+    HIPCHK(hipSetDevice(s->device));
+    if (ensure_codebook_capacity(s, 2 * s->M)) return 1;
+    e2vq::launch_grow(s->d_refl, s->M, s->NC, s->d_refl_next, s->stream);
+    std::swap(s->d_refl, s->d_refl_next);
+    s->M *= 2;
+    return codebook_prepare(s);
+}
+
+// ---- LBG iteration pieces ------------------------------------------------------------------
+
+static int pass_mode(const e2vq_session* s)
+{
+    if (!e2vq::has_register_kernel(s->NC)) return 2;
+    return s->M <= e2vq::lds_mode_max_M(s->NC) && s->M <= 128 ? 1 : 2;
+}
+
+extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
+{
+    if (!s->prepared) return e2vq_set_error("e2vq_prepare has not run");
+    if (s->M < 1) return e2vq_set_error("no codebook");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemsetAsync(s->d_rows, 0, (size_t)s->M * s->RS * 8, s->stream));
+    e2vq::launch_pass(s->NC, pass_mode(s), s->d_blk, s->T, s->nblocks, s->d_cbq, s->M, s->d_sc, s->d_l1max,
+                      (unsigned short*)device_sym, (double*)device_dmin, s->d_rows, s->stream);
+    HIPCHK(hipGetLastError());
+    if (reduce(s, s->d_rows, (i64)s->M * s->RS, 0)) return 1;
+    s->stats_valid = false;
+    return 0;
+}
+
+extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
+{
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemsetAsync(s->d_lstats, 0, 8 * 8, s->stream));
+    e2vq::launch_rows_stats(s->d_rows, s->M, s->NC, s->d_sc, s->d_S, s->d_within, s->d_lstats, s->stream);
+    i64 l[8];
+    u64 l1bits = 0;
+    std::vector<double> within((size_t)s->M);
+    HIPCHK(hipMemcpyAsync(l, s->d_lstats, sizeof l, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(&l1bits, s->d_l1max, 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(within.data(), s->d_within, (size_t)s->M * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipGetLastError());
+    double l1max;
+    memcpy(&l1max, &l1bits, 8);
+    const int Ed = e2vq::dist_exponent(s->h_sc.maxabs, l1max);
+    const double DD = e2vq::unfix(l[0], l[1], 30 - Ed);
+    const double SS = e2vq::unfix(l[2], l[3], 30 - 2 * Ed);
+    const double T = (double)s->T_total;
+    const double avg = DD / T;
+    const double q = SS / T;
+    const double p = avg * avg;
+    double v = q - p;
+    if (!(v > 0.0)) v = 0.0;
+    double w = 0.0;
+    for (int m = 0; m < s->M; ++m) w += within[m];  // empty cells contribute +0.0
+    s->last.M = s->M;
+    s->last.DD = DD;
+    s->last.avg_distortion = avg;
+    s->last.sigma = sqrt(v);
+    s->last.inertia = s->h_sc.Q - w;
+    s->last.empty_cells = l[4];
+    s->stats_valid = true;
+    if (out) *out = s->last;
+    return 0;
+}
+
+extern "C" int e2vq_update(e2vq_session* s)
+{
+    if (!s->stats_valid) {
+        if (e2vq_pass_stats(s, nullptr)) return 1;
+    }
+    HIPCHK(hipSetDevice(s->device));
+    e2vq::launch_centroids(s->d_rows, s->d_S, s->M, s->NC, s->d_refl, s->d_lstats, s->stream);
+    HIPCHK(hipGetLastError());
+    return codebook_prepare(s);
+}
+
+extern "C" int e2vq_row_stride(int prediction_order) { return e2vq::row_stride(prediction_order + 1); }
+
+extern "C" int e2vq_get_rows(e2vq_session* s, int64_t* rows)
+{
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemcpyAsync(rows, s->d_rows, (size_t)s->M * s->RS * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+// ---- LBG ladder ------------------------------------------------------------------------------
+
+extern "C" int e2vq_learn(e2vq_session* s, double epsilon, int max_M, const char* class_name, const char* out_root,
+                          void* target, ecoz2_vq_learn_callback_t callback, e2vq_level_stats* levels, int max_levels,
+                          int* num_levels)
+{
+    if (num_levels) *num_levels = 0;
+    if (!s->prepared) return e2vq_set_error("e2vq_prepare has not run");
+    if (s->M < 1) return e2vq_set_error("no codebook: call e2vq_init_codebook or e2vq_set_codebook");
+    const bool verbose = getenv("ECOZ2_VQ_QUIET") == nullptr && s->rank == 0;
+    const bool write_files = out_root != nullptr && s->rank == 0;
+    FILE* rpt = nullptr;
+    char path[4096];
+    if (write_files) {
+        snprintf(path, sizeof path, "%s/data/codebooks/%s/eps_%g.rpt", out_root, class_name, epsilon);
+        if (e2vq_io::mkdirs_for(path) == 0) rpt = fopen(path, "w");
+        if (rpt)
+            fprintf(rpt,
+                    "# %lld training vectors, P=%d, eps=%g\n# M passes DD avg_distortion sigma inertia empty_cells\n",
+                    (long long)s->T_total, s->P, epsilon);
+        if (verbose) printf("Report: %s\n", path);
+    }
+    std::vector<double> refl;
+    int nlev = 0;
+    while (s->M < max_M) {
+        if (e2vq_grow(s)) return 1;
+        if (write_files) {
+            snprintf(path, sizeof path, "%s/data/codebooks/%s/eps_%g_M_%04d.cbook", out_root, class_name, epsilon,
+                     s->M);
+            if (verbose) printf("%s\n", path);
+        }
+        e2vq_level_stats ls{};
+        int pass = 0;
+        for (;; ++pass) {
+            if (e2vq_pass(s, nullptr, nullptr)) return 1;
+            if (e2vq_pass_stats(s, &ls)) return 1;
+            const double DD = ls.DD;
+            const double ratio = (s->DDprv - DD) / DD;
+            if (verbose) {
+                printf("(%d)\tDP=%g\tDDprv=%g\tDD=%g\t%g\n", pass, ls.avg_distortion, s->DDprv, DD, ratio);
+                if (ls.empty_cells > 0)
+                    printf("WARN: review_cells: %lld empty cell(s) for codebook size %d)\n", (long long)ls.empty_cells,
+                           s->M);
+            }
+            // pass 0 never ends a level; DDprv carries over between levels (notes.md:128-153)
+            const bool converged = pass > 0 && !(ratio >= epsilon);
+            s->DDprv = DD;
+            if (converged) break;
+            if (e2vq_update(s)) return 1;
+        }
+        ls.passes = pass + 1;
+        if (write_files) {
+            refl.resize((size_t)s->M * s->NC);
+            if (e2vq_get_codebook(s, refl.data(), nullptr)) return 1;
+            if (e2vq_cbook_write(path, class_name, s->P, s->M, refl.data())) return 1;
+            if (rpt)
+                fprintf(rpt, "%d %d %.17g %.17g %.17g %.17g %lld\n", s->M, ls.passes, ls.DD, ls.avg_distortion,
+                        ls.sigma, ls.inertia, (long long)ls.empty_cells);
+        }
+        if (levels && nlev < max_levels) levels[nlev] = ls;
+        ++nlev;
+        if (callback && s->rank == 0) callback(target, s->M, ls.avg_distortion, ls.sigma, ls.inertia);
+    }
+    if (rpt) fclose(rpt);
+    if (num_levels) *num_levels = nlev;
+    return 0;
+}
+
+// ---- quantize --------------------------------------------------------------------------------
+
+static int ensure_quantize_scratch(e2vq_session* s, i64 T, bool need_aos, bool need_out)
+{
+    if (T <= s->q_cap && (!need_aos || s->d_qaos) && (!need_out || s->d_qsym)) return 0;
+    HIPCHK(hipSetDevice(s->device));
+    const i64 cap = std::max<i64>(T, s->q_cap);
+    const i64 nb = (cap + s->FB - 1) / s->FB;
+    if (cap > s->q_cap || !s->d_qblk) {
+        if (s->d_qblk) (void)hipFree(s->d_qblk);
+        HIPCHK(hipMalloc(&s->d_qblk, (size_t)nb * s->NC * s->FB * 8));
+        if (s->d_qaos) { (void)hipFree(s->d_qaos); s->d_qaos = nullptr; }
+        if (s->d_qsym) { (void)hipFree(s->d_qsym); s->d_qsym = nullptr; }
+        if (s->d_qdmin) { (void)hipFree(s->d_qdmin); s->d_qdmin = nullptr; }
+    }
+    if (need_aos && !s->d_qaos) HIPCHK(hipMalloc(&s->d_qaos, (size_t)cap * s->NC * 8));
+    if (need_out && !s->d_qsym) {
+        HIPCHK(hipMalloc(&s->d_qsym, (size_t)cap * 2 + 64));
+        HIPCHK(hipMalloc(&s->d_qdmin, (size_t)cap * 8));
+    }
+    s->q_cap = cap;
+    return 0;
+}
+
+extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, int64_t T, void* device_sym,
+                                    void* device_dmin)
+{
+    if (s->M < 1) return e2vq_set_error("no codebook");
+    if (T < 1) return 0;
+    HIPCHK(hipSetDevice(s->device));
+    if (ensure_quantize_scratch(s, T, false, false)) return 1;
+    const i64 nb = (T + s->FB - 1) / s->FB;
+    e2vq::launch_blockify((const double*)device_frames, T, s->NC, s->FB, s->d_qblk, nb, s->stream);
+    e2vq::launch_pass(s->NC, 0, s->d_qblk, T, nb, s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
+                      (double*)device_dmin, nullptr, s->stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int e2vq_quantize_host(e2vq_session* s, const double* frames, int64_t T, uint16_t* sym, double* dmin)
+{
+    if (s->M < 1) return e2vq_set_error("no codebook");
+    HIPCHK(hipSetDevice(s->device));
+    const i64 CH = 1 << 22;  // frames per chunk (1.2 GB of predictor vectors)
+    for (i64 t0 = 0; t0 < T; t0 += CH) {
+        const i64 n = std::min<i64>(CH, T - t0);
+        if (ensure_quantize_scratch(s, n, true, true)) return 1;
+        HIPCHK(hipMemcpyAsync(s->d_qaos, frames + (size_t)t0 * s->NC, (size_t)n * s->NC * 8, hipMemcpyHostToDevice,
+                              s->stream));
+        if (e2vq_quantize_device(s, s->d_qaos, n, s->d_qsym, dmin ? s->d_qdmin : nullptr)) return 1;
+        HIPCHK(hipMemcpyAsync(sym + t0, s->d_qsym, (size_t)n * 2, hipMemcpyDeviceToHost, s->stream));
+        if (dmin) HIPCHK(hipMemcpyAsync(dmin + t0, s->d_qdmin, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    return 0;
+}
+
+// ==========================================================================================
+// Part 1: the reference's entry points
+// ==========================================================================================
+
+static int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+static const char* env_str(const char* name, const char* dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? v : dflt;
+}
+
+// load every .prd (all must share P) into one host array, in the given order
+static int load_predictors(const char* const* files, int n, int P_expected, std::vector<double>& frames, i64* T_out,
+                           int* P_out)
+{
+    i64 total = 0;
+    int P = P_expected;
+    std::vector<i64> Ts((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        char cls[96];
+        int p;
+        int64_t t;
+        if (e2vq_prd_info(files[i], cls, &p, &t)) return 1;
+        if (P < 0) P = p;
+        if (p != P) return e2vq_set_error("%s: prediction order %d, expected %d", files[i], p, P);
+        Ts[(size_t)i] = t;
+        total += t;
+    }
+    if (total < 1) return e2vq_set_error("no training vectors");
+    frames.resize((size_t)total * (P + 1));
+    i64 off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (e2vq_prd_read(files[i], frames.data() + (size_t)off * (P + 1), Ts[(size_t)i])) return 1;
+        off += Ts[(size_t)i];
+    }
+    *T_out = total;
+    *P_out = P;
+    return 0;
+}
+
+static int learn_common(int P, double eps, const char* class_name, const double* base_refl, int base_M,
+                        const char* const* files, int n, void* target, ecoz2_vq_learn_callback_t cb)
+{
+    std::vector<double> frames;
+    i64 T = 0;
+    int Pf = 0;
+    if (load_predictors(files, n, P, frames, &T, &Pf)) return 1;
+    printf("Codebook generation:\n\n%lld training vectors (ε=%g)\n", (long long)T, eps);
+    e2vq_session* s = nullptr;
+    if (e2vq_session_create(env_int("ECOZ2_VQ_DEVICE", 0), P, &s)) return 1;
+    int rc = e2vq_set_frames_host(s, frames.data(), T);
+    std::vector<double>().swap(frames);
+    if (!rc) rc = e2vq_prepare(s);
+    if (!rc) rc = base_refl ? e2vq_set_codebook(s, base_refl, base_M) : e2vq_init_codebook(s);
+    if (!rc)
+        rc = e2vq_learn(s, eps, env_int("ECOZ2_VQ_MAX_CODEBOOK_SIZE", 2048), class_name,
+                        env_str("ECOZ2_VQ_OUT_ROOT", "."), target, cb, nullptr, 0, nullptr);
+    e2vq_session_destroy(s);
+    return rc;
+}
+
+extern "C" int ecoz2_vq_learn(int prediction_order, double epsilon, const char* codebook_class_name,
+                              const char* const* predictor_filenames, int num_predictors, void* target,
+                              ecoz2_vq_learn_callback_t callback)
+{
+    if (!codebook_class_name || !predictor_filenames || num_predictors < 1)
+        return e2vq_set_error("ecoz2_vq_learn: bad arguments");
+    return learn_common(prediction_order, epsilon, codebook_class_name, nullptr, 0, predictor_filenames,
+                        num_predictors, target, callback);
+}
+
+extern "C" int ecoz2_vq_learn_using_base_codebook(const char* base_codebook, double epsilon,
+                                                  const char* const* predictor_filenames, int num_predictors,
+                                                  void* target, ecoz2_vq_learn_callback_t callback)
+{
+    if (!base_codebook || !predictor_filenames || num_predictors < 1)
+        return e2vq_set_error("ecoz2_vq_learn_using_base_codebook: bad arguments");
+    char cls[96];
+    int P, M;
+    if (e2vq_cbook_info(base_codebook, cls, &P, &M)) return 1;
+    std::vector<double> refl((size_t)M * (P + 1));
+    if (e2vq_cbook_read(base_codebook, refl.data(), M)) return 1;
+    printf("base codebook: %s (class '%s', P=%d, M=%d)\n", base_codebook, cls, P, M);
+    return learn_common(P, epsilon, cls, refl.data(), M, predictor_filenames, num_predictors, target, callback);
+}
+
+extern "C" int ecoz2_vq_quantize(const char* nom_raas, const char* const* predictor_filenames, int num_predictors,
+                                 int show_filenames)
+{
+    if (!nom_raas || !predictor_filenames || num_predictors < 0) return e2vq_set_error("ecoz2_vq_quantize: bad arguments");
+    char cb_cls[96];
+    int P, M;
+    if (e2vq_cbook_info(nom_raas, cb_cls, &P, &M)) return 1;
+    std::vector<double> refl((size_t)M * (P + 1));
+    if (e2vq_cbook_read(nom_raas, refl.data(), M)) return 1;
+    e2vq_session* s = nullptr;
+    if (e2vq_session_create(env_int("ECOZ2_VQ_DEVICE", 0), P, &s)) return 1;
+    int rc = e2vq_set_codebook(s, refl.data(), M);
+    const char* root = env_str("ECOZ2_VQ_OUT_ROOT", ".");
+    std::vector<double> frames;
+    std::vector<uint16_t> sym;
+    std::vector<double> dmin;
+    double total_e = 0.0;
+    i64 total_T = 0;
+    for (int i = 0; i < num_predictors && !rc; ++i) {
+        char cls[96];
+        int p;
+        int64_t T;
+        rc = e2vq_prd_info(predictor_filenames[i], cls, &p, &T);
+        if (rc) break;
+        if (p != P) {
+            rc = e2vq_set_error("%s: prediction order %d differs from the codebook's %d", predictor_filenames[i], p, P);
+            break;
+        }
+        frames.resize((size_t)T * (P + 1));
+        sym.resize((size_t)T);
+        dmin.resize((size_t)T);
+        rc = e2vq_prd_read(predictor_filenames[i], frames.data(), T);
+        if (!rc && T > 0) rc = e2vq_quantize_host(s, frames.data(), T, sym.data(), dmin.data());
+        if (rc) break;
+        double e = 0.0;
+        for (i64 t = 0; t < T; ++t) e += dmin[(size_t)t] - 1.0;
+        total_e += e;
+        total_T += T;
+        const std::string base = e2vq_io::basename_noext(predictor_filenames[i]);
+        char path[4096];
+        snprintf(path, sizeof path, "%s/data/sequences/M%d/%s/%s.seq", root, M, cls, base.c_str());
+        rc = e2vq_seq_write(path, cls, M, sym.data(), T);
+        if (show_filenames)
+            printf("%s: '%s' T=%lld avg distortion=%g -> %s\n", predictor_filenames[i], cls, (long long)T,
+                   T ? e / (double)T : 0.0, path);
+    }
+    if (!rc)
+        printf("total: %d predictor file(s), %lld vectors, M=%d, avg distortion=%g\n", num_predictors,
+               (long long)total_T, M, total_T ? total_e / (double)total_T : 0.0);
+    e2vq_session_destroy(s);
+    return rc;
+}
+
+extern "C" int ecoz2_vq_show(const char* codebook_filename, int from, int to)
+{
+    char cls[96];
+    int P, M;
+    if (e2vq_cbook_info(codebook_filename, cls, &P, &M)) return 1;
+    std::vector<double> refl((size_t)M * (P + 1));
+    if (e2vq_cbook_read(codebook_filename, refl.data(), M)) return 1;
+    if (from < 0) from = 1;
+    if (to < 0 || to > P) to = P;
+    printf("# %s:\n# className='%s', M=%d, P=%d\n", codebook_filename, cls, M, P);
+    for (int n = from; n <= to; ++n) printf("%sk%d", n == from ? "" : ",", n);
+    printf("\n");
+    for (int m = 0; m < M; ++m) {
+        for (int n = from; n <= to; ++n) printf("%s%g", n == from ? "" : ",", refl[(size_t)m * (P + 1) + n]);
+        printf("\n");
+    }
+    return 0;
+}

@@ -1,0 +1,353 @@
+// vq_io.cpp -- .prd / .cbook / .seq files, file-list resolution, synthetic predictor frames.
+//
+// Formats.  Every file starts with a 16-byte NUL-padded ident and a
+// 96-byte NUL-padded class name (FILE_IDENT_LEN / MAX_CLASS_NAME_LEN,
+// /root/reference/src/utl/mod.rs:19-20), then little-endian fields:
+//   .prd    "<predictor>"  u32 T, u32 P, T*(P+1) f64 (gain-normalised autocorrelations)
+//   .cbook  "<codebook>"   u32 P, u32 M, M*(P+1) f64 (reflection coefficients, [0] unused)
+//   .seq    "<sequence>"   u32 T, u32 M, T * u16 symbols      (src/sequence/mod.rs:49-75)
+#include "../../include/ecoz2_vq.h"
+#include "vq_io.h"
+
+#include <dirent.h>
+#include <errno.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <fstream>
+#include <sstream>
+#include <thread>
+
+namespace e2vq_io {
+
+int mkdirs_for(const char* path)
+{
+    std::string p(path);
+    for (size_t i = 1; i < p.size(); ++i) {
+        if (p[i] == '/') {
+            p[i] = 0;
+            if (mkdir(p.c_str(), 0777) != 0 && errno != EEXIST) return -1;
+            p[i] = '/';
+        }
+    }
+    return 0;
+}
+
+std::string basename_noext(const char* path)
+{
+    std::string p(path);
+    const size_t slash = p.find_last_of('/');
+    if (slash != std::string::npos) p = p.substr(slash + 1);
+    const size_t dot = p.find_last_of('.');
+    if (dot != std::string::npos && dot > 0) p = p.substr(0, dot);
+    return p;
+}
+
+static bool ends_with(const std::string& s, const char* ext)
+{
+    const size_t n = strlen(ext);
+    return s.size() >= n && s.compare(s.size() - n, n, ext) == 0;
+}
+
+static void walk(const std::string& dir, const char* ext, std::vector<std::string>& out)
+{
+    DIR* d = opendir(dir.c_str());
+    if (!d) return;
+    while (struct dirent* e = readdir(d)) {
+        if (!strcmp(e->d_name, ".") || !strcmp(e->d_name, "..")) continue;
+        const std::string p = dir + "/" + e->d_name;
+        struct stat st;
+        if (stat(p.c_str(), &st) != 0) continue;
+        if (S_ISDIR(st.st_mode))
+            walk(p, ext, out);
+        else if (S_ISREG(st.st_mode) && ends_with(p, ext))
+            out.push_back(p);
+    }
+    closedir(d);
+}
+
+int resolve_filenames(const std::vector<std::string>& given, const char* file_ext, std::vector<std::string>& out)
+{
+    out.clear();
+    for (const std::string& g : given) {
+        struct stat st;
+        if (stat(g.c_str(), &st) != 0) continue;
+        if (S_ISDIR(st.st_mode)) {
+            std::string dir = g;
+            while (dir.size() > 1 && dir.back() == '/') dir.pop_back();
+            walk(dir, file_ext, out);
+        } else if (S_ISREG(st.st_mode) && ends_with(g, file_ext)) {
+            out.push_back(g);
+        }
+    }
+    std::sort(out.begin(), out.end());
+    return 0;
+}
+
+static std::string replace_all(std::string s, const std::string& what, const std::string& with)
+{
+    for (size_t pos = 0; (pos = s.find(what, pos)) != std::string::npos; pos += with.size())
+        s.replace(pos, what.size(), with);
+    return s;
+}
+
+int files_from_csv(const std::string& csv, const std::string& tt, const std::string& class_name,
+                   const std::string& subdir, const char* file_ext, const std::string* subdir_template,
+                   std::vector<std::string>& out)
+{
+    std::ifstream in(csv);
+    if (!in) return e2vq_set_error("%s: cannot open", csv.c_str());
+    out.clear();
+    std::string line;
+    bool header = true;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty() || line[0] == '#') continue;
+        if (header) {  // first record is the header `tt,class,selection`
+            header = false;
+            continue;
+        }
+        std::stringstream ss(line);
+        std::string rtt, rclass, rsel;
+        if (!std::getline(ss, rtt, ',') || !std::getline(ss, rclass, ',') || !std::getline(ss, rsel, ',')) continue;
+        if (tt != rtt) continue;
+        if (!class_name.empty() && class_name != rclass) continue;
+        if (subdir_template)
+            out.push_back(replace_all(replace_all(*subdir_template, "{class}", rclass), "{selection}", rsel));
+        else
+            out.push_back("data/" + subdir + "/" + rclass + "/" + rsel + file_ext);
+    }
+    if (out.empty()) return e2vq_set_error("No %s given in given file", subdir.c_str());
+    return 0;
+}
+
+}  // namespace e2vq_io
+
+// ------------------------------------------------------------------------------------------
+namespace {
+
+void put_u32(FILE* f, uint32_t v)
+{
+    const unsigned char b[4] = {(unsigned char)v, (unsigned char)(v >> 8), (unsigned char)(v >> 16),
+                                (unsigned char)(v >> 24)};
+    fwrite(b, 1, 4, f);
+}
+
+bool get_u32(FILE* f, uint32_t* v)
+{
+    unsigned char b[4];
+    if (fread(b, 1, 4, f) != 4) return false;
+    *v = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+    return true;
+}
+
+void put_header(FILE* f, const char* ident, const char* class_name)
+{
+    char id[16] = {0}, cn[96] = {0};
+    strncpy(id, ident, sizeof id - 1);
+    strncpy(cn, class_name, sizeof cn - 1);
+    fwrite(id, 1, sizeof id, f);
+    fwrite(cn, 1, sizeof cn, f);
+}
+
+// 0 ok; message set otherwise
+int get_header(FILE* f, const char* path, const char* ident, const char* what, char class_name[96])
+{
+    char id[16];
+    if (fread(id, 1, sizeof id, f) != sizeof id) return e2vq_set_error("%s: truncated header", path);
+    if (strncmp(id, ident, strlen(ident)) != 0) return e2vq_set_error("%s: Not a %s", path, what);
+    if (fread(class_name, 1, 96, f) != 96) return e2vq_set_error("%s: truncated header", path);
+    class_name[95] = 0;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int e2vq_prd_info(const char* path, char class_name[96], int* P, int64_t* T)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return e2vq_set_error("%s: %s", path, strerror(errno));
+    uint32_t t = 0, p = 0;
+    int rc = get_header(f, path, "<predictor>", "predictor", class_name);
+    if (!rc && (!get_u32(f, &t) || !get_u32(f, &p))) rc = e2vq_set_error("%s: truncated header", path);
+    fclose(f);
+    if (rc) return rc;
+    *P = (int)p;
+    *T = (int64_t)t;
+    return 0;
+}
+
+extern "C" int e2vq_prd_read(const char* path, double* frames, int64_t capacity_frames)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return e2vq_set_error("%s: %s", path, strerror(errno));
+    char cls[96];
+    uint32_t t = 0, p = 0;
+    int rc = get_header(f, path, "<predictor>", "predictor", cls);
+    if (!rc && (!get_u32(f, &t) || !get_u32(f, &p))) rc = e2vq_set_error("%s: truncated header", path);
+    if (!rc && (int64_t)t > capacity_frames) rc = e2vq_set_error("%s: %u vectors exceed the buffer", path, t);
+    if (!rc && fread(frames, sizeof(double), (size_t)t * (p + 1), f) != (size_t)t * (p + 1))
+        rc = e2vq_set_error("%s: truncated payload", path);
+    fclose(f);
+    return rc;
+}
+
+extern "C" int e2vq_prd_write(const char* path, const char* class_name, int P, const double* frames, int64_t T)
+{
+    if (e2vq_io::mkdirs_for(path) != 0) return e2vq_set_error("%s: cannot create directories", path);
+    FILE* f = fopen(path, "wb");
+    if (!f) return e2vq_set_error("%s: %s", path, strerror(errno));
+    put_header(f, "<predictor>", class_name);
+    put_u32(f, (uint32_t)T);
+    put_u32(f, (uint32_t)P);
+    const size_t n = (size_t)T * (P + 1);
+    const bool ok = fwrite(frames, sizeof(double), n, f) == n;
+    if (fclose(f) != 0 || !ok) return e2vq_set_error("%s: write failed", path);
+    return 0;
+}
+
+extern "C" int e2vq_cbook_info(const char* path, char class_name[96], int* P, int* M)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return e2vq_set_error("%s: %s", path, strerror(errno));
+    uint32_t p = 0, m = 0;
+    int rc = get_header(f, path, "<codebook>", "codebook", class_name);
+    if (!rc && (!get_u32(f, &p) || !get_u32(f, &m))) rc = e2vq_set_error("%s: truncated header", path);
+    fclose(f);
+    if (rc) return rc;
+    if (p < 1 || p > 200 || m < 1 || m > 65536) return e2vq_set_error("%s: implausible P=%u M=%u", path, p, m);
+    *P = (int)p;
+    *M = (int)m;
+    return 0;
+}
+
+extern "C" int e2vq_cbook_read(const char* path, double* reflections, int capacity_codewords)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return e2vq_set_error("%s: %s", path, strerror(errno));
+    char cls[96];
+    uint32_t p = 0, m = 0;
+    int rc = get_header(f, path, "<codebook>", "codebook", cls);
+    if (!rc && (!get_u32(f, &p) || !get_u32(f, &m))) rc = e2vq_set_error("%s: truncated header", path);
+    if (!rc && (int)m > capacity_codewords) rc = e2vq_set_error("%s: %u codewords exceed the buffer", path, m);
+    if (!rc && fread(reflections, sizeof(double), (size_t)m * (p + 1), f) != (size_t)m * (p + 1))
+        rc = e2vq_set_error("%s: truncated payload", path);
+    fclose(f);
+    return rc;
+}
+
+extern "C" int e2vq_cbook_write(const char* path, const char* class_name, int P, int M, const double* reflections)
+{
+    if (e2vq_io::mkdirs_for(path) != 0) return e2vq_set_error("%s: cannot create directories", path);
+    FILE* f = fopen(path, "wb");
+    if (!f) return e2vq_set_error("%s: %s", path, strerror(errno));
+    put_header(f, "<codebook>", class_name);
+    put_u32(f, (uint32_t)P);
+    put_u32(f, (uint32_t)M);
+    const size_t n = (size_t)M * (P + 1);
+    const bool ok = fwrite(reflections, sizeof(double), n, f) == n;
+    if (fclose(f) != 0 || !ok) return e2vq_set_error("%s: write failed", path);
+    return 0;
+}
+
+extern "C" int e2vq_seq_write(const char* path, const char* class_name, int M, const uint16_t* sym, int64_t T)
+{
+    if (e2vq_io::mkdirs_for(path) != 0) return e2vq_set_error("%s: cannot create directories", path);
+    FILE* f = fopen(path, "wb");
+    if (!f) return e2vq_set_error("%s: %s", path, strerror(errno));
+    put_header(f, "<sequence>", class_name);
+    put_u32(f, (uint32_t)T);
+    put_u32(f, (uint32_t)M);
+    std::vector<unsigned char> buf((size_t)T * 2);
+    for (int64_t t = 0; t < T; ++t) {
+        buf[(size_t)2 * t] = (unsigned char)sym[t];
+        buf[(size_t)2 * t + 1] = (unsigned char)(sym[t] >> 8);
+    }
+    const bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    if (fclose(f) != 0 || !ok) return e2vq_set_error("%s: write failed", path);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic predictor frames: valid gain-normalised autocorrelation vectors.
+// class j prototype reflections k_j[i] ~ U(-0.7,0.7)*0.97^i; frame: k = clamp(k_j + noise, +-0.95),
+// noise ~ N(0, 0.05^2) approximated by a 12-uniform sum (pure arithmetic, no libm);
+// step-up k -> a, inverse Levinson with r0 = 1, then divide by E_P (src/lpc/lpc_rs.rs:125-131).
+// Counter based: frame t depends only on (seed, n_classes, P, t).
+// ------------------------------------------------------------------------------------------
+namespace {
+
+inline uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+inline double u01(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
+
+void synth_one(uint64_t seed, int n_classes, int P, int64_t t, double* r)
+{
+    const uint64_t ft = splitmix64(seed ^ splitmix64((uint64_t)t + 0x51ED270Bull));
+    const int cls = (int)(ft % (uint64_t)n_classes);
+    double k[201], a[201];
+    double decay = 1.0;
+    for (int i = 1; i <= P; ++i) {
+        decay *= 0.97;
+        const uint64_t hp = splitmix64(seed * 0x2545F4914F6CDD1Dull + (uint64_t)cls * 1000003ull + (uint64_t)i);
+        const double proto = (u01(hp) * 1.4 - 0.7) * decay;
+        double g = -6.0;
+        uint64_t h = splitmix64(ft + (uint64_t)i * 0xD1B54A32D192ED03ull);
+        for (int j = 0; j < 12; ++j) {
+            h = splitmix64(h);
+            g += u01(h);
+        }
+        double v = proto + 0.05 * g;
+        if (v > 0.95) v = 0.95;
+        if (v < -0.95) v = -0.95;
+        k[i] = v;
+    }
+    // inverse Levinson: r[0] = 1, E = 1
+    double E = 1.0;
+    r[0] = 1.0;
+    a[0] = 1.0;
+    for (int kk = 1; kk <= P; ++kk) {
+        const double akk = k[kk];
+        double s = 0.0;
+        for (int i = 1; i < kk; ++i) s += a[kk - i] * r[i];
+        r[kk] = -akk * E - s;
+        a[kk] = akk;
+        for (int i = 1; i <= (kk >> 1); ++i) {
+            const double ai = a[i], aj = a[kk - i];
+            a[i] = ai + akk * aj;
+            a[kk - i] = aj + akk * ai;
+        }
+        E *= 1.0 - akk * akk;
+    }
+    for (int n = 0; n <= P; ++n) r[n] /= E;
+}
+
+}  // namespace
+
+extern "C" int e2vq_synth_frames(uint64_t seed, int n_classes, int P, int64_t first, int64_t count, double* frames)
+{
+    if (n_classes < 1 || P < 1 || P > 200 || count < 0) return e2vq_set_error("e2vq_synth_frames: bad arguments");
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 32) nt = 32;
+    if ((int64_t)nt > count / 1024 + 1) nt = (unsigned)(count / 1024 + 1);
+    std::vector<std::thread> th;
+    for (unsigned w = 0; w < nt; ++w) {
+        th.emplace_back([=]() {
+            const int64_t a = count * w / nt, b = count * (w + 1) / nt;
+            for (int64_t i = a; i < b; ++i) synth_one(seed, n_classes, P, first + i, frames + (size_t)i * (P + 1));
+        });
+    }
+    for (auto& t : th) t.join();
+    return 0;
+}

@@ -1,0 +1,18 @@
+// vq_io.h -- file helpers shared by the host driver and the CLI (internal)
+#pragma once
+#include <string>
+#include <vector>
+
+int e2vq_set_error(const char* fmt, ...);
+
+namespace e2vq_io {
+int mkdirs_for(const char* path);
+std::string basename_noext(const char* path);
+// mirrors utl::resolve_filenames (/root/reference/src/utl/mod.rs:201-222): directories are
+// walked recursively, only names ending in file_ext are kept, the result is sorted
+int resolve_filenames(const std::vector<std::string>& given, const char* file_ext, std::vector<std::string>& out);
+// mirrors utl::get_files_from_csv (src/utl/mod.rs:143-193): rows `tt,class,selection`
+int files_from_csv(const std::string& csv, const std::string& tt, const std::string& class_name,
+                   const std::string& subdir, const char* file_ext, const std::string* subdir_template,
+                   std::vector<std::string>& out);
+}  // namespace e2vq_io

@@ -1,0 +1,207 @@
+"""Host-side mirror of the reference's VQ wrappers.
+
+``vq_learn`` / ``vq_quantize`` / ``vq_show`` take the arguments of the Rust functions of the same
+name (/root/reference/src/ecoz2_lib/mod.rs:252-368) and call the same C symbols.
+``VqSession`` wraps the resident-data session API (include/ecoz2_vq.h, part 2).
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._lib import ALLREDUCE_FN, LEARN_CALLBACK, LevelStatsC, c_char_pp, check, lib
+
+
+def version():
+    return lib.ecoz2_version().decode()
+
+
+def _to_vec_of_ptr_const_c_char(paths):
+    # to_vec_of_ptr_const_c_char, src/ecoz2_lib/mod.rs:530-543
+    arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+    return C.cast(arr, c_char_pp), arr
+
+
+def _observer(callback):
+    def step(_target, m, avg_distortion, sigma, inertia):
+        # Ecoz2ObserverRef::step, src/ecoz2_lib/mod.rs:61-69
+        print(f"   Ecoz2ObserverRef.step: M={m} avg_distortion={avg_distortion} sigma={sigma} inertia={inertia}")
+        if callback is not None:
+            callback(m, avg_distortion, sigma, inertia)
+
+    return LEARN_CALLBACK(step)
+
+
+def vq_learn(base_codebook_opt, prediction_order_opt, epsilon, codebook_class_name, predictor_filenames,
+             exp_key=None, callback=None):
+    """ecoz2_lib::vq_learn (src/ecoz2_lib/mod.rs:252-323). ``exp_key`` is accepted and ignored."""
+    assert (base_codebook_opt is not None) != (prediction_order_opt is not None)
+    print(f"vq_learn: base_codebook_opt={base_codebook_opt!r} prediction_order={prediction_order_opt!r}, "
+          f"epsilon={epsilon} codebook_class_name={codebook_class_name} "
+          f"predictor_filenames: {len(predictor_filenames)}")
+    files, _keep = _to_vec_of_ptr_const_c_char(predictor_filenames)
+    cb = _observer(callback)
+    if base_codebook_opt is not None:
+        rc = lib.ecoz2_vq_learn_using_base_codebook(str(base_codebook_opt).encode(), float(epsilon), files,
+                                                    len(predictor_filenames), None, cb)
+    else:
+        rc = lib.ecoz2_vq_learn(int(prediction_order_opt), float(epsilon), codebook_class_name.encode(), files,
+                                len(predictor_filenames), None, cb)
+    check(rc)
+
+
+def vq_quantize(nom_raas, predictor_filenames, show_filenames=False):
+    """ecoz2_lib::vq_quantize (src/ecoz2_lib/mod.rs:325-342)."""
+    print(f"nom_raas = {nom_raas}")
+    files, _keep = _to_vec_of_ptr_const_c_char(predictor_filenames)
+    check(lib.ecoz2_vq_quantize(str(nom_raas).encode(), files, len(predictor_filenames), int(show_filenames)))
+
+
+def vq_show(codebook_filename, from_=-1, to=-1):
+    """ecoz2_lib::vq_show (src/ecoz2_lib/mod.rs:360-368)."""
+    print(f"codebook_filename = {codebook_filename}")
+    check(lib.ecoz2_vq_show(str(codebook_filename).encode(), int(from_), int(to)))
+
+
+@dataclass
+class LevelStats:
+    M: int
+    passes: int
+    DD: float
+    avg_distortion: float
+    sigma: float
+    inertia: float
+    empty_cells: int
+    failed_cells: int
+
+    @classmethod
+    def from_c(cls, c):
+        return cls(c.M, c.passes, c.DD, c.avg_distortion, c.sigma, c.inertia, c.empty_cells, c.failed_cells)
+
+
+def _ptr(x):
+    """Device pointer of a torch tensor / int address / None."""
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return int(x)
+
+
+class VqSession:
+    """One resident training set + codebook on one GPU (one rank of a sharded run)."""
+
+    def __init__(self, prediction_order, device=0):
+        self.P = int(prediction_order)
+        self._h = C.c_void_p()
+        check(lib.e2vq_session_create(int(device), self.P, C.byref(self._h)))
+        self._ar = None
+
+    def close(self):
+        if self._h:
+            lib.e2vq_session_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- plumbing -------------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        check(lib.e2vq_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def set_allreduce(self, fn, rank, world):
+        """fn(device_ptr:int, count:int, op:int, stream:int) -> None; op 0 = int64 sum, 1 = uint64 max."""
+
+        def tramp(_user, buf, count, op, stream):
+            try:
+                fn(int(buf or 0), int(count), int(op), int(stream or 0))
+                return 0
+            except Exception as e:  # never unwind across the C boundary
+                print(f"all-reduce hook raised: {e!r}")
+                return 1
+
+        self._ar = ALLREDUCE_FN(tramp)
+        check(lib.e2vq_set_allreduce(self._h, self._ar, None, int(rank), int(world)))
+
+    def synchronize(self):
+        check(lib.e2vq_synchronize(self._h))
+
+    # -- training set -----------------------------------------------------------------
+    def set_frames(self, frames):
+        """frames: (T, P+1) float64 numpy array, or a CUDA/HIP torch tensor of that shape."""
+        if hasattr(frames, "data_ptr"):
+            assert frames.is_contiguous() and frames.shape[1] == self.P + 1
+            check(lib.e2vq_set_frames_device(self._h, frames.data_ptr(), frames.shape[0]))
+        else:
+            a = np.ascontiguousarray(frames, dtype=np.float64)
+            assert a.ndim == 2 and a.shape[1] == self.P + 1
+            check(lib.e2vq_set_frames_host(self._h, a.ctypes.data, a.shape[0]))
+
+    def prepare(self):
+        check(lib.e2vq_prepare(self._h))
+
+    # -- codebook ---------------------------------------------------------------------
+    def set_codebook(self, reflections):
+        a = np.ascontiguousarray(reflections, dtype=np.float64)
+        assert a.ndim == 2 and a.shape[1] == self.P + 1
+        check(lib.e2vq_set_codebook(self._h, a.ctypes.data, a.shape[0]))
+
+    def codebook_size(self):
+        m = C.c_int()
+        check(lib.e2vq_get_codebook(self._h, None, C.byref(m)))
+        return m.value
+
+    def get_codebook(self):
+        out = np.empty((self.codebook_size(), self.P + 1), dtype=np.float64)
+        check(lib.e2vq_get_codebook(self._h, out.ctypes.data, None))
+        return out
+
+    def init_codebook(self):
+        check(lib.e2vq_init_codebook(self._h))
+
+    def grow(self):
+        check(lib.e2vq_grow(self._h))
+
+    # -- LBG iteration ------------------------------------------------------------------
+    def run_pass(self, device_sym=None, device_dmin=None):
+        check(lib.e2vq_pass(self._h, _ptr(device_sym), _ptr(device_dmin)))
+
+    def pass_stats(self):
+        st = LevelStatsC()
+        check(lib.e2vq_pass_stats(self._h, C.byref(st)))
+        return LevelStats.from_c(st)
+
+    def update(self):
+        check(lib.e2vq_update(self._h))
+
+    def get_rows(self):
+        rs = lib.e2vq_row_stride(self.P)
+        out = np.empty((self.codebook_size(), rs), dtype=np.int64)
+        check(lib.e2vq_get_rows(self._h, out.ctypes.data))
+        return out
+
+    def learn(self, epsilon, max_M, class_name="_", out_root=None, callback=None):
+        levels = (LevelStatsC * 32)()
+        n = C.c_int()
+        cb = LEARN_CALLBACK((lambda _t, m, a, s, i: callback(m, a, s, i)) if callback else (lambda *_: None))
+        check(lib.e2vq_learn(self._h, float(epsilon), int(max_M), class_name.encode(),
+                             out_root.encode() if out_root else None, None, cb, levels, 32, C.byref(n)))
+        return [LevelStats.from_c(levels[i]) for i in range(min(n.value, 32))]
+
+    # -- quantize -------------------------------------------------------------------------
+    def quantize(self, frames, want_dmin=True):
+        a = np.ascontiguousarray(frames, dtype=np.float64)
+        assert a.ndim == 2 and a.shape[1] == self.P + 1
+        sym = np.empty(a.shape[0], dtype=np.uint16)
+        dmin = np.empty(a.shape[0], dtype=np.float64) if want_dmin else None
+        check(lib.e2vq_quantize_host(self._h, a.ctypes.data, a.shape[0], sym.ctypes.data,
+                                     dmin.ctypes.data if want_dmin else None))
+        return (sym, dmin) if want_dmin else sym
+
+    def quantize_device(self, device_frames, T, device_sym, device_dmin=None):
+        check(lib.e2vq_quantize_device(self._h, _ptr(device_frames), int(T), _ptr(device_sym), _ptr(device_dmin)))

@@ -1,0 +1,156 @@
+/*
+ * ecoz2_vq.h -- C-ABI of libecoz2vq.so: the MI355X-native drop-in for the VQ hot path of
+ * mbari-org/ecoz2rs (`ecoz2 vq learn` / `ecoz2 vq quantize`).
+ *
+ * Part 1 declares exactly the symbols the reference's Rust FFI binds for this path
+ * (extern "C" block, /root/reference/src/ecoz2_lib/mod.rs:72-178), with the same argument
+ * order and meaning, so the reference's front-end can link this library in place of the
+ * static `ecoz2_lib` that build.rs:59-77 compiles.  Part 2 is the resident-data session
+ * API the same entry points are built on; bench.py, the tests and multi-GPU runs use it.
+ *
+ * Plain pointers and sizes only; no HIP or torch types.  All compute runs in hand-written
+ * HIP kernels on the GPU; there is no CPU fallback: every entry point fails (non-zero
+ * return + message on stderr, e2vq_last_error()) when no HIP device is usable.
+ */
+#ifndef ECOZ2_VQ_H
+#define ECOZ2_VQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ========================================================================================
+ * Part 1 -- the reference's FFI surface for this path
+ * ====================================================================================== */
+
+/* replaces `fn ecoz2_version() -> *const c_char`            src/ecoz2_lib/mod.rs:73 */
+const char *ecoz2_version(void);
+
+/* Per-codebook-size callback: (target, M, avg_distortion, sigma, inertia).
+ * `callback: extern "C" fn(*mut Ecoz2ObserverRef, c_int, c_double, c_double, c_double)`
+ *                                                            src/ecoz2_lib/mod.rs:104, 241-250
+ * `target` is opaque here and handed back unchanged as argument 0. */
+typedef void (*ecoz2_vq_learn_callback_t)(void *target, int M, double avg_distortion,
+                                          double sigma, double inertia);
+
+/* replaces `fn ecoz2_vq_learn(prediction_order, epsilon, codebook_class_name,
+ *           predictor_filenames, num_predictors, target, callback)`
+ *                                                            src/ecoz2_lib/mod.rs:96-105
+ * LBG training over all frames of the given .prd files, M = 2, 4, ... ; writes
+ * data/codebooks/<class>/eps_<eps>_M_<%04d>.cbook (+ .rpt) under the working directory
+ * and invokes the callback once per codebook size, on the calling thread.
+ * The Rust declaration has no return value; the int returned here is ignored by that
+ * caller (ABI-safe) and is 0 on success. All strings are borrowed for the call. */
+int ecoz2_vq_learn(int prediction_order, double epsilon, const char *codebook_class_name,
+                   const char *const *predictor_filenames, int num_predictors, void *target,
+                   ecoz2_vq_learn_callback_t callback);
+
+/* replaces `fn ecoz2_vq_learn_using_base_codebook(base_codebook, epsilon,
+ *           predictor_filenames, num_predictors, target, callback)`
+ *                                                            src/ecoz2_lib/mod.rs:107-115
+ * Same, starting from a saved codebook of size M0: the first trained size is 2*M0
+ * (CHANGELOG.md:366-368). P and the class name come from the base codebook. */
+int ecoz2_vq_learn_using_base_codebook(const char *base_codebook, double epsilon,
+                                       const char *const *predictor_filenames,
+                                       int num_predictors, void *target,
+                                       ecoz2_vq_learn_callback_t callback);
+
+/* replaces `fn ecoz2_vq_quantize(nom_raas, predictor_filenames, num_predictors,
+ *           show_filenames)`                                  src/ecoz2_lib/mod.rs:117-122
+ * Per .prd file: nearest-codeword symbol per frame -> data/sequences/M<M>/<class>/<name>.seq
+ * (layout pinned by src/sequence/mod.rs:49-75). */
+int ecoz2_vq_quantize(const char *nom_raas, const char *const *predictor_filenames,
+                      int num_predictors, int show_filenames);
+
+/* replaces `fn ecoz2_vq_show(codebook_filename, from, to)`   src/ecoz2_lib/mod.rs:132
+ * Prints the reflection coefficients [from, to] of every codeword (-1 = whole range). */
+int ecoz2_vq_show(const char *codebook_filename, int from, int to);
+
+/* Knobs the reference has no argument for (environment):
+ *   ECOZ2_VQ_MAX_CODEBOOK_SIZE  last codebook size trained (default 2048, notes.md:147)
+ *   ECOZ2_VQ_DEVICE             HIP device ordinal (default 0)
+ *   ECOZ2_VQ_OUT_ROOT           prefix for data/... outputs (default ".")               */
+
+/* ========================================================================================
+ * Part 2 -- session API (resident training set, one session per GPU / per rank)
+ * ====================================================================================== */
+
+typedef struct e2vq_session e2vq_session;
+
+typedef struct {
+    int M;                /* codebook size of this level                              */
+    int passes;           /* assignment passes run at this level                      */
+    double DD;            /* sum over frames of (min distortion - 1), last pass       */
+    double avg_distortion;/* DD / T                                                   */
+    double sigma;         /* std deviation of (min distortion - 1)                    */
+    double inertia;       /* sum ||r - cell mean||^2 in autocorrelation space         */
+    int64_t empty_cells;
+    int64_t failed_cells; /* cells whose Levinson recursion failed in the last update */
+} e2vq_level_stats;
+
+/* Collective hook for N > 1 ranks: reduce `count` 64-bit integers in place on the device,
+ * enqueued on `stream` (a hipStream_t). op 0 = sum (int64), 1 = max (uint64).
+ * bench.py passes a torch.distributed (RCCL) all_reduce here. */
+typedef int (*e2vq_allreduce_fn)(void *user, void *device_buf, int64_t count, int op, void *stream);
+
+const char *e2vq_last_error(void);
+int e2vq_device_count(void);
+
+int e2vq_session_create(int device, int prediction_order, e2vq_session **out);
+void e2vq_session_destroy(e2vq_session *s);
+/* use an existing hipStream_t (e.g. torch's current stream); NULL = the session's own */
+int e2vq_set_stream(e2vq_session *s, void *hip_stream);
+int e2vq_set_allreduce(e2vq_session *s, e2vq_allreduce_fn fn, void *user, int rank, int world);
+
+/* training set: T x (P+1) doubles, row-major (the .prd payload). Copies / re-lays it out in HBM. */
+int e2vq_set_frames_host(e2vq_session *s, const double *frames, int64_t T);
+int e2vq_set_frames_device(e2vq_session *s, const void *device_frames, int64_t T);
+/* data statistics (max |x|, global sums, sum of squares) incl. the cross-rank reduction */
+int e2vq_prepare(e2vq_session *s);
+
+/* codebook state (reflection coefficients, M x (P+1), row-major) */
+int e2vq_set_codebook(e2vq_session *s, const double *reflections, int M);
+int e2vq_get_codebook(e2vq_session *s, double *reflections, int *M);
+int e2vq_init_codebook(e2vq_session *s); /* M = 1 centroid of the whole set */
+int e2vq_grow(e2vq_session *s);          /* M -> 2M split                   */
+
+/* one LBG iteration, in pieces: assignment+accumulation (+ all-reduce), statistics, update.
+ * device_sym / device_dmin: optional device buffers of T uint16 / T doubles (NULL to skip). */
+int e2vq_pass(e2vq_session *s, void *device_sym, void *device_dmin);
+int e2vq_pass_stats(e2vq_session *s, e2vq_level_stats *out);
+int e2vq_update(e2vq_session *s);
+/* the reduced accumulator rows of the last pass (M x row_stride int64) copied to the host */
+int e2vq_row_stride(int prediction_order);
+int e2vq_get_rows(e2vq_session *s, int64_t *rows);
+
+/* whole LBG ladder from the current codebook up to max_M. out_root NULL = no files. */
+int e2vq_learn(e2vq_session *s, double epsilon, int max_M, const char *class_name,
+               const char *out_root, void *target, ecoz2_vq_learn_callback_t callback,
+               e2vq_level_stats *levels, int max_levels, int *num_levels);
+
+/* nearest-codeword assignment of arbitrary frames against the session's codebook */
+int e2vq_quantize_host(e2vq_session *s, const double *frames, int64_t T, uint16_t *sym,
+                       double *dmin);
+int e2vq_quantize_device(e2vq_session *s, const void *device_frames, int64_t T, void *device_sym,
+                         void *device_dmin);
+int e2vq_synchronize(e2vq_session *s);
+
+/* ---- files (.prd / .cbook / .seq) and synthetic data ------------------------------------- */
+int e2vq_prd_info(const char *path, char class_name[96], int *P, int64_t *T);
+int e2vq_prd_read(const char *path, double *frames, int64_t capacity_frames);
+int e2vq_prd_write(const char *path, const char *class_name, int P, const double *frames, int64_t T);
+int e2vq_cbook_info(const char *path, char class_name[96], int *P, int *M);
+int e2vq_cbook_read(const char *path, double *reflections, int capacity_codewords);
+int e2vq_cbook_write(const char *path, const char *class_name, int P, int M, const double *reflections);
+int e2vq_seq_write(const char *path, const char *class_name, int M, const uint16_t *sym, int64_t T);
+
+/* Synthetic gain-normalised autocorrelation frames [first, first+count) of the stream
+ * (seed, n_classes): counter-based, so any shard regenerates identical frames. */
+int e2vq_synth_frames(uint64_t seed, int n_classes, int P, int64_t first, int64_t count, double *frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

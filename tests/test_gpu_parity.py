@@ -1,0 +1,96 @@
+"""GPU parity: the HIP path, called through the C-ABI, against the CPU oracle -- bit-exact."""
+import numpy as np
+import pytest
+
+import ecoz2rs_amd as e
+
+pytestmark = pytest.mark.gpu
+
+P = 36
+
+
+def _frames(seed, T, classes=8):
+    return e.synth.synth_frames(seed, classes, P, 0, T)
+
+
+def _codebook(oracle, frames, M, seed=0):
+    """A plausible codebook: reflections of M random frames (lpca_r on their autocorrelation)."""
+    rng = np.random.default_rng(seed)
+    idx = rng.choice(frames.shape[0], size=M, replace=False)
+    refl = np.zeros((M, P + 1))
+    for i, t in enumerate(idx):
+        st, _pe, rc, _a = oracle.lpca_r(frames[t], P)
+        assert st == 0
+        refl[i, 1:] = rc[1:]
+    return refl
+
+
+@pytest.mark.parametrize("T,M", [(1000, 2), (4096, 16), (5000, 64), (10000, 128), (7777, 256), (20000, 1024)])
+def test_quantize_bit_exact(oracle, T, M):
+    frames = _frames(20243, T)
+    refl = _codebook(oracle, frames, M)
+    cq = oracle.reflections_to_cq(refl)
+    sym_o, dmin_o = oracle.quantize(cq, frames)
+    with e.VqSession(P) as s:
+        s.set_codebook(refl)
+        sym, dmin = s.quantize(frames)
+    assert np.array_equal(sym, sym_o)
+    assert np.array_equal(dmin.view(np.uint64), dmin_o.view(np.uint64))
+
+
+@pytest.mark.parametrize("T,M", [(1000, 2), (4096, 16), (10000, 128), (7777, 256), (20000, 1024)])
+def test_pass_rows_bit_exact(oracle, T, M):
+    """One LBG pass: per-cell exact sums, counts and distortion sums equal the oracle's."""
+    frames = _frames(20242, T)
+    refl = _codebook(oracle, frames, M, seed=1)
+    cq = oracle.reflections_to_cq(refl)
+    rc, st = oracle.data_stats(frames)
+    assert rc == 0
+    sh_r, sh_q = oracle.shifts(st.maxabs)
+    Ed = oracle.dist_exponent(cq, st.maxabs)
+    _sym_o, _dmin_o, rows_o = oracle.run_pass(cq, frames, sh_r, Ed)
+    Q = oracle.unfix(st.q_hi, st.q_lo, sh_q)
+    ls_o = oracle.rows_stats(rows_o, P, T, sh_r, Ed, Q)
+    refl_o, _failed = oracle.update(rows_o, P, sh_r, refl)
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.set_codebook(refl)
+        s.run_pass()
+        rows = s.get_rows()
+        ls = s.pass_stats()
+        s.update()
+        refl_g = s.get_codebook()
+    assert np.array_equal(rows, rows_o)
+    assert ls.DD == ls_o.DD and ls.avg_distortion == ls_o.avg and ls.sigma == ls_o.sigma
+    assert ls.inertia == ls_o.inertia and ls.empty_cells == ls_o.empty_cells
+    assert np.array_equal(refl_g.view(np.uint64), refl_o.view(np.uint64))
+
+
+@pytest.mark.parametrize("T,maxM", [(10000, 16), (30000, 256)])
+def test_learn_ladder_bit_exact(oracle, T, maxM, tmp_path):
+    """Whole LBG ladder: every level's codebook, pass count and callback scalars equal the oracle's."""
+    frames = _frames(20241, T, classes=4)
+    rc, levels_o, cbs_o = oracle.learn(frames, 0.05, maxM)
+    assert rc == 0
+    cbs = []
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        got = []
+
+        def cb(M, avg, sigma, inertia):
+            cbs.append((M, avg, sigma, inertia))
+            got.append(s.get_codebook())
+
+        levels = s.learn(0.05, maxM, out_root=str(tmp_path), callback=cb)
+    assert [l.M for l in levels] == [l["M"] for l in levels_o]
+    assert [l.passes for l in levels] == [l["passes"] for l in levels_o]
+    for g, o in zip(got, levels_o):
+        assert np.array_equal(g.view(np.uint64), o["reflections"].view(np.uint64))
+    assert cbs == cbs_o
+    # files written by the product read back identical to the oracle's codebooks
+    for o in levels_o:
+        _cls, _P, refl = e.formats.read_cbook(str(tmp_path / "data" / "codebooks" / "_" / f"eps_0.05_M_{o['M']:04d}.cbook"))
+        assert np.array_equal(refl.view(np.uint64), o["reflections"].view(np.uint64))
