@@ -93,6 +93,9 @@ struct e2vq_session {
     unsigned short* d_qsym = nullptr;
     double* d_qdmin = nullptr;
     i64 q_cap = 0;
+    // HIP events around the sweep kernel (bench.py's roofline figures)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false, timed = false;
     // collective hook
     e2vq_allreduce_fn allreduce = nullptr;
     void* ar_user = nullptr;
@@ -162,6 +165,8 @@ extern "C" int e2vq_session_create(int device, int prediction_order, e2vq_sessio
     HIPCHK(hipMalloc(&s->d_stats, (size_t)(2 * s->NC + 3) * 8));
     HIPCHK(hipMalloc(&s->d_lstats, 8 * 8));
     HIPCHK(hipMemset(s->d_sc, 0, sizeof(DevScalars)));
+    HIPCHK(hipEventCreate(&s->ev0));
+    HIPCHK(hipEventCreate(&s->ev1));
     *out = s;
     return 0;
 }
@@ -176,6 +181,8 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
                     s->d_qdmin};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     delete s;
 }
@@ -347,11 +354,31 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     if (s->M < 1) return e2vq_set_error("no codebook");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipMemsetAsync(s->d_rows, 0, (size_t)s->M * s->RS * 8, s->stream));
+    if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
     e2vq::launch_pass(s->NC, pass_mode(s), s->d_blk, s->T, s->nblocks, s->d_cbq, s->M, s->d_sc, s->d_l1max,
                       (unsigned short*)device_sym, (double*)device_dmin, s->d_rows, s->stream);
+    if (s->timing) {
+        HIPCHK(hipEventRecord(s->ev1, s->stream));
+        s->timed = true;
+    }
     HIPCHK(hipGetLastError());
     if (reduce(s, s->d_rows, (i64)s->M * s->RS, 0)) return 1;
     s->stats_valid = false;
+    return 0;
+}
+
+extern "C" int e2vq_enable_timing(e2vq_session* s, int on)
+{
+    s->timing = on != 0;
+    s->timed = false;
+    return 0;
+}
+
+extern "C" int e2vq_last_pass_kernel_ms(e2vq_session* s, float* ms)
+{
+    if (!s->timed) return e2vq_set_error("no timed pass recorded");
+    HIPCHK(hipEventSynchronize(s->ev1));
+    HIPCHK(hipEventElapsedTime(ms, s->ev0, s->ev1));
     return 0;
 }
 

@@ -179,6 +179,14 @@ class VqSession:
     def update(self):
         check(lib.e2vq_update(self._h))
 
+    def enable_timing(self, on=True):
+        check(lib.e2vq_enable_timing(self._h, int(on)))
+
+    def last_pass_kernel_ms(self):
+        ms = C.c_float()
+        check(lib.e2vq_last_pass_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
     def get_rows(self):
         rs = lib.e2vq_row_stride(self.P)
         out = np.empty((self.codebook_size(), rs), dtype=np.int64)

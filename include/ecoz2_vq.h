@@ -120,6 +120,9 @@ int e2vq_grow(e2vq_session *s);          /* M -> 2M split                   */
  * device_sym / device_dmin: optional device buffers of T uint16 / T doubles (NULL to skip). */
 int e2vq_pass(e2vq_session *s, void *device_sym, void *device_dmin);
 int e2vq_pass_stats(e2vq_session *s, e2vq_level_stats *out);
+/* HIP events around the sweep kernel of e2vq_pass, on the session's stream */
+int e2vq_enable_timing(e2vq_session *s, int on);
+int e2vq_last_pass_kernel_ms(e2vq_session *s, float *ms);
 int e2vq_update(e2vq_session *s);
 /* the reduced accumulator rows of the last pass (M x row_stride int64) copied to the host */
 int e2vq_row_stride(int prediction_order);
