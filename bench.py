@@ -51,8 +51,16 @@ def cpu_baseline(e, np):
         _st, _pe, rc, _a = strict.lpca_r(frames[i * 7], P)
         refl[i, 1:] = rc[1:]
     cq = strict.reflections_to_cq(refl)
-    secs, threads = fast.time_pass(cq, frames[:4096], 1)  # calibrate
-    rate = 4096 / max(secs, 1e-9)
+    # the box's CPU share is smaller than the visible core count: pick the thread count that runs fastest
+    ncpu = len(os.sched_getaffinity(0))
+    best_rate, best_nt = 0.0, 1
+    for nt in sorted({1, 8, 16, 32, 64, ncpu} & set(range(1, ncpu + 1))):
+        fast.set_threads(nt)
+        secs, _ = fast.time_pass(cq, frames[:8192], 1)
+        if 8192 / secs > best_rate:
+            best_rate, best_nt = 8192 / secs, nt
+    fast.set_threads(best_nt)
+    rate = best_rate
     n = int(min(frames.shape[0], max(4096, rate * 1.5)))
     reps = max(1, int(round(12.0 * rate / n)))
     secs, threads = fast.time_pass(cq, frames[:n], reps)
@@ -178,10 +186,10 @@ def main():
                 "ladder_seconds_untimed": round(t_ladder, 3),
                 "final_avg_distortion": st.avg_distortion,
             },
-            # the sweep is FP64-FMA bound (248 flop/B); on MI355X the FP64 vector and matrix peaks coincide
+            # the sweep is FP64-FMA bound (248 flop/B): useful flops 2*M*(P+1) per frame against the 78.6 TF FP64 peak
             "roofline": {
                 "bound": "mfma",
-                "kernel": "k_pass<37,2,2> (sweep + accumulate, v_fma_f64 on the VALU; no MFMA by design)",
+                "kernel": "k_pass_mfma<37,2,256> (sweep on v_mfma_f64_16x16x4_f64 + argmin + exact accumulate)",
                 "achieved": achieved_tf,
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",

@@ -18,6 +18,8 @@ struct DevScalars {
 inline int row_stride(int NC) { return (2 * NC + 5 + 7) & ~7; }
 inline int cb_pad(int NC) { return (NC + 7) & ~7; }
 
+bool uses_mfma(int NC);            // P = 36: the sweep runs on the FP64 matrix pipe
+inline long cbm_doubles(int NC, int M) { return (long)((M + 15) / 16) * ((((NC + 3) / 4) + 1) / 2) * 128; }
 int frames_per_lane(int NC);       // F of the kernel that will serve this NC (block = 64*F frames)
 bool has_register_kernel(int NC);
 int lds_mode_max_M(int NC);        // largest M whose accumulator table fits LDS
@@ -28,8 +30,8 @@ void launch_finish_scalars(const unsigned long long* maxabs_bits, DevScalars* sc
 void launch_global_sums(const double* blk, long nblocks, int NC, int FB, const DevScalars* sc, long long* stats,
                         hipStream_t s);
 // mode 0 assign only, 1 LDS accumulators, 2 global atomics
-int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const double* cbq, int M,
-                const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
+int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const double* cbq, const double* cbm,
+                int M, const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                 long long* rows, hipStream_t s);
 void launch_rows_stats(const long long* rows, int M, int NC, const DevScalars* sc, double* S, double* within,
                        long long* lstats, hipStream_t s);
@@ -40,6 +42,6 @@ void launch_init_codebook(const long long* stats, int NC, const DevScalars* sc, 
                           hipStream_t s);
 void launch_grow(const double* old_refl, int M, int NC, double* new_refl, hipStream_t s);
 void launch_codebook_prepare(const double* reflections, int M, int NC, double* cbq, unsigned long long* l1max_bits,
-                             hipStream_t s);
+                             double* cbm, hipStream_t s);
 
 }  // namespace e2vq

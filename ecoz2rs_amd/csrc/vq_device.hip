@@ -8,12 +8,16 @@
 //   K4  codebook   reflections -> raas -> pre-doubled codewords; M -> 2M split
 //
 // Design notes (measured on MI355X):
-//  * FP64-FMA bound at M >= 64.  Lane = frame; a frame's P+1 coefficients live in VGPRs
-//    for the whole sweep; codewords are wave-uniform and stream through SGPRs
-//    (s_load_dwordx16 from a 64B-aligned padded row), so each v_fmac_f64 takes its
-//    codeword operand from an SGPR pair: no LDS/VGPR bandwidth for the broadcast.
-//  * Training frames are resident in HBM in a blocked-transposed layout
-//    [block][n][64*F] so a wave's loads are fully coalesced 16 B/lane.
+//  * FP64-FMA bound at M >= 64.  The canonical distortion chain
+//        acc = +0.0; for n = 0..P: acc = fma(r[n], c[n], acc)
+//    is bit-for-bit what v_mfma_f64_16x16x4_f64 computes along k (verified on hardware:
+//    tools/probe/mfma64.hip), and on real data the FP64 matrix pipe sustains ~71 TFLOP/s at
+//    2.39 GHz where a v_fma_f64 stream power-throttles to ~56-60.  P = 36 therefore runs the
+//    chain on the matrix pipe: 16 codewords x 16 frames per MFMA, frames resident in VGPRs,
+//    codeword tiles streamed from L2, per-lane running argmin on the VALU (which idles
+//    otherwise).  Other P use the VALU kernels (lane = frame, codeword via SGPRs).
+//  * Training frames are resident in HBM in the operand layout of their kernel, so a wave's
+//    loads are fully coalesced 16 B/lane.
 //  * All sums are exact integers (two signed 32-bit limbs per value, 64-bit
 //    accumulators), so LDS/global atomics in any order, any grid, any GPU count give
 //    bit-identical cell sums; RCCL all-reduce runs on int64.
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(TPB) void k_pass(const double* __restrict__ blk, lo
             cdouble_k* c = cbq + (long)m * NPAD;
             double d[F];
 #pragma unroll
-            for (int f = 0; f < F; ++f) d[f] = r[f][0] * c[0];
+            for (int f = 0; f < F; ++f) d[f] = __builtin_fma(r[f][0], c[0], 0.0);
 #pragma unroll
             for (int n = 1; n < NC; ++n)
 #pragma unroll
@@ -301,6 +305,276 @@ __global__ __launch_bounds__(TPB) void k_pass(const double* __restrict__ blk, lo
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// MFMA path (P = 36): operand layouts
+//   frames : block of 64 frames = 2 super-tiles of 32 frames; super-tile =
+//            [s < NS-1][lane 0..63][h 0..1] then the partial last k-step [q < REM][j 0..15][h],
+//            value = r[t0 + 16h + j][4s + q]  (lane = 16q + j): exactly NC*32 doubles, no padding
+//   codebook: cbm[tile][p][lane][2] = cq[16*tile + j][4*(2p+e) + q], zero beyond n = P,
+//            codewords beyond M are copies of codeword 0 (they can never win a tie)
+// ------------------------------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__global__ void k_blockify_mfma(const double* __restrict__ aos, long T, int NC, double* __restrict__ blk,
+                                long nblocks)
+{
+    const int NS = (NC + 3) >> 2;
+    const long total = nblocks * (long)NC * 64;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const long b = o / ((long)NC * 64);
+        const int w = (int)(o - b * (long)NC * 64);
+        const int u = w / (NC * 32), x = w - u * (NC * 32);
+        int n, h, j;
+        if (x < (NS - 1) * 128) {
+            const int st = x >> 7, y = x & 127, l = y >> 1;
+            h = y & 1;
+            j = l & 15;
+            n = 4 * st + (l >> 4);
+        } else {
+            const int y = x - (NS - 1) * 128, z = y >> 1;
+            h = y & 1;
+            j = z & 15;
+            n = 4 * (NS - 1) + (z >> 4);
+        }
+        const long t = b * 64 + u * 32 + h * 16 + j;
+        blk[o] = t < T ? aos[t * NC + n] : 0.0;
+    }
+}
+
+template <int NC, int MODE, int TPBM>
+__global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict__ blk, long T, long nblocks,
+                                                       const double* __restrict__ cbm, int MT, int M,
+                                                       const DevScalars* __restrict__ sc,
+                                                       const u64* __restrict__ l1max_bits,
+                                                       unsigned short* __restrict__ sym, double* __restrict__ dmin,
+                                                       i64* __restrict__ rows)
+{
+    constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2, REM = NC - 4 * (NS - 1);
+    constexpr int RS = (2 * NC + 5 + 7) & ~7;
+    constexpr int NE = 2 * NC + 5;
+    constexpr int IMG = NE + IMG_STRIDE_PAD;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, j = lane & 15;
+    const int wib = threadIdx.x >> 6;
+    const long wave = (long)blockIdx.x * (TPBM >> 6) + wib;
+    const long nwaves = (long)gridDim.x * (TPBM >> 6);
+
+    int sh_r = 0, sh_d = 0, sh_d2 = 0;
+    if constexpr (MODE != 0) {
+        sh_r = sc->sh_r;
+        const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
+        sh_d = 30 - Ed;
+        sh_d2 = 30 - 2 * Ed;
+    }
+    i64* lacc = (i64*)smem;  // MODE 1: [M][RS] table shared by the workgroup
+    int* img = (int*)(smem + (MODE == 1 ? (size_t)M * RS * 8 : 0)) + wib * (16 * IMG);
+    if constexpr (MODE == 1) {
+        for (int i = threadIdx.x; i < M * RS; i += TPBM) lacc[i] = 0;
+        __syncthreads();
+    }
+
+    for (long b = wave; b < nblocks; b += nwaves) {
+        // ---- frames -> B operands (resident for the whole sweep) ---------------------------
+        double Bf[4][2 * NP];
+        const double* fb = blk + b * (long)(NC * 64);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const double* base = fb + u * (NC * 32);
+#pragma unroll
+            for (int st = 0; st < NS - 1; ++st) {
+                const double2 v = *(const double2*)(base + (st * 64 + lane) * 2);
+                Bf[2 * u][st] = v.x;
+                Bf[2 * u + 1][st] = v.y;
+            }
+            double2 v = make_double2(0.0, 0.0);
+            if (q < REM) v = *(const double2*)(base + (NS - 1) * 128 + (q * 16 + j) * 2);
+            Bf[2 * u][NS - 1] = v.x;
+            Bf[2 * u + 1][NS - 1] = v.y;
+        }
+
+        // ---- sweep: 16 codewords x 16 frames per MFMA, k ascending = canonical chain -------
+        double best[4];
+        int code[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            best[ft] = __builtin_inf();
+            code[ft] = 0;
+        }
+        double2 An[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) An[p] = *(const double2*)(cbm + ((long)p * 64 + lane) * 2);
+        for (int ct = 0; ct < MT; ++ct) {
+            double A[2 * NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                A[2 * p] = An[p].x;
+                A[2 * p + 1] = An[p].y;
+            }
+            const int nt = ct + 1 < MT ? ct + 1 : ct;  // prefetch the next codeword tile (L2 resident)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) An[p] = *(const double2*)(cbm + (((long)nt * NP + p) * 64 + lane) * 2);
+            d4 acc[4];
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+                acc[ft] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[0], Bf[ft][0], (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+#pragma unroll
+            for (int st = 1; st < NS; ++st)
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+                    acc[ft] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[st], Bf[ft][st], acc[ft], 0, 0, 0);
+            // lane (q, j) sees codewords 16ct + 4rg + q of frame j: ascending in (ct, rg)
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const double v = acc[ft][rg];
+                    const bool lt = v < best[ft];
+                    code[ft] = lt ? ct * 4 + rg : code[ft];
+                    best[ft] = __builtin_fmin(best[ft], v);
+                }
+        }
+
+        // ---- combine the four lanes (q = 0..3) that hold one frame: min value, lowest index ---
+        int idx[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            idx[ft] = ((code[ft] >> 2) << 4) + ((code[ft] & 3) << 2) + q;
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const double ob = __shfl_xor(best[ft], off, 64);
+                const int oi = __shfl_xor(idx[ft], off, 64);
+                const bool take = ob < best[ft] || (ob == best[ft] && oi < idx[ft]);
+                best[ft] = take ? ob : best[ft];
+                idx[ft] = take ? oi : idx[ft];
+            }
+        }
+
+        // ---- outputs: lane 16q + j owns frame b*64 + lane ---------------------------------------
+        {
+            const double bs = q == 0 ? best[0] : q == 1 ? best[1] : q == 2 ? best[2] : best[3];
+            const int is = q == 0 ? idx[0] : q == 1 ? idx[1] : q == 2 ? idx[2] : idx[3];
+            const long t = b * 64 + lane;
+            if (t < T) {
+                if (sym) sym[t] = (unsigned short)is;
+                if (dmin) dmin[t] = bs;
+            }
+        }
+
+        // ---- accumulate: int32 row images [frame][2n+limb | count, d, d2] -> exact 64-bit adds ----
+        if constexpr (MODE != 0) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                int* my = img + j * IMG;
+#pragma unroll
+                for (int st = 0; st < NS; ++st) {
+                    if (st < NS - 1 || q < REM) {
+                        int hi, lo;
+                        fix2(Bf[ft][st], sh_r, hi, lo);
+                        *(int2*)&my[2 * (4 * st + q)] = make_int2(hi, lo);
+                    }
+                }
+                if (q == 0) {
+                    const double e = best[ft] - 1.0;
+                    int hi, lo;
+                    my[2 * NC] = 1;
+                    fix2(e, sh_d, hi, lo);
+                    my[2 * NC + 1] = hi;
+                    my[2 * NC + 2] = lo;
+                    fix2(e * e, sh_d2, hi, lo);
+                    my[2 * NC + 3] = hi;
+                    my[2 * NC + 4] = lo;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int jj = 0; jj < 16; ++jj) {
+                    const long tj = b * 64 + ft * 16 + jj;
+                    if (tj >= T) break;  // wave-uniform: padding frames are never counted
+                    const int cell = __builtin_amdgcn_readlane(idx[ft], jj);
+                    i64* row = (MODE == 1 ? lacc : rows) + (long)cell * RS;
+                    const int* im = img + jj * IMG;
+                    if (lane < NE) atomicAdd((u64*)&row[lane], (u64)(i64)im[lane]);
+                    if (NE > 64 && lane < NE - 64) atomicAdd((u64*)&row[64 + lane], (u64)(i64)im[64 + lane]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
+
+    if constexpr (MODE == 1) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < M * RS; i += TPBM) {
+            const i64 v = lacc[i];
+            if (v != 0) atomicAdd((u64*)&rows[i], (u64)v);
+        }
+    }
+}
+
+
+// global sums for the MFMA frame layout: per-lane 64-bit accumulators for its coefficients
+// n = 4s + q, reduced over the 16 lanes (frames) that share q, one atomic per (n, limb) per wave.
+template <int NC>
+__global__ __launch_bounds__(256) void k_global_sums_mfma(const double* __restrict__ blk, long nblocks,
+                                                          const DevScalars* __restrict__ sc, i64* __restrict__ stats)
+{
+    constexpr int NS = (NC + 3) / 4, REM = NC - 4 * (NS - 1);
+    const int sh_r = sc->sh_r, sh_q = sc->sh_q;
+    const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    i64 sh[NS], sl[NS], qh = 0, ql = 0;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) sh[st] = sl[st] = 0;
+    for (long u = wave; u < 2 * nblocks; u += nwaves) {  // super-tiles of 32 frames
+        const double* base = blk + u * (long)(NC * 32);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            double2 v = make_double2(0.0, 0.0);
+            if (st < NS - 1)
+                v = *(const double2*)(base + (st * 64 + lane) * 2);
+            else if (q < REM)
+                v = *(const double2*)(base + (NS - 1) * 128 + (q * 16 + j) * 2);
+            int hi, lo;
+            fix2(v.x, sh_r, hi, lo);
+            sh[st] += hi;
+            sl[st] += lo;
+            fix2(v.y, sh_r, hi, lo);
+            sh[st] += hi;
+            sl[st] += lo;
+            fix2(v.x * v.x, sh_q, hi, lo);
+            qh += hi;
+            ql += lo;
+            fix2(v.y * v.y, sh_q, hi, lo);
+            qh += hi;
+            ql += lo;
+        }
+    }
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            sh[st] += __shfl_xor(sh[st], off, 64);
+            sl[st] += __shfl_xor(sl[st], off, 64);
+        }
+        const int n = 4 * st + q;
+        if (j == 0 && n < NC) {
+            atomicAdd((u64*)&stats[2 * n], (u64)sh[st]);
+            atomicAdd((u64*)&stats[2 * n + 1], (u64)sl[st]);
+        }
+    }
+    qh = wave_sum_i64(qh);
+    ql = wave_sum_i64(ql);
+    if (lane == 0) {
+        atomicAdd((u64*)&stats[2 * NC], (u64)qh);
+        atomicAdd((u64*)&stats[2 * NC + 1], (u64)ql);
+    }
+}
+
 // generic (any P) fallback: frame coefficients re-read from global/L1 per codeword.
 // Correct for every P <= E2VQ_MAX_P; only the instantiated NC values get the register kernel.
 template <int MODE>
@@ -329,7 +603,7 @@ __global__ __launch_bounds__(TPB) void k_pass_generic(const double* __restrict__
         int bi = 0;
         for (int m = 0; m < M; ++m) {
             const double* c = cbq + (long)m * NPAD;
-            double d = fb[lane] * c[0];
+            double d = __builtin_fma(fb[lane], c[0], 0.0);
             for (int n = 1; n < NC; ++n) d = __builtin_fma(fb[n * 64 + lane], c[n], d);
             const bool lt = d < best;
             best = lt ? d : best;
@@ -469,14 +743,15 @@ __global__ void k_grow(const double* __restrict__ old_refl, int M, int NC, doubl
 
 // K4b: reflections -> predictor (step-up) -> raas -> pre-doubled padded codeword rows; L1 max
 __global__ void k_codebook_prepare(const double* __restrict__ reflections, int M, int NC, double* __restrict__ cbq,
-                                   u64* __restrict__ l1max_bits)
+                                   u64* __restrict__ l1max_bits, double* __restrict__ cbm, int MT)
 {
     const int NPAD = (NC + 7) & ~7;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
+    const bool real = m < M;
+    if (!real && !(cbm && m < 16 * MT)) return;
     const int P = NC - 1;
     double a[E2VQ_MAX_P + 1];
-    const double* rc = reflections + (long)m * NC;
+    const double* rc = reflections + (long)(real ? m : 0) * NC;  // tile padding repeats codeword 0
     a[0] = 1.0;
     for (int k = 1; k <= P; ++k) {
         const double akk = rc[k];
@@ -489,16 +764,23 @@ __global__ void k_codebook_prepare(const double* __restrict__ reflections, int M
         }
     }
     double* dst = cbq + (long)m * NPAD;
+    const int NS = (NC + 3) >> 2, NP = (NS + 1) >> 1;
+    double* mt = cbm ? cbm + (long)(m >> 4) * NP * 128 : nullptr;  // [p][lane = 16q + j][e]
+    const int jm = m & 15;
     double l1 = 0.0;
     for (int n = 0; n <= P; ++n) {
         double s = 0.0;
         for (int i = 0; i <= P - n; ++i) s += a[i] * a[i + n];
         const double c = n == 0 ? s : 2.0 * s;
-        dst[n] = c;
+        if (real) dst[n] = c;
+        if (mt) mt[(((n >> 3) * 64) + ((n & 3) * 16 + jm)) * 2 + ((n >> 2) & 1)] = c;
         l1 += fabs(c);
     }
-    for (int n = NC; n < NPAD; ++n) dst[n] = 0.0;
-    atomicMax(l1max_bits, (u64)__double_as_longlong(l1));
+    if (real)
+        for (int n = NC; n < NPAD; ++n) dst[n] = 0.0;
+    if (mt)
+        for (int n = NC; n < 8 * NP; ++n) mt[(((n >> 3) * 64) + ((n & 3) * 16 + jm)) * 2 + ((n >> 2) & 1)] = 0.0;
+    if (real) atomicMax(l1max_bits, (u64)__double_as_longlong(l1));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -513,10 +795,16 @@ static inline int grid_for(long work_items, int per_block, int cap)
     return (int)g;
 }
 
+bool uses_mfma(int NC) { return NC == 37; }
+
 void launch_blockify(const double* aos, long T, int NC, int FB, double* blk, long nblocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_blockify, dim3(grid_for(nblocks * NC * FB, 256, 8192)), dim3(256), 0, s, aos, T, NC, FB, blk,
-                       nblocks);
+    if (uses_mfma(NC))
+        hipLaunchKernelGGL(k_blockify_mfma, dim3(grid_for(nblocks * NC * 64, 256, 8192)), dim3(256), 0, s, aos, T, NC,
+                           blk, nblocks);
+    else
+        hipLaunchKernelGGL(k_blockify, dim3(grid_for(nblocks * NC * FB, 256, 8192)), dim3(256), 0, s, aos, T, NC, FB,
+                           blk, nblocks);
 }
 
 void launch_maxabs(const double* blk, long count, u64* out_bits, int* bad, hipStream_t s)
@@ -532,18 +820,56 @@ void launch_finish_scalars(const u64* maxabs_bits, DevScalars* sc, hipStream_t s
 void launch_global_sums(const double* blk, long nblocks, int NC, int FB, const DevScalars* sc, i64* stats,
                         hipStream_t s)
 {
+    if (NC == 37) {
+        hipLaunchKernelGGL((k_global_sums_mfma<37>), dim3(grid_for(2 * nblocks, 4, 2048)), dim3(256), 0, s, blk, nblocks,
+                           sc, stats);
+        return;
+    }
     hipLaunchKernelGGL(k_global_sums, dim3(grid_for(nblocks * NC, 4, 4096)), dim3(256), 0, s, blk, nblocks, NC, FB, sc,
                        stats);
 }
 
 int frames_per_lane(int NC)
 {
-    return NC == 37 ? 2 : 1;
+    (void)NC;
+    return 1;  // every kernel works on blocks of 64 frames
 }
 
 bool has_register_kernel(int NC)
 {
-    return NC == 37 || NC == 13 || NC == 17 || NC == 21 || NC == 25;
+    return uses_mfma(NC) || NC == 13 || NC == 17 || NC == 21 || NC == 25;
+}
+
+template <int NC>
+static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, const double* cbm, int M,
+                            const DevScalars* sc, const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows,
+                            hipStream_t s)
+{
+    constexpr int RS = (2 * NC + 5 + 7) & ~7;
+    constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
+    const int MT = (M + 15) / 16;
+    if (mode == 0) {
+        const int grid = grid_for(nblocks, 4, 512);
+        hipLaunchKernelGGL((k_pass_mfma<NC, 0, 256>), dim3(grid), dim3(256), 0, s, blk, T, nblocks, cbm, MT, M, sc,
+                           l1max_bits, sym, dmin, rows);
+    } else if (mode == 1) {
+        const size_t lds = (size_t)M * RS * 8 + (size_t)8 * 16 * IMG * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)k_pass_mfma<NC, 1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      E2VQ_LDS_BYTES);
+            attr_set = true;
+        }
+        const int grid = grid_for(nblocks, 8, 256);  // one persistent 8-wave workgroup per CU
+        hipLaunchKernelGGL((k_pass_mfma<NC, 1, 512>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, MT, M, sc,
+                           l1max_bits, sym, dmin, rows);
+    } else {
+        const size_t lds = (size_t)4 * 16 * IMG * 4;
+        const int grid = grid_for(nblocks, 4, 512);
+        hipLaunchKernelGGL((k_pass_mfma<NC, 2, 256>), dim3(grid), dim3(256), lds, s, blk, T, nblocks, cbm, MT, M, sc,
+                           l1max_bits, sym, dmin, rows);
+    }
+    return 0;
 }
 
 int lds_mode_max_M(int NC)
@@ -585,12 +911,12 @@ static int launch_pass_t(int mode, const double* blk, long T, long nblocks, cons
     return 0;
 }
 
-int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const double* cbq, int M,
-                const DevScalars* sc, const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows,
+int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const double* cbq, const double* cbm,
+                int M, const DevScalars* sc, const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows,
                 hipStream_t s)
 {
     switch (NC) {
-        case 37: return launch_pass_t<37, 2>(mode, blk, T, nblocks, cbq, M, sc, l1max_bits, sym, dmin, rows, s);
+        case 37: return launch_pass_mfma<37>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
         case 13: return launch_pass_t<13, 1>(mode, blk, T, nblocks, cbq, M, sc, l1max_bits, sym, dmin, rows, s);
         case 17: return launch_pass_t<17, 1>(mode, blk, T, nblocks, cbq, M, sc, l1max_bits, sym, dmin, rows, s);
         case 21: return launch_pass_t<21, 1>(mode, blk, T, nblocks, cbq, M, sc, l1max_bits, sym, dmin, rows, s);
@@ -636,10 +962,14 @@ void launch_grow(const double* old_refl, int M, int NC, double* new_refl, hipStr
     hipLaunchKernelGGL(k_grow, dim3((M * NC + 255) / 256), dim3(256), 0, s, old_refl, M, NC, new_refl);
 }
 
-void launch_codebook_prepare(const double* reflections, int M, int NC, double* cbq, u64* l1max_bits, hipStream_t s)
+void launch_codebook_prepare(const double* reflections, int M, int NC, double* cbq, u64* l1max_bits, double* cbm,
+                             hipStream_t s)
 {
     (void)hipMemsetAsync(l1max_bits, 0, sizeof(u64), s);
-    hipLaunchKernelGGL(k_codebook_prepare, dim3((M + 63) / 64), dim3(64), 0, s, reflections, M, NC, cbq, l1max_bits);
+    const int MT = (M + 15) / 16;
+    const int n = cbm ? 16 * MT : M;
+    hipLaunchKernelGGL(k_codebook_prepare, dim3((n + 63) / 64), dim3(64), 0, s, reflections, M, NC, cbq, l1max_bits, cbm,
+                       MT);
 }
 
 }  // namespace e2vq

@@ -73,6 +73,7 @@ struct e2vq_session {
     double* d_refl = nullptr;      // current reflections [M][NC]
     double* d_refl_next = nullptr; // grow target
     double* d_cbq = nullptr;       // [M][NPAD] pre-doubled raas rows
+    double* d_cbm = nullptr;       // MFMA operand layout of the same codewords (P = 36)
     u64* d_l1max = nullptr;
     // statistics
     DevScalars* d_sc = nullptr;
@@ -107,28 +108,34 @@ static int ensure_codebook_capacity(e2vq_session* s, int M)
     if (M <= s->M_cap) return 0;
     int cap = std::max(M, std::max(2 * s->M_cap, 64));
     HIPCHK(hipSetDevice(s->device));
-    double *refl, *refl_next, *cbq, *S, *within;
+    double *refl, *refl_next, *cbq, *S, *within, *cbm = nullptr;
     i64* rows;
     HIPCHK(hipMalloc(&refl, (size_t)cap * s->NC * 8));
     HIPCHK(hipMalloc(&refl_next, (size_t)cap * s->NC * 8));
     HIPCHK(hipMalloc(&cbq, (size_t)cap * s->NPAD * 8 + 512));
+    if (e2vq::uses_mfma(s->NC)) HIPCHK(hipMalloc(&cbm, (size_t)e2vq::cbm_doubles(s->NC, cap) * 8));
     HIPCHK(hipMalloc(&S, (size_t)cap * s->NC * 8));
     HIPCHK(hipMalloc(&within, (size_t)cap * 8));
     HIPCHK(hipMalloc(&rows, (size_t)cap * s->RS * 8));
     if (s->M > 0) {
         HIPCHK(hipMemcpyAsync(refl, s->d_refl, (size_t)s->M * s->NC * 8, hipMemcpyDeviceToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(cbq, s->d_cbq, (size_t)s->M * s->NPAD * 8, hipMemcpyDeviceToDevice, s->stream));
+        if (cbm)
+            HIPCHK(hipMemcpyAsync(cbm, s->d_cbm, (size_t)e2vq::cbm_doubles(s->NC, s->M) * 8, hipMemcpyDeviceToDevice,
+                                  s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
     }
     (void)hipFree(s->d_refl);
     (void)hipFree(s->d_refl_next);
     (void)hipFree(s->d_cbq);
+    (void)hipFree(s->d_cbm);
     (void)hipFree(s->d_S);
     (void)hipFree(s->d_within);
     (void)hipFree(s->d_rows);
     s->d_refl = refl;
     s->d_refl_next = refl_next;
     s->d_cbq = cbq;
+    s->d_cbm = cbm;
     s->d_S = S;
     s->d_within = within;
     s->d_rows = rows;
@@ -176,7 +183,7 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipStreamSynchronize(s->stream);
-    void* ptrs[] = {s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
+    void* ptrs[] = {s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
                     s->d_qdmin};
     for (void* p : ptrs)
@@ -286,7 +293,7 @@ extern "C" int e2vq_prepare(e2vq_session* s)
 
 static int codebook_prepare(e2vq_session* s)
 {
-    e2vq::launch_codebook_prepare(s->d_refl, s->M, s->NC, s->d_cbq, s->d_l1max, s->stream);
+    e2vq::launch_codebook_prepare(s->d_refl, s->M, s->NC, s->d_cbq, s->d_l1max, s->d_cbm, s->stream);
     HIPCHK(hipGetLastError());
     s->stats_valid = false;
     return 0;
@@ -355,7 +362,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipMemsetAsync(s->d_rows, 0, (size_t)s->M * s->RS * 8, s->stream));
     if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
-    e2vq::launch_pass(s->NC, pass_mode(s), s->d_blk, s->T, s->nblocks, s->d_cbq, s->M, s->d_sc, s->d_l1max,
+    e2vq::launch_pass(s->NC, pass_mode(s), s->d_blk, s->T, s->nblocks, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max,
                       (unsigned short*)device_sym, (double*)device_dmin, s->d_rows, s->stream);
     if (s->timing) {
         HIPCHK(hipEventRecord(s->ev1, s->stream));
@@ -541,7 +548,7 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
     if (ensure_quantize_scratch(s, T, false, false)) return 1;
     const i64 nb = (T + s->FB - 1) / s->FB;
     e2vq::launch_blockify((const double*)device_frames, T, s->NC, s->FB, s->d_qblk, nb, s->stream);
-    e2vq::launch_pass(s->NC, 0, s->d_qblk, T, nb, s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
+    e2vq::launch_pass(s->NC, 0, s->d_qblk, T, nb, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                       (double*)device_dmin, nullptr, s->stream);
     HIPCHK(hipGetLastError());
     return 0;

@@ -121,7 +121,7 @@ void e2o_reflections_to_cq(int P, int M, const double *reflections, double *cq)
 
 double e2o_distortion(int P, const double *r, const double *cq)
 {
-    double acc = r[0] * cq[0];
+    double acc = E2O_FMA(r[0], cq[0], 0.0);
     for (int n = 1; n <= P; n++) acc = E2O_FMA(r[n], cq[n], acc);
     return acc;
 }
@@ -190,41 +190,58 @@ int e2o_row_stride(int P) { return (2 * (P + 1) + 5 + 7) & ~7; }
 /* ------------------------------------------------------------------------ */
 
 /* argmin over codewords, ascending index, strict '<' (lowest index wins ties).
- * Codebook is used transposed [n][m] in groups of 8 so the compiler can keep 8
- * independent chains in flight; each (frame, codeword) chain is still the canonical
- * sequential one. */
+ * Codebook is used transposed [n][m] in groups of E2O_GROUP so the compiler can keep
+ * that many independent (vectorised) chains in flight; each (frame, codeword) chain is
+ * still the canonical sequential one. */
+#define E2O_GROUP 32
+#define E2O_FRAME_BLOCK 64
+/* Frames are taken in blocks so a codeword group (37 x 32 doubles, L1 sized) is reused across
+ * the whole block; per (frame, codeword) the arithmetic and the codeword order are unchanged. */
 static void assign_frames(int P, const double *cqT, int M, int Mp, const double *frames,
                           int64_t t0, int64_t t1, uint16_t *sym, double *dmin)
 {
-    for (int64_t t = t0; t < t1; t++) {
-        const double *r = frames + (size_t)t * (P + 1);
-        double best = INFINITY;
-        int bi = 0;
-        for (int m0 = 0; m0 < M; m0 += 8) {
-            double d[8];
-            const double r0 = r[0];
-            for (int j = 0; j < 8; j++) d[j] = r0 * cqT[m0 + j];
-            for (int n = 1; n <= P; n++) {
-                const double rn = r[n];
-                const double *c = cqT + (size_t)n * Mp + m0;
-                for (int j = 0; j < 8; j++) d[j] = E2O_FMA(rn, c[j], d[j]);
-            }
-            const int lim = (M - m0) < 8 ? (M - m0) : 8;
-            for (int j = 0; j < lim; j++) {
-                if (d[j] < best) {
-                    best = d[j];
-                    bi = m0 + j;
+    for (int64_t tb = t0; tb < t1; tb += E2O_FRAME_BLOCK) {
+        const int nb = (int)((t1 - tb) < E2O_FRAME_BLOCK ? (t1 - tb) : E2O_FRAME_BLOCK);
+        double best[E2O_FRAME_BLOCK];
+        int bi[E2O_FRAME_BLOCK];
+        for (int i = 0; i < nb; i++) {
+            best[i] = INFINITY;
+            bi[i] = 0;
+        }
+        for (int m0 = 0; m0 < M; m0 += E2O_GROUP) {
+            const int lim = (M - m0) < E2O_GROUP ? (M - m0) : E2O_GROUP;
+            for (int i = 0; i < nb; i++) {
+                const double *r = frames + (size_t)(tb + i) * (P + 1);
+                double d[E2O_GROUP];
+                const double r0 = r[0];
+                for (int j = 0; j < E2O_GROUP; j++) d[j] = E2O_FMA(r0, cqT[m0 + j], 0.0);
+                for (int n = 1; n <= P; n++) {
+                    const double rn = r[n];
+                    const double *c = cqT + (size_t)n * Mp + m0;
+                    for (int j = 0; j < E2O_GROUP; j++) d[j] = E2O_FMA(rn, c[j], d[j]);
                 }
+                double b = best[i];
+                int k = bi[i];
+                for (int j = 0; j < lim; j++) {
+                    if (d[j] < b) {
+                        b = d[j];
+                        k = m0 + j;
+                    }
+                }
+                best[i] = b;
+                bi[i] = k;
             }
         }
-        if (sym) sym[t] = (uint16_t)bi;
-        if (dmin) dmin[t] = best;
+        for (int i = 0; i < nb; i++) {
+            if (sym) sym[tb + i] = (uint16_t)bi[i];
+            if (dmin) dmin[tb + i] = best[i];
+        }
     }
 }
 
 static double *transpose_cq(int P, const double *cq, int M, int *Mp_out)
 {
-    const int Mp = (M + 7) & ~7;
+    const int Mp = (M + E2O_GROUP - 1) & ~(E2O_GROUP - 1);
     double *cqT = (double *)calloc((size_t)(P + 1) * Mp, sizeof(double));
     for (int m = 0; m < M; m++)
         for (int n = 0; n <= P; n++) cqT[(size_t)n * Mp + m] = cq[(size_t)m * (P + 1) + n];
@@ -237,7 +254,7 @@ void e2o_quantize(int P, const double *cq, int M, const double *frames, int64_t 
 {
     int Mp;
     double *cqT = transpose_cq(P, cq, M, &Mp);
-    const int64_t CH = 256;
+    const int64_t CH = E2O_FRAME_BLOCK;
     const int64_t nch = (T + CH - 1) / CH;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int64_t c = 0; c < nch; c++) {
@@ -646,6 +663,15 @@ done:
 }
 
 /* ------------------------------------------------------------------------ */
+
+void e2o_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 double e2o_time_pass(int P, const double *cq, int M, const double *frames, int64_t T, int reps,
                      int *threads_used)

@@ -47,7 +47,8 @@ void e2o_ref2raas(int P, const double *rc, double *raa);
 void e2o_codeword_q(int P, const double *raa, double *cq);
 
 /* d(r, c) = r0*c0 + 2*sum r[n]*c[n] evaluated as the canonical chain
- *   acc = r[0]*cq[0]; for n = 1..P: acc = fma(r[n], cq[n], acc)           */
+ *   acc = +0.0; for n = 0..P: acc = fma(r[n], cq[n], acc)               
+ * (one rounding per term, ascending n; exactly what v_mfma_f64_16x16x4_f64 computes per k) */
 double e2o_distortion(int P, const double *r, const double *cq);
 
 /* ---- fixed-point exact accumulation (order-free sums) ------------------ */
@@ -132,6 +133,7 @@ int e2o_seq_load(const char *path, char class_name[E2O_MAX_CLASS_NAME_LEN], int 
                  uint16_t **sym, int64_t *T);
 void e2o_free(void *p);
 
+void e2o_set_threads(int n); /* OpenMP threads for the passes (bench.py cpu_baseline) */
 /* timing helper for bench.py's cpu_baseline: runs `reps` passes, returns seconds */
 double e2o_time_pass(int P, const double *cq, int M, const double *frames, int64_t T, int reps,
                      int *threads_used);

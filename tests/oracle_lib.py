@@ -173,6 +173,9 @@ class Oracle:
                               LEVEL_HOOK(hook))
         return rc, levels, cbs
 
+    def set_threads(self, n):
+        self.L.e2o_set_threads(int(n))
+
     def time_pass(self, cq, frames, reps=1):
         frames = np.ascontiguousarray(frames, dtype=np.float64)
         cq = np.ascontiguousarray(cq, dtype=np.float64)
