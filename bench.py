@@ -106,7 +106,7 @@ def main():
     frames = e.synth.synth_frames(SEED, N_CLASSES, P, lo, S)
 
     sess = e.VqSession(P, device=local)
-    sess.set_stream(torch.cuda.current_stream().cuda_stream)
+    parallel.bind_torch_stream(sess, local)  # session kernels + RCCL collectives on one torch stream
     if world > 1:
         sess.set_allreduce(parallel.make_allreduce(local), rank, world)
     sess.set_frames(frames)  # H2D + blocked re-layout; resident from here on

@@ -16,6 +16,16 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def bind_torch_stream(session, device_index):
+    """Run the session on a dedicated torch stream and make it the thread's current stream, so torch ops
+    (the collective, host copies) and the session's kernels are ordered on ONE stream.  (torch's default
+    stream has handle 0, which the C-ABI reads as "use the session's own stream" -- hence a real stream.)"""
+    st = torch.cuda.Stream(device=device_index)
+    torch.cuda.set_stream(st)
+    session.set_stream(st.cuda_stream)
+    return st
+
+
 class _DeviceBuffer:
     def __init__(self, ptr, count):
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<i8", "data": (ptr, False), "version": 2}

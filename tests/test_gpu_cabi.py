@@ -1,0 +1,214 @@
+"""GPU tests through the reference's own entry points (C-ABI part 1) and at the BASELINE sizes."""
+import ctypes as C
+import hashlib
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import ecoz2rs_amd as e
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+P = 36
+
+
+def test_ecoz2_vq_learn_and_quantize_reproduce_golden_files(tmp_path, monkeypatch):
+    """config 1 through ecoz2_vq_learn / ecoz2_vq_quantize: emitted .cbook / .seq are byte-identical to the fixtures."""
+    meta = json.load(open(os.path.join(GOLD, "config1.json")))
+    frames = e.synth.synth_frames(meta["seed"], meta["classes"], P, 0, meta["T"])
+    # several .prd files of ragged length; sorted file order is the frame order (src/utl/mod.rs:216-218)
+    cuts = [0, 1, 1000, 1777, 4096, 9999, 10000]
+    files = []
+    for i, (a, b) in enumerate(zip(cuts, cuts[1:])):
+        f = tmp_path / "data" / "predictors" / "_" / f"{i:05d}.prd"
+        e.formats.write_prd(str(f), "_", frames[a:b])
+        files.append(str(f))
+    monkeypatch.setenv("ECOZ2_VQ_OUT_ROOT", str(tmp_path))
+    monkeypatch.setenv("ECOZ2_VQ_MAX_CODEBOOK_SIZE", str(meta["max_M"]))
+    seen = []
+    e.vq_learn(None, P, meta["eps"], "_", files, callback=lambda *a: seen.append(a))
+    assert [s[0] for s in seen] == [g["M"] for g in meta["levels"]]
+    for s, g in zip(seen, meta["levels"]):
+        assert (s[1].hex(), s[2].hex(), s[3].hex()) == (g["avg"], g["sigma"], g["inertia"])
+        name = f"eps_0.05_M_{g['M']:04d}.cbook"
+        got = open(tmp_path / "data" / "codebooks" / "_" / name, "rb").read()
+        assert got == open(os.path.join(GOLD, "config1_" + name), "rb").read()
+    assert (tmp_path / "data" / "codebooks" / "_" / "eps_0.05.rpt").exists()
+    # quantize one .prd holding all frames against the M=16 codebook
+    whole = tmp_path / "data" / "predictors" / "_" / "all.prd"
+    e.formats.write_prd(str(whole), "_", frames)
+    e.vq_quantize(str(tmp_path / "data" / "codebooks" / "_" / "eps_0.05_M_0016.cbook"), [str(whole)], True)
+    got = open(tmp_path / "data" / "sequences" / "M16" / "_" / "all.seq", "rb").read()
+    assert got == open(os.path.join(GOLD, "config1_M0016.seq"), "rb").read()
+    # resume from the M=4 codebook (-B): trains 8 and 16 (CHANGELOG.md:366-368)
+    seen2 = []
+    e.vq_learn(str(tmp_path / "data" / "codebooks" / "_" / "eps_0.05_M_0004.cbook"), None, 1e9, "_", files,
+               callback=lambda *a: seen2.append(a))
+    assert [s[0] for s in seen2] == [8, 16]
+
+
+@pytest.mark.parametrize("T", [1, 15, 16, 17, 63, 64, 65, 129, 4097])
+def test_ragged_sizes(oracle, T):
+    """Block / tile padding never leaks: any T gives the oracle's rows, symbols and codebook."""
+    frames = e.synth.synth_frames(31, 3, P, 5, T)
+    refl = np.zeros((5, P + 1))  # M = 5: not a multiple of the 16-codeword MFMA tile
+    for i in range(5):
+        refl[i, 1:] = oracle.lpca_r(e.synth.synth_frames(32, 3, P, i, 1)[0], P)[2][1:]
+    cq = oracle.reflections_to_cq(refl)
+    rc, st = oracle.data_stats(frames)
+    sh_r, _ = oracle.shifts(st.maxabs)
+    sym_o, dmin_o, rows_o = oracle.run_pass(cq, frames, sh_r, oracle.dist_exponent(cq, st.maxabs))
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.set_codebook(refl)
+        s.run_pass()
+        assert np.array_equal(s.get_rows(), rows_o)
+        sym, dmin = s.quantize(frames)
+    assert np.array_equal(sym, sym_o) and np.array_equal(dmin.view(np.uint64), dmin_o.view(np.uint64))
+
+
+def test_invalid_inputs_fail_loudly():
+    frames = e.synth.synth_frames(1, 2, P, 0, 100)
+    with e.VqSession(P) as s:
+        with pytest.raises(e.Ecoz2Error):
+            s.run_pass()  # no training set / codebook
+        bad = frames.copy()
+        bad[7, 3] = np.inf
+        s.set_frames(bad)
+        with pytest.raises(e.Ecoz2Error, match="NaN or infinite"):
+            s.prepare()
+        s.set_frames(np.zeros((10, P + 1)))
+        with pytest.raises(e.Ecoz2Error, match="all zeros"):
+            s.prepare()
+    with pytest.raises(e.Ecoz2Error):
+        e.vq_quantize("/nonexistent.cbook", [])
+
+
+@pytest.mark.parametrize("Pn", [12, 20, 30])
+def test_other_prediction_orders(oracle, Pn):
+    """P = 36 runs on the matrix pipe; other orders use the VALU register kernels (12, 20) or the generic one (30)."""
+    frames = e.synth.synth_frames(41, 3, Pn, 0, 3000)
+    rc, levels_o, cbs_o = oracle.learn(frames, 0.05, 8)
+    assert rc == 0
+    cbs = []
+    with e.VqSession(Pn) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        s.learn(0.05, 8, callback=lambda *a: cbs.append(a))
+        refl = s.get_codebook()
+        sym, dmin = s.quantize(frames)
+    assert cbs == cbs_o
+    assert np.array_equal(refl.view(np.uint64), levels_o[-1]["reflections"].view(np.uint64))
+    sym_o, dmin_o = oracle.quantize(oracle.reflections_to_cq(refl), frames)
+    assert np.array_equal(sym, sym_o) and np.array_equal(dmin.view(np.uint64), dmin_o.view(np.uint64))
+
+
+def test_config2_sized_learn_pass_against_oracle(oracle):
+    """configs[1] scale (1M frames, M=256): one full LBG iteration, bit-exact against the oracle (a few seconds of CPU)."""
+    T, M = 1 << 20, 256
+    frames = e.synth.synth_frames(20242, 20, P, 0, T)
+    refl = np.zeros((M, P + 1))
+    for i in range(M):
+        refl[i, 1:] = oracle.lpca_r(frames[i * 4001], P)[2][1:]
+    cq = oracle.reflections_to_cq(refl)
+    rc, st = oracle.data_stats(frames)
+    sh_r, sh_q = oracle.shifts(st.maxabs)
+    Ed = oracle.dist_exponent(cq, st.maxabs)
+    _so, _do, rows_o = oracle.run_pass(cq, frames, sh_r, Ed)
+    refl_o, _ = oracle.update(rows_o, P, sh_r, refl)
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.set_codebook(refl)
+        s.run_pass()
+        rows = s.get_rows()
+        s.update()
+        refl_g = s.get_codebook()
+    assert np.array_equal(rows, rows_o)
+    assert np.array_equal(refl_g.view(np.uint64), refl_o.view(np.uint64))
+    assert int(rows[:, 2 * (P + 1)].sum()) == T  # every frame counted exactly once
+
+
+def test_config3_sized_quantize_properties(oracle):
+    """configs[2] scale: 10M frames against M=1024.  Full oracle check on a 2M-frame slice; size-independent
+    properties on all 10M: chunking invariance, dmin recomputed independently, every symbol < M."""
+    T, M = 10_000_000, 1024
+    frames = e.synth.synth_frames(20243, 20, P, 0, T)
+    refl = np.zeros((M, P + 1))
+    for i in range(M):
+        refl[i, 1:] = oracle.lpca_r(frames[i * 9001], P)[2][1:]
+    cq = oracle.reflections_to_cq(refl)
+    with e.VqSession(P) as s:
+        s.set_codebook(refl)
+        sym, dmin = s.quantize(frames)
+        sym2 = s.quantize(frames[1234567:1234567 + 300001], want_dmin=False)  # different chunk boundaries
+    assert sym.max() < M and np.array_equal(sym2, sym[1234567:1234567 + 300001])
+    sl = slice(3_000_000, 5_000_000)
+    sym_o, dmin_o = oracle.quantize(cq, frames[sl])
+    assert np.array_equal(sym[sl], sym_o) and np.array_equal(dmin[sl].view(np.uint64), dmin_o.view(np.uint64))
+    # the reported minimum is the distortion of the reported codeword (independent fp64 evaluation, sampled)
+    idx = np.random.default_rng(0).choice(T, 20000, replace=False)
+    d = np.einsum("ij,ij->i", frames[idx], cq[sym[idx]])
+    assert np.allclose(d, dmin[idx], rtol=1e-12, atol=1e-12)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+_RANK_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+import ecoz2rs_amd as e
+from ecoz2rs_amd import parallel
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+T = 50001
+lo, hi = parallel.shard_range(T, rank, world)
+frames = e.synth.synth_frames(55, 5, 36, lo, hi - lo)
+os.environ["ECOZ2_VQ_QUIET"] = "1"
+s = e.VqSession(36, device=0)
+parallel.bind_torch_stream(s, 0)
+s.set_allreduce(parallel.make_allreduce(0), rank, world)
+s.set_frames(frames); s.prepare(); s.init_codebook()
+levels = s.learn(0.05, 64)
+np.save(sys.argv[2] + f"/cb_{rank}.npy", s.get_codebook())
+np.save(sys.argv[2] + f"/passes_{rank}.npy", np.array([l.passes for l in levels]))
+s.close(); dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
+    """Sharded learn (2 processes, gloo exchange of the int64 cell sums) gives the single-rank codebook bit-for-bit."""
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    frames = e.synth.synth_frames(55, 5, P, 0, 50001)
+    os.environ["ECOZ2_VQ_QUIET"] = "1"
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        levels = s.learn(0.05, 64)
+        ref = s.get_codebook()
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"cb_{r}.npy").view(np.uint64), ref.view(np.uint64))
+        assert list(np.load(tmp_path / f"passes_{r}.npy")) == [l.passes for l in levels]
