@@ -350,7 +350,11 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                                                        unsigned short* __restrict__ sym, double* __restrict__ dmin,
                                                        i64* __restrict__ rows)
 {
+    // NS k-steps of 4 cover n < 4*NS; with NC = 4*NSF + 1 the last coefficient (n = NC-1) is not padded to
+    // a fifth MFMA k-step but applied as one VALU fma after the MFMA chain: same ascending order, same roundings.
     constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2, REM = NC - 4 * (NS - 1);
+    constexpr bool TAILV = REM == 1;           // single trailing coefficient -> VALU
+    constexpr int NSM = TAILV ? NS - 1 : NS;   // k-steps run on the matrix pipe
     constexpr int RS = (2 * NC + 5 + 7) & ~7;
     constexpr int NE = 2 * NC + 5;
     constexpr int IMG = NE + IMG_STRIDE_PAD;
@@ -375,6 +379,20 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
         for (int i = threadIdx.x; i < M * RS; i += TPBM) lacc[i] = 0;
         __syncthreads();
     }
+    // Two waves share a SIMD (waves w and w+4 of an 8-wave workgroup).  Left alone they run in lockstep and
+    // reach their accumulate phase -- atomic-latency bound, no MFMA -- together, idling the matrix pipe.
+    // Delaying waves 4..7 by about half a sweep keeps one partner sweeping while the other accumulates.
+    // The accumulate traffic (632 B of atomics per frame) is absorbed at the memory side at ~1 TB/s.  If all
+    // waves arrive there together, each block round ends in a chip-wide atomic burst that every wave waits out
+    // (its next frame loads queue behind its own atomics in vmcnt order).  Spreading the start phases over one
+    // block period turns the bursts into a steady stream; partners differ by half a period.
+    if constexpr (MODE != 0 && TPBM == 512) {
+        if (nblocks >= 4 * nwaves) {
+            const int phase = (((int)blockIdx.x + 4 * (wib & 3)) & 7) + 8 * (wib >> 2);  // 0..15
+            const int naps = (phase * (MT * NSM * 4 * 64 / 16)) >> 13;  // s_sleep(127) ~ 8k cycles
+            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
 
     for (long b = wave; b < nblocks; b += nwaves) {
         // ---- frames -> B operands (resident for the whole sweep) ---------------------------
@@ -390,7 +408,10 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                 Bf[2 * u + 1][st] = v.y;
             }
             double2 v = make_double2(0.0, 0.0);
-            if (q < REM) v = *(const double2*)(base + (NS - 1) * 128 + (q * 16 + j) * 2);
+            if (TAILV)  // every lane of frame j keeps r[NC-1] (the four q lanes read the same 16 B)
+                v = *(const double2*)(base + (NS - 1) * 128 + j * 2);
+            else if (q < REM)
+                v = *(const double2*)(base + (NS - 1) * 128 + (q * 16 + j) * 2);
             Bf[2 * u][NS - 1] = v.x;
             Bf[2 * u + 1][NS - 1] = v.y;
         }
@@ -403,9 +424,12 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             best[ft] = __builtin_inf();
             code[ft] = 0;
         }
+        const double* ctail = cbm + (long)MT * NP * 128;  // [tile][q][rg]: cq[16*tile + 4*rg + q][NC-1]
         double2 An[NP];
+        d4 Tn = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int p = 0; p < NP; ++p) An[p] = *(const double2*)(cbm + ((long)p * 64 + lane) * 2);
+        if (TAILV) Tn = *(const d4*)(ctail + q * 4);
         for (int ct = 0; ct < MT; ++ct) {
             double A[2 * NP];
 #pragma unroll
@@ -413,18 +437,26 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                 A[2 * p] = An[p].x;
                 A[2 * p + 1] = An[p].y;
             }
+            const d4 Tc = Tn;
             const int nt = ct + 1 < MT ? ct + 1 : ct;  // prefetch the next codeword tile (L2 resident)
 #pragma unroll
             for (int p = 0; p < NP; ++p) An[p] = *(const double2*)(cbm + (((long)nt * NP + p) * 64 + lane) * 2);
+            if (TAILV) Tn = *(const d4*)(ctail + (long)nt * 16 + q * 4);
             d4 acc[4];
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft)
                 acc[ft] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[0], Bf[ft][0], (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
 #pragma unroll
-            for (int st = 1; st < NS; ++st)
+            for (int st = 1; st < NSM; ++st)
 #pragma unroll
                 for (int ft = 0; ft < 4; ++ft)
                     acc[ft] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[st], Bf[ft][st], acc[ft], 0, 0, 0);
+            if (TAILV) {
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) acc[ft][rg] = __builtin_fma(Bf[ft][NS - 1], Tc[rg], acc[ft][rg]);
+            }
             // lane (q, j) sees codewords 16ct + 4rg + q of frame j: ascending in (ct, rg)
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft)
@@ -470,7 +502,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                 int* my = img + j * IMG;
 #pragma unroll
                 for (int st = 0; st < NS; ++st) {
-                    if (st < NS - 1 || q < REM) {
+                    if (st < NS - 1 || q < REM) {  // with TAILV only q = 0 writes r[NC-1] (all q lanes hold it)
                         int hi, lo;
                         fix2(Bf[ft][st], sh_r, hi, lo);
                         *(int2*)&my[2 * (4 * st + q)] = make_int2(hi, lo);
@@ -490,14 +522,48 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (int jj = 0; jj < 16; ++jj) {
-                    const long tj = b * 64 + ft * 16 + jj;
-                    if (tj >= T) break;  // wave-uniform: padding frames are never counted
-                    const int cell = __builtin_amdgcn_readlane(idx[ft], jj);
-                    i64* row = (MODE == 1 ? lacc : rows) + (long)cell * RS;
-                    const int* im = img + jj * IMG;
-                    if (lane < NE) atomicAdd((u64*)&row[lane], (u64)(i64)im[lane]);
-                    if (NE > 64 && lane < NE - 64) atomicAdd((u64*)&row[64 + lane], (u64)(i64)im[64 + lane]);
+                // padding frames (t >= T) are never counted; nv is wave-uniform
+                const long left = T - (b * 64 + ft * 16);
+                const int nv = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
+                if (nv == 16) {
+                    // full tile, 4 frames per step: four full-width adds (elements 0..63 of each frame's row)
+                    // and ONE add carrying the four 15-element row tails (lanes 16k..16k+14 -> frame k),
+                    // so LDS reads and atomics of different frames overlap and no lane-divergent branch remains.
+                    static_assert(NE > 64 && NE <= 80, "row tail must fit 16 lanes");
+                    const int tq = lane >> 4, te = lane & 15;
+#pragma unroll
+                    for (int j0 = 0; j0 < 16; j0 += 4) {
+                        int v[4], cell[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            cell[k] = __builtin_amdgcn_readlane(idx[ft], j0 + k);
+                            v[k] = img[(j0 + k) * IMG + lane];
+                        }
+                        const int tv = te < NE - 64 ? img[(j0 + tq) * IMG + 64 + te] : 0;
+                        const int tcell = tq == 0 ? cell[0] : tq == 1 ? cell[1] : tq == 2 ? cell[2] : cell[3];
+                        i64* base = MODE == 1 ? lacc : rows;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if constexpr (MODE == 3)
+                                asm volatile("" ::"v"(v[k]), "s"(cell[k]));
+                            else
+                                atomicAdd((u64*)&base[(long)cell[k] * RS + lane], (u64)(i64)v[k]);
+                        }
+                        if (te < NE - 64) {
+                            if constexpr (MODE == 3)
+                                asm volatile("" ::"v"(tv), "v"(tcell));
+                            else
+                                atomicAdd((u64*)&base[(long)tcell * RS + 64 + te], (u64)(i64)tv);
+                        }
+                    }
+                } else {
+                    for (int jj = 0; jj < nv; ++jj) {
+                        const int cell = __builtin_amdgcn_readlane(idx[ft], jj);
+                        i64* row = (MODE == 1 ? lacc : rows) + (long)cell * RS;
+                        const int* im = img + jj * IMG;
+                        if (lane < NE) atomicAdd((u64*)&row[lane], (u64)(i64)im[lane]);
+                        if (NE > 64 && lane < NE - 64) atomicAdd((u64*)&row[64 + lane], (u64)(i64)im[64 + lane]);
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -666,8 +732,16 @@ __global__ void k_rows_stats(const i64* __restrict__ rows, int M, int NC, const 
     within[m] = ss / (double)cnt;
 }
 
-// Levinson-Durbin from autocorrelation; src/lpc/lpca_r_rs.rs:8-43.  a[] is scratch.
-__device__ int lpca_r(int P, const double* r, double* rc, double* a)
+// Per-thread arrays live in LDS as columns (element i of thread t at [i*64 + t]): dynamic indexing without
+// scratch memory, conflict-free, ~64-cycle access instead of a global round trip.
+struct Col {
+    double* p;
+    int stride;  // threads per block
+    __device__ __forceinline__ double& operator[](int i) const { return p[i * stride]; }
+};
+
+// Levinson-Durbin from autocorrelation; src/lpc/lpca_r_rs.rs:8-43.  rc and a are LDS columns.
+__device__ int lpca_r(int P, Col r, Col rc, Col a)
 {
     const double r0 = r[0];
     if (0.0 == r0) return 1;
@@ -692,16 +766,20 @@ __device__ int lpca_r(int P, const double* r, double* rc, double* a)
 }
 
 // K3: cell sums -> reflections (non-empty cells whose recursion succeeds; others keep theirs)
-__global__ void k_centroids(const i64* __restrict__ rows, const double* __restrict__ S, int M, int NC,
-                            double* __restrict__ reflections, i64* __restrict__ lstats)
+__global__ void k_centroids(const i64* __restrict__ rows, const double* __restrict__ S, int M,
+                                                  int NC, double* __restrict__ reflections, i64* __restrict__ lstats)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* base = (double*)smem;
+    const int W = blockDim.x;
+    const Col r{base + threadIdx.x, W}, rc{base + NC * W + threadIdx.x, W}, a{base + 2 * NC * W + threadIdx.x, W};
     const int RS = (2 * NC + 5 + 7) & ~7;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     if (rows[(long)m * RS + 2 * NC] == 0) return;
-    double rc[E2VQ_MAX_P + 1], a[E2VQ_MAX_P + 1];
     const int P = NC - 1;
-    if (lpca_r(P, S + (long)m * NC, rc, a) != 0) {
+    for (int n = 0; n < NC; ++n) r[n] = S[(long)m * NC + n];
+    if (lpca_r(P, r, rc, a) != 0) {
         atomicAdd((u64*)&lstats[5], 1ull);
         return;
     }
@@ -711,11 +789,15 @@ __global__ void k_centroids(const i64* __restrict__ rows, const double* __restri
 }
 
 // the M = 1 codeword from the global sums
-__global__ void k_init_codebook(const i64* __restrict__ stats, int NC, const DevScalars* __restrict__ sc,
-                                double* __restrict__ reflections, int* __restrict__ status)
+__global__ void k_init_codebook(const i64* __restrict__ stats, int NC,
+                                                      const DevScalars* __restrict__ sc,
+                                                      double* __restrict__ reflections, int* __restrict__ status)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* base = (double*)smem;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double S[E2VQ_MAX_P + 1], rc[E2VQ_MAX_P + 1], a[E2VQ_MAX_P + 1];
+    const int W = blockDim.x;
+    const Col S{base, W}, rc{base + NC * W, W}, a{base + 2 * NC * W, W};
     for (int n = 0; n < NC; ++n) S[n] = unfix(stats[2 * n], stats[2 * n + 1], sc->sh_r);
     const int st = lpca_r(NC - 1, S, rc, a);
     *status = st;
@@ -747,10 +829,11 @@ __global__ void k_codebook_prepare(const double* __restrict__ reflections, int M
 {
     const int NPAD = (NC + 7) & ~7;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Col a{(double*)smem + threadIdx.x, (int)blockDim.x};
     const bool real = m < M;
     if (!real && !(cbm && m < 16 * MT)) return;
     const int P = NC - 1;
-    double a[E2VQ_MAX_P + 1];
     const double* rc = reflections + (long)(real ? m : 0) * NC;  // tile padding repeats codeword 0
     a[0] = 1.0;
     for (int k = 1; k <= P; ++k) {
@@ -767,19 +850,23 @@ __global__ void k_codebook_prepare(const double* __restrict__ reflections, int M
     const int NS = (NC + 3) >> 2, NP = (NS + 1) >> 1;
     double* mt = cbm ? cbm + (long)(m >> 4) * NP * 128 : nullptr;  // [p][lane = 16q + j][e]
     const int jm = m & 15;
-    double l1 = 0.0;
+    double l1 = 0.0, lastc = 0.0;
     for (int n = 0; n <= P; ++n) {
         double s = 0.0;
         for (int i = 0; i <= P - n; ++i) s += a[i] * a[i + n];
         const double c = n == 0 ? s : 2.0 * s;
+        lastc = c;
         if (real) dst[n] = c;
         if (mt) mt[(((n >> 3) * 64) + ((n & 3) * 16 + jm)) * 2 + ((n >> 2) & 1)] = c;
         l1 += fabs(c);
     }
     if (real)
         for (int n = NC; n < NPAD; ++n) dst[n] = 0.0;
-    if (mt)
+    if (mt) {
         for (int n = NC; n < 8 * NP; ++n) mt[(((n >> 3) * 64) + ((n & 3) * 16 + jm)) * 2 + ((n >> 2) & 1)] = 0.0;
+        // trailing-coefficient table [tile][q][rg] for the VALU term: codeword jm = 4*rg + q
+        cbm[(long)MT * NP * 128 + (long)(m >> 4) * 16 + (jm & 3) * 4 + (jm >> 2)] = lastc;
+    }
     if (real) atomicMax(l1max_bits, (u64)__double_as_longlong(l1));
 }
 
@@ -863,10 +950,15 @@ static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, c
         const int grid = grid_for(nblocks, 8, 256);  // one persistent 8-wave workgroup per CU
         hipLaunchKernelGGL((k_pass_mfma<NC, 1, 512>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, MT, M, sc,
                            l1max_bits, sym, dmin, rows);
+    } else if (mode == 3) {  // diagnostics: MODE 2 without the atomics
+        const size_t lds = (size_t)8 * 16 * IMG * 4;
+        const int grid = grid_for(nblocks, 8, 256);
+        hipLaunchKernelGGL((k_pass_mfma<NC, 3, 512>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, MT, M, sc,
+                           l1max_bits, sym, dmin, rows);
     } else {
-        const size_t lds = (size_t)4 * 16 * IMG * 4;
-        const int grid = grid_for(nblocks, 4, 512);
-        hipLaunchKernelGGL((k_pass_mfma<NC, 2, 256>), dim3(grid), dim3(256), lds, s, blk, T, nblocks, cbm, MT, M, sc,
+        const size_t lds = (size_t)8 * 16 * IMG * 4;
+        const int grid = grid_for(nblocks, 8, 256);  // one 8-wave workgroup per CU: partner waves are w, w+4
+        hipLaunchKernelGGL((k_pass_mfma<NC, 2, 512>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, MT, M, sc,
                            l1max_bits, sym, dmin, rows);
     }
     return 0;
@@ -934,6 +1026,9 @@ int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const
     return 0;
 }
 
+// threads per block of the per-cell kernels: 3 LDS columns of NC doubles per thread must fit 64 KB
+static inline int small_tpb(int NC) { return NC <= 42 ? 64 : (NC <= 84 ? 32 : 8); }
+
 void launch_rows_stats(const i64* rows, int M, int NC, const DevScalars* sc, double* S, double* within, i64* lstats,
                        hipStream_t s)
 {
@@ -943,7 +1038,9 @@ void launch_rows_stats(const i64* rows, int M, int NC, const DevScalars* sc, dou
 void launch_centroids(const i64* rows, const double* S, int M, int NC, double* reflections, i64* lstats,
                       hipStream_t s)
 {
-    hipLaunchKernelGGL(k_centroids, dim3((M + 63) / 64), dim3(64), 0, s, rows, S, M, NC, reflections, lstats);
+    const int tpb = small_tpb(NC);
+    hipLaunchKernelGGL(k_centroids, dim3((M + tpb - 1) / tpb), dim3(tpb), (size_t)3 * NC * tpb * 8, s, rows, S, M, NC,
+                       reflections, lstats);
 }
 
 void launch_finish_q(const i64* stats, int NC, DevScalars* sc, hipStream_t s)
@@ -954,7 +1051,9 @@ void launch_finish_q(const i64* stats, int NC, DevScalars* sc, hipStream_t s)
 void launch_init_codebook(const i64* stats, int NC, const DevScalars* sc, double* reflections, int* status,
                           hipStream_t s)
 {
-    hipLaunchKernelGGL(k_init_codebook, dim3(1), dim3(64), 0, s, stats, NC, sc, reflections, status);
+    const int tpb = small_tpb(NC);
+    hipLaunchKernelGGL(k_init_codebook, dim3(1), dim3(tpb), (size_t)3 * NC * tpb * 8, s, stats, NC, sc, reflections,
+                       status);
 }
 
 void launch_grow(const double* old_refl, int M, int NC, double* new_refl, hipStream_t s)
@@ -968,8 +1067,9 @@ void launch_codebook_prepare(const double* reflections, int M, int NC, double* c
     (void)hipMemsetAsync(l1max_bits, 0, sizeof(u64), s);
     const int MT = (M + 15) / 16;
     const int n = cbm ? 16 * MT : M;
-    hipLaunchKernelGGL(k_codebook_prepare, dim3((n + 63) / 64), dim3(64), 0, s, reflections, M, NC, cbq, l1max_bits, cbm,
-                       MT);
+    const int tpb = small_tpb(NC);
+    hipLaunchKernelGGL(k_codebook_prepare, dim3((n + tpb - 1) / tpb), dim3(tpb), (size_t)NC * tpb * 8, s, reflections, M, NC,
+                       cbq, l1max_bits, cbm, MT);
 }
 
 }  // namespace e2vq

@@ -351,6 +351,7 @@ extern "C" int e2vq_grow(e2vq_session* s)
 
 static int pass_mode(const e2vq_session* s)
 {
+    if (const char* f = getenv("ECOZ2_VQ_FORCE_MODE")) return atoi(f);  // diagnostics only (0 = assignment only)
     if (!e2vq::has_register_kernel(s->NC)) return 2;
     return s->M <= e2vq::lds_mode_max_M(s->NC) && s->M <= 128 ? 1 : 2;
 }
