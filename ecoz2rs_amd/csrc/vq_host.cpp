@@ -219,7 +219,8 @@ extern "C" int e2vq_synchronize(e2vq_session* s)
 
 static int reduce(e2vq_session* s, void* buf, i64 count, int op)
 {
-    if (s->world <= 1 || !s->allreduce) return 0;
+    // ECOZ2_VQ_FORCE_ALLREDUCE: call the hook even for a single rank (tests exercise the RCCL plumbing on one GPU)
+    if (!s->allreduce || (s->world <= 1 && !getenv("ECOZ2_VQ_FORCE_ALLREDUCE"))) return 0;
     const int rc = s->allreduce(s->ar_user, buf, count, op, (void*)s->stream);
     if (rc != 0) return e2vq_set_error("all-reduce hook failed (%d)", rc);
     return 0;

@@ -212,3 +212,50 @@ def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / f"cb_{r}.npy").view(np.uint64), ref.view(np.uint64))
         assert list(np.load(tmp_path / f"passes_{r}.npy")) == [l.passes for l in levels]
+
+
+_NCCL_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+import ecoz2rs_amd as e
+from ecoz2rs_amd import parallel
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+frames = e.synth.synth_frames(56, 5, 36, 0, 20000)
+os.environ["ECOZ2_VQ_QUIET"] = "1"
+os.environ["ECOZ2_VQ_FORCE_ALLREDUCE"] = "1"
+calls = []
+hook = parallel.make_allreduce(0)
+def counting(ptr, count, op, stream):
+    calls.append((count, op)); hook(ptr, count, op, stream)
+s = e.VqSession(36, device=0)
+parallel.bind_torch_stream(s, 0)
+s.set_allreduce(counting, 0, 1)
+s.set_frames(frames); s.prepare(); s.init_codebook()
+s.learn(0.05, 32)
+np.save(sys.argv[2] + "/cb_nccl.npy", s.get_codebook())
+np.save(sys.argv[2] + "/calls.npy", np.array(calls))
+s.close(); dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_rccl_hook_single_rank_group(tmp_path):
+    """The exact `nccl` (RCCL) exchange code of bench.py, on a 1-rank group: int64 SUM/MAX all-reduce of the
+    session's device buffers on the bound torch stream must leave the result unchanged."""
+    script = tmp_path / "nccl.py"
+    script.write_text(_NCCL_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    assert subprocess.run([sys.executable, str(script), ROOT, str(tmp_path)], env=env, timeout=600).returncode == 0
+    frames = e.synth.synth_frames(56, 5, P, 0, 20000)
+    os.environ["ECOZ2_VQ_QUIET"] = "1"
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        s.learn(0.05, 32)
+        ref = s.get_codebook()
+    assert np.array_equal(np.load(tmp_path / "cb_nccl.npy").view(np.uint64), ref.view(np.uint64))
+    calls = np.load(tmp_path / "calls.npy")
+    assert calls[0].tolist() == [1, 1] and calls[1].tolist() == [2 * 37 + 3, 0]  # MAX of max|x|, SUM of data stats
+    assert all(c[1] == 0 and c[0] % e.lib.e2vq_row_stride(P) == 0 for c in calls[2:])  # per-pass row all-reduces
