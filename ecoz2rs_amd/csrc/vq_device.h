@@ -35,8 +35,8 @@ int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const
                 long long* rows, hipStream_t s);
 void launch_rows_stats(const long long* rows, int M, int NC, const DevScalars* sc, double* S, double* within,
                        long long* lstats, hipStream_t s);
-void launch_centroids(const long long* rows, const double* S, int M, int NC, double* reflections, long long* lstats,
-                      hipStream_t s);
+void launch_centroids(const long long* rows, const double* S, int M, int NC, const double* refl_in, double* refl_out,
+                      long long* lstats, hipStream_t s);
 void launch_finish_q(const long long* stats, int NC, DevScalars* sc, hipStream_t s);
 void launch_init_codebook(const long long* stats, int NC, const DevScalars* sc, double* reflections, int* status,
                           hipStream_t s);

@@ -765,9 +765,10 @@ __device__ int lpca_r(int P, Col r, Col rc, Col a)
     return 0;
 }
 
-// K3: cell sums -> reflections (non-empty cells whose recursion succeeds; others keep theirs)
-__global__ void k_centroids(const i64* __restrict__ rows, const double* __restrict__ S, int M,
-                                                  int NC, double* __restrict__ reflections, i64* __restrict__ lstats)
+// K3: cell sums -> reflections.  Non-empty cells whose recursion succeeds get new reflections, every other
+// cell keeps its codeword (refl_out may alias refl_in, or be a shadow buffer for the speculative update).
+__global__ void k_centroids(const i64* __restrict__ rows, const double* __restrict__ S, int M, int NC,
+                            const double* refl_in, double* refl_out, i64* __restrict__ lstats)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* base = (double*)smem;
@@ -776,16 +777,23 @@ __global__ void k_centroids(const i64* __restrict__ rows, const double* __restri
     const int RS = (2 * NC + 5 + 7) & ~7;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    if (rows[(long)m * RS + 2 * NC] == 0) return;
     const int P = NC - 1;
-    for (int n = 0; n < NC; ++n) r[n] = S[(long)m * NC + n];
-    if (lpca_r(P, r, rc, a) != 0) {
-        atomicAdd((u64*)&lstats[5], 1ull);
-        return;
+    double* dst = refl_out + (long)m * NC;
+    const double* src = refl_in + (long)m * NC;
+    bool fresh = rows[(long)m * RS + 2 * NC] != 0;
+    if (fresh) {
+        for (int n = 0; n < NC; ++n) r[n] = S[(long)m * NC + n];
+        if (lpca_r(P, r, rc, a) != 0) {
+            atomicAdd((u64*)&lstats[5], 1ull);
+            fresh = false;
+        }
     }
-    double* dst = reflections + (long)m * NC;
-    dst[0] = 0.0;
-    for (int n = 1; n <= P; ++n) dst[n] = rc[n];
+    if (fresh) {
+        dst[0] = 0.0;
+        for (int n = 1; n <= P; ++n) dst[n] = rc[n];
+    } else if (dst != src) {
+        for (int n = 0; n < NC; ++n) dst[n] = src[n];
+    }
 }
 
 // the M = 1 codeword from the global sums
@@ -1035,12 +1043,12 @@ void launch_rows_stats(const i64* rows, int M, int NC, const DevScalars* sc, dou
     hipLaunchKernelGGL(k_rows_stats, dim3((M + 63) / 64), dim3(64), 0, s, rows, M, NC, sc, S, within, lstats);
 }
 
-void launch_centroids(const i64* rows, const double* S, int M, int NC, double* reflections, i64* lstats,
-                      hipStream_t s)
+void launch_centroids(const i64* rows, const double* S, int M, int NC, const double* refl_in, double* refl_out,
+                      i64* lstats, hipStream_t s)
 {
     const int tpb = small_tpb(NC);
     hipLaunchKernelGGL(k_centroids, dim3((M + tpb - 1) / tpb), dim3(tpb), (size_t)3 * NC * tpb * 8, s, rows, S, M, NC,
-                       reflections, lstats);
+                       refl_in, refl_out, lstats);
 }
 
 void launch_finish_q(const i64* stats, int NC, DevScalars* sc, hipStream_t s)

@@ -75,6 +75,16 @@ struct e2vq_session {
     double* d_cbq = nullptr;       // [M][NPAD] pre-doubled raas rows
     double* d_cbm = nullptr;       // MFMA operand layout of the same codewords (P = 36)
     u64* d_l1max = nullptr;
+    // shadow codebook: the centroid update of a pass is launched speculatively into these right after the
+    // statistics kernel, while the host reads DD and decides; e2vq_update commits by swapping pointers
+    double* d_refl_spec = nullptr;
+    double* d_cbq_spec = nullptr;
+    double* d_cbm_spec = nullptr;
+    u64* d_l1max_spec = nullptr;
+    bool spec_valid = false;
+    hipEvent_t ev_stats = nullptr;
+    struct HostStats { i64 l[8]; u64 l1bits; }* h_stats = nullptr;  // pinned
+    double* h_within = nullptr;                                      // pinned, M_cap doubles
     // statistics
     DevScalars* d_sc = nullptr;
     DevScalars h_sc{};
@@ -108,12 +118,18 @@ static int ensure_codebook_capacity(e2vq_session* s, int M)
     if (M <= s->M_cap) return 0;
     int cap = std::max(M, std::max(2 * s->M_cap, 64));
     HIPCHK(hipSetDevice(s->device));
-    double *refl, *refl_next, *cbq, *S, *within, *cbm = nullptr;
+    double *refl, *refl_next, *cbq, *S, *within, *cbm = nullptr, *refl_spec, *cbq_spec, *cbm_spec = nullptr, *hw;
     i64* rows;
     HIPCHK(hipMalloc(&refl, (size_t)cap * s->NC * 8));
     HIPCHK(hipMalloc(&refl_next, (size_t)cap * s->NC * 8));
     HIPCHK(hipMalloc(&cbq, (size_t)cap * s->NPAD * 8 + 512));
-    if (e2vq::uses_mfma(s->NC)) HIPCHK(hipMalloc(&cbm, (size_t)e2vq::cbm_doubles(s->NC, cap) * 8));
+    HIPCHK(hipMalloc(&refl_spec, (size_t)cap * s->NC * 8));
+    HIPCHK(hipMalloc(&cbq_spec, (size_t)cap * s->NPAD * 8 + 512));
+    HIPCHK(hipHostMalloc(&hw, (size_t)cap * 8));
+    if (e2vq::uses_mfma(s->NC)) {
+        HIPCHK(hipMalloc(&cbm, (size_t)e2vq::cbm_doubles(s->NC, cap) * 8));
+        HIPCHK(hipMalloc(&cbm_spec, (size_t)e2vq::cbm_doubles(s->NC, cap) * 8));
+    }
     HIPCHK(hipMalloc(&S, (size_t)cap * s->NC * 8));
     HIPCHK(hipMalloc(&within, (size_t)cap * 8));
     HIPCHK(hipMalloc(&rows, (size_t)cap * s->RS * 8));
@@ -129,6 +145,10 @@ static int ensure_codebook_capacity(e2vq_session* s, int M)
     (void)hipFree(s->d_refl_next);
     (void)hipFree(s->d_cbq);
     (void)hipFree(s->d_cbm);
+    (void)hipFree(s->d_refl_spec);
+    (void)hipFree(s->d_cbq_spec);
+    (void)hipFree(s->d_cbm_spec);
+    if (s->h_within) (void)hipHostFree(s->h_within);
     (void)hipFree(s->d_S);
     (void)hipFree(s->d_within);
     (void)hipFree(s->d_rows);
@@ -136,6 +156,11 @@ static int ensure_codebook_capacity(e2vq_session* s, int M)
     s->d_refl_next = refl_next;
     s->d_cbq = cbq;
     s->d_cbm = cbm;
+    s->d_refl_spec = refl_spec;
+    s->d_cbq_spec = cbq_spec;
+    s->d_cbm_spec = cbm_spec;
+    s->h_within = hw;
+    s->spec_valid = false;
     s->d_S = S;
     s->d_within = within;
     s->d_rows = rows;
@@ -174,6 +199,9 @@ extern "C" int e2vq_session_create(int device, int prediction_order, e2vq_sessio
     HIPCHK(hipMemset(s->d_sc, 0, sizeof(DevScalars)));
     HIPCHK(hipEventCreate(&s->ev0));
     HIPCHK(hipEventCreate(&s->ev1));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_stats, hipEventDisableTiming));
+    HIPCHK(hipMalloc(&s->d_l1max_spec, 8));
+    HIPCHK(hipHostMalloc(&s->h_stats, sizeof(*s->h_stats)));
     *out = s;
     return 0;
 }
@@ -183,11 +211,14 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipStreamSynchronize(s->stream);
-    void* ptrs[] = {s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
+    void* ptrs[] = {s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
                     s->d_qdmin};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->ev_stats) (void)hipEventDestroy(s->ev_stats);
+    if (s->h_stats) (void)hipHostFree(s->h_stats);
+    if (s->h_within) (void)hipHostFree(s->h_within);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
@@ -297,6 +328,7 @@ static int codebook_prepare(e2vq_session* s)
     e2vq::launch_codebook_prepare(s->d_refl, s->M, s->NC, s->d_cbq, s->d_l1max, s->d_cbm, s->stream);
     HIPCHK(hipGetLastError());
     s->stats_valid = false;
+    s->spec_valid = false;
     return 0;
 }
 
@@ -373,6 +405,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     HIPCHK(hipGetLastError());
     if (reduce(s, s->d_rows, (i64)s->M * s->RS, 0)) return 1;
     s->stats_valid = false;
+    s->spec_valid = false;
     return 0;
 }
 
@@ -394,18 +427,26 @@ extern "C" int e2vq_last_pass_kernel_ms(e2vq_session* s, float* ms)
 extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
 {
     HIPCHK(hipSetDevice(s->device));
+    if (s->stats_valid) {
+        if (out) *out = s->last;
+        return 0;
+    }
     HIPCHK(hipMemsetAsync(s->d_lstats, 0, 8 * 8, s->stream));
     e2vq::launch_rows_stats(s->d_rows, s->M, s->NC, s->d_sc, s->d_S, s->d_within, s->d_lstats, s->stream);
-    i64 l[8];
-    u64 l1bits = 0;
-    std::vector<double> within((size_t)s->M);
-    HIPCHK(hipMemcpyAsync(l, s->d_lstats, sizeof l, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipMemcpyAsync(&l1bits, s->d_l1max, 8, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipMemcpyAsync(within.data(), s->d_within, (size_t)s->M * 8, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpyAsync(s->h_stats->l, s->d_lstats, sizeof s->h_stats->l, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(&s->h_stats->l1bits, s->d_l1max, 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(s->h_within, s->d_within, (size_t)s->M * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipEventRecord(s->ev_stats, s->stream));
+    // speculative centroid update into the shadow codebook: keeps the GPU busy while the host decides
+    e2vq::launch_centroids(s->d_rows, s->d_S, s->M, s->NC, s->d_refl, s->d_refl_spec, s->d_lstats, s->stream);
+    e2vq::launch_codebook_prepare(s->d_refl_spec, s->M, s->NC, s->d_cbq_spec, s->d_l1max_spec, s->d_cbm_spec,
+                                  s->stream);
     HIPCHK(hipGetLastError());
+    s->spec_valid = true;
+    HIPCHK(hipEventSynchronize(s->ev_stats));
+    const i64* l = s->h_stats->l;
     double l1max;
-    memcpy(&l1max, &l1bits, 8);
+    memcpy(&l1max, &s->h_stats->l1bits, 8);
     const int Ed = e2vq::dist_exponent(s->h_sc.maxabs, l1max);
     const double DD = e2vq::unfix(l[0], l[1], 30 - Ed);
     const double SS = e2vq::unfix(l[2], l[3], 30 - 2 * Ed);
@@ -416,7 +457,7 @@ extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
     double v = q - p;
     if (!(v > 0.0)) v = 0.0;
     double w = 0.0;
-    for (int m = 0; m < s->M; ++m) w += within[m];  // empty cells contribute +0.0
+    for (int m = 0; m < s->M; ++m) w += s->h_within[m];  // empty cells contribute +0.0
     s->last.M = s->M;
     s->last.DD = DD;
     s->last.avg_distortion = avg;
@@ -434,7 +475,16 @@ extern "C" int e2vq_update(e2vq_session* s)
         if (e2vq_pass_stats(s, nullptr)) return 1;
     }
     HIPCHK(hipSetDevice(s->device));
-    e2vq::launch_centroids(s->d_rows, s->d_S, s->M, s->NC, s->d_refl, s->d_lstats, s->stream);
+    if (s->spec_valid) {  // commit the speculative update: no launch, just swap the codebook sets
+        std::swap(s->d_refl, s->d_refl_spec);
+        std::swap(s->d_cbq, s->d_cbq_spec);
+        std::swap(s->d_cbm, s->d_cbm_spec);
+        std::swap(s->d_l1max, s->d_l1max_spec);
+        s->spec_valid = false;
+        s->stats_valid = false;
+        return 0;
+    }
+    e2vq::launch_centroids(s->d_rows, s->d_S, s->M, s->NC, s->d_refl, s->d_refl, s->d_lstats, s->stream);
     HIPCHK(hipGetLastError());
     return codebook_prepare(s);
 }
