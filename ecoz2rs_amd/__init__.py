@@ -12,6 +12,7 @@ from .vq import (  # noqa: F401
     LevelStats,
     vq_learn,
     vq_quantize,
+    vq_classify,
     vq_show,
     version,
 )

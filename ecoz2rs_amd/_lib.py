@@ -52,6 +52,7 @@ _sig("ecoz2_vq_learn_using_base_codebook", C.c_int, C.c_char_p, C.c_double, c_ch
      LEARN_CALLBACK)
 _sig("ecoz2_vq_quantize", C.c_int, C.c_char_p, c_char_pp, C.c_int, C.c_int)
 _sig("ecoz2_vq_show", C.c_int, C.c_char_p, C.c_int, C.c_int)
+_sig("ecoz2_vq_classify", C.c_int, c_char_pp, C.c_int, c_char_pp, C.c_int, C.c_int)
 
 # Part 2: session API
 _sig("e2vq_last_error", C.c_char_p)
@@ -79,6 +80,7 @@ _sig("e2vq_learn", C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_char_p, C.c_cha
 _sig("e2vq_quantize_host", C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 _sig("e2vq_quantize_device", C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 _sig("e2vq_synchronize", C.c_int, C.c_void_p)
+_sig("e2vq_avg_distortion_host", C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double))
 _sig("e2vq_prd_info", C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int64))
 _sig("e2vq_prd_read", C.c_int, C.c_char_p, C.c_void_p, C.c_int64)
 _sig("e2vq_prd_write", C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64)

@@ -28,6 +28,7 @@ static int usage()
             "                 --predictors <files|dirs|tt.csv>...\n"
             "  ecoz2 vq quantize --codebook <cbook> --predictors <files|dirs|tt.csv>...\n"
             "                 [--predictors-dir-template <t>] [--tt <TRAIN|TEST>] [--class-name <class>] [-s]\n"
+            "  ecoz2 vq classify [-r] --codebooks <files|dirs>... --tt <TRAIN|TEST> --predictors <files|dirs|tt.csv>...\n"
             "  ecoz2 vq show [-f <from>] [-t <to>] <codebook>\n"
             "  ecoz2 cversion\n");
     return 2;
@@ -120,6 +121,36 @@ static int vq_quantize(int argc, char** argv)
     return 0;
 }
 
+static int vq_classify(int argc, char** argv)
+{
+    bool ranked = false;
+    std::string tt;
+    std::vector<std::string> codebooks, predictors;
+    for (int i = 0; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "-r" || a == "--show-ranked") ranked = true;
+        else if (a == "--tt" && i + 1 < argc) tt = argv[++i];
+        else if (a == "--codebooks") { while (i + 1 < argc && !is_flag(argv[i + 1])) codebooks.push_back(argv[++i]); }
+        else if (a == "--predictors") { while (i + 1 < argc && !is_flag(argv[i + 1])) predictors.push_back(argv[++i]); }
+        else return usage();
+    }
+    if (codebooks.empty() || predictors.empty() || tt.empty()) return usage();
+    std::vector<std::string> cbs, prds;
+    e2vq_io::resolve_filenames(codebooks, ".cbook", cbs);
+    if (cbs.empty()) { printf("No codebooks given\n"); return 0; }
+    const bool tt_list = predictors.size() == 1 && predictors[0].size() > 4 &&
+                         predictors[0].compare(predictors[0].size() - 4, 4, ".csv") == 0;
+    int rc = tt_list ? e2vq_io::files_from_csv(predictors[0], tt, "", "predictors", ".prd", nullptr, prds)
+                     : e2vq_io::resolve_filenames(predictors, ".prd", prds);
+    if (rc) { printf("%s\n", e2vq_last_error()); return 0; }
+    if (prds.empty()) { printf("No predictors given\n"); return 0; }
+    printf("number of codebooks: %zu  number of predictors: %zu\n", cbs.size(), prds.size());  // src/vq/mod.rs:236-241
+    printf("show_ranked = %s\n", ranked ? "true" : "false");
+    auto pc = cptrs(cbs), pp = cptrs(prds);
+    ecoz2_vq_classify(pc.data(), (int)pc.size(), pp.data(), (int)pp.size(), ranked ? 1 : 0);
+    return 0;
+}
+
 static int vq_show(int argc, char** argv)
 {
     int from = -1, to = -1;
@@ -147,6 +178,7 @@ int main(int argc, char** argv)
     const std::string cmd = argv[2];
     if (cmd == "learn") return vq_learn(argc - 3, argv + 3);
     if (cmd == "quantize") return vq_quantize(argc - 3, argv + 3);
+    if (cmd == "classify") return vq_classify(argc - 3, argv + 3);
     if (cmd == "show") return vq_show(argc - 3, argv + 3);
     return usage();
 }

@@ -624,6 +624,18 @@ extern "C" int e2vq_quantize_host(e2vq_session* s, const double* frames, int64_t
     return 0;
 }
 
+extern "C" int e2vq_avg_distortion_host(e2vq_session* s, const double* frames, int64_t T, double* avg)
+{
+    if (T < 1) return e2vq_set_error("no frames");
+    std::vector<uint16_t> sym((size_t)T);
+    std::vector<double> dmin((size_t)T);
+    if (e2vq_quantize_host(s, frames, T, sym.data(), dmin.data())) return 1;
+    double e = 0.0;
+    for (int64_t t = 0; t < T; ++t) e += dmin[(size_t)t] - 1.0;
+    *avg = e / (double)T;
+    return 0;
+}
+
 // ==========================================================================================
 // Part 1: the reference's entry points
 // ==========================================================================================
@@ -766,6 +778,93 @@ extern "C" int ecoz2_vq_quantize(const char* nom_raas, const char* const* predic
                (long long)total_T, M, total_T ? total_e / (double)total_T : 0.0);
     e2vq_session_destroy(s);
     return rc;
+}
+
+extern "C" int ecoz2_vq_classify(const char* const* cb_filenames, int num_codebooks, const char* const* prd_filenames,
+                                 int num_predictors, int show_ranked)
+{
+    if (!cb_filenames || !prd_filenames || num_codebooks < 1 || num_predictors < 0)
+        return e2vq_set_error("ecoz2_vq_classify: bad arguments");
+    struct Cb {
+        std::string cls;
+        int P, M;
+        std::vector<double> refl;
+    };
+    std::vector<Cb> cbs((size_t)num_codebooks);
+    for (int i = 0; i < num_codebooks; ++i) {
+        char cls[96];
+        if (e2vq_cbook_info(cb_filenames[i], cls, &cbs[i].P, &cbs[i].M)) return 1;
+        cbs[i].cls = cls;
+        cbs[i].refl.resize((size_t)cbs[i].M * (cbs[i].P + 1));
+        if (e2vq_cbook_read(cb_filenames[i], cbs[i].refl.data(), cbs[i].M)) return 1;
+        if (cbs[i].P != cbs[0].P) return e2vq_set_error("%s: prediction order differs from the first codebook", cb_filenames[i]);
+    }
+    const int P = cbs[0].P;
+    // load all predictor files once
+    struct Prd {
+        std::string cls;
+        int64_t T;
+        std::vector<double> frames;
+    };
+    std::vector<Prd> prds((size_t)num_predictors);
+    for (int k = 0; k < num_predictors; ++k) {
+        char cls[96];
+        int p;
+        if (e2vq_prd_info(prd_filenames[k], cls, &p, &prds[k].T)) return 1;
+        if (p != P) return e2vq_set_error("%s: prediction order %d differs from the codebooks' %d", prd_filenames[k], p, P);
+        prds[k].cls = cls;
+        prds[k].frames.resize((size_t)prds[k].T * (P + 1));
+        if (e2vq_prd_read(prd_filenames[k], prds[k].frames.data(), prds[k].T)) return 1;
+    }
+    e2vq_session* s = nullptr;
+    if (e2vq_session_create(env_int("ECOZ2_VQ_DEVICE", 0), P, &s)) return 1;
+    std::vector<double> score((size_t)num_predictors * num_codebooks, 0.0);
+    int rc = 0;
+    for (int i = 0; i < num_codebooks && !rc; ++i) {  // codebook-major: one codebook upload per class
+        rc = e2vq_set_codebook(s, cbs[i].refl.data(), cbs[i].M);
+        for (int k = 0; k < num_predictors && !rc; ++k) {
+            if (prds[k].T < 1) continue;
+            rc = e2vq_avg_distortion_host(s, prds[k].frames.data(), prds[k].T, &score[(size_t)k * num_codebooks + i]);
+        }
+    }
+    e2vq_session_destroy(s);
+    if (rc) return rc;
+    int correct = 0, total = 0;
+    std::vector<std::string> classes;
+    std::vector<int> ok_by, n_by;
+    for (int k = 0; k < num_predictors; ++k) {
+        if (prds[k].T < 1) continue;
+        const double* sc = &score[(size_t)k * num_codebooks];
+        int best = 0;
+        for (int i = 1; i < num_codebooks; ++i)
+            if (sc[i] < sc[best]) best = i;
+        const bool ok = cbs[best].cls == prds[k].cls;
+        size_t ci = 0;
+        for (; ci < classes.size(); ++ci)
+            if (classes[ci] == prds[k].cls) break;
+        if (ci == classes.size()) {
+            classes.push_back(prds[k].cls);
+            ok_by.push_back(0);
+            n_by.push_back(0);
+        }
+        n_by[ci]++;
+        ok_by[ci] += ok;
+        total++;
+        correct += ok;
+        if (!ok && show_ranked) {
+            std::vector<int> order((size_t)num_codebooks);
+            for (int i = 0; i < num_codebooks; ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sc[a] < sc[b]; });
+            printf("%s: '%s' classified as '%s'; ranked:", prd_filenames[k], prds[k].cls.c_str(), cbs[best].cls.c_str());
+            for (int i : order) printf(" %s(%g)", cbs[i].cls.c_str(), sc[i]);
+            printf("\n");
+        }
+    }
+    printf("\n%-24s %8s %8s %8s\n", "class", "tests", "correct", "percent");
+    for (size_t ci = 0; ci < classes.size(); ++ci)
+        printf("%-24s %8d %8d %7.2f%%\n", classes[ci].c_str(), n_by[ci], ok_by[ci], 100.0 * ok_by[ci] / n_by[ci]);
+    printf("%-24s %8d %8d %7.2f%%\n", "TOTAL", total, correct, total ? 100.0 * correct / total : 0.0);
+    return 0;
 }
 
 extern "C" int ecoz2_vq_show(const char* codebook_filename, int from, int to)

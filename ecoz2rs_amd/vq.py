@@ -57,6 +57,13 @@ def vq_quantize(nom_raas, predictor_filenames, show_filenames=False):
     check(lib.ecoz2_vq_quantize(str(nom_raas).encode(), files, len(predictor_filenames), int(show_filenames)))
 
 
+def vq_classify(cb_filenames, prd_filenames, show_ranked=False):
+    """ecoz2_lib::vq_classify (src/ecoz2_lib/mod.rs:344-358)."""
+    cbs, _k1 = _to_vec_of_ptr_const_c_char(cb_filenames)
+    prds, _k2 = _to_vec_of_ptr_const_c_char(prd_filenames)
+    check(lib.ecoz2_vq_classify(cbs, len(cb_filenames), prds, len(prd_filenames), int(show_ranked)))
+
+
 def vq_show(codebook_filename, from_=-1, to=-1):
     """ecoz2_lib::vq_show (src/ecoz2_lib/mod.rs:360-368)."""
     print(f"codebook_filename = {codebook_filename}")
@@ -210,6 +217,12 @@ class VqSession:
         check(lib.e2vq_quantize_host(self._h, a.ctypes.data, a.shape[0], sym.ctypes.data,
                                      dmin.ctypes.data if want_dmin else None))
         return (sym, dmin) if want_dmin else sym
+
+    def avg_distortion(self, frames):
+        a = np.ascontiguousarray(frames, dtype=np.float64)
+        out = C.c_double()
+        check(lib.e2vq_avg_distortion_host(self._h, a.ctypes.data, a.shape[0], C.byref(out)))
+        return out.value
 
     def quantize_device(self, device_frames, T, device_sym, device_dmin=None):
         check(lib.e2vq_quantize_device(self._h, _ptr(device_frames), int(T), _ptr(device_sym), _ptr(device_dmin)))

@@ -68,6 +68,14 @@ int ecoz2_vq_quantize(const char *nom_raas, const char *const *predictor_filenam
  * Prints the reflection coefficients [from, to] of every codeword (-1 = whole range). */
 int ecoz2_vq_show(const char *codebook_filename, int from, int to);
 
+/* replaces `fn ecoz2_vq_classify(cb_filenames, num_codebooks, prd_filenames, num_predictors, show_ranked)`
+ *                                                            src/ecoz2_lib/mod.rs:124-130
+ * VQ-based classification: every .prd is quantised against every class codebook (same sweep kernel as
+ * quantize); the predicted class is the codebook with the smallest average distortion (ties: first codebook).
+ * Prints per-class and overall accuracy; with show_ranked, the ranked codebooks of each misclassified file. */
+int ecoz2_vq_classify(const char *const *cb_filenames, int num_codebooks,
+                      const char *const *prd_filenames, int num_predictors, int show_ranked);
+
 /* Knobs the reference has no argument for (environment):
  *   ECOZ2_VQ_MAX_CODEBOOK_SIZE  last codebook size trained (default 2048, notes.md:147)
  *   ECOZ2_VQ_DEVICE             HIP device ordinal (default 0)
@@ -139,6 +147,8 @@ int e2vq_quantize_host(e2vq_session *s, const double *frames, int64_t T, uint16_
 int e2vq_quantize_device(e2vq_session *s, const void *device_frames, int64_t T, void *device_sym,
                          void *device_dmin);
 int e2vq_synchronize(e2vq_session *s);
+/* average distortion sum_t (dmin_t - 1) / T of frames against the session's codebook (frame order, plain f64 sum) */
+int e2vq_avg_distortion_host(e2vq_session *s, const double *frames, int64_t T, double *avg);
 
 /* ---- files (.prd / .cbook / .seq) and synthetic data ------------------------------------- */
 int e2vq_prd_info(const char *path, char class_name[96], int *P, int64_t *T);

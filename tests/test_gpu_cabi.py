@@ -259,3 +259,45 @@ def test_rccl_hook_single_rank_group(tmp_path):
     calls = np.load(tmp_path / "calls.npy")
     assert calls[0].tolist() == [1, 1] and calls[1].tolist() == [2 * 37 + 3, 0]  # MAX of max|x|, SUM of data stats
     assert all(c[1] == 0 and c[0] % e.lib.e2vq_row_stride(P) == 0 for c in calls[2:])  # per-pass row all-reduces
+
+
+def test_vq_classify(tmp_path, oracle, capfd):
+    """ecoz2_vq_classify (src/ecoz2_lib/mod.rs:124-130): min average distortion over class codebooks."""
+    os.environ["ECOZ2_VQ_QUIET"] = "1"
+    classes = {"A": 101, "Bm": 202, "C3": 303}
+    cb_files, prd_files, truth = [], [], []
+    for cls, seed in classes.items():
+        train = e.synth.synth_frames(seed, 1, P, 0, 4000)
+        with e.VqSession(P) as s:
+            s.set_frames(train)
+            s.prepare()
+            s.init_codebook()
+            s.learn(0.05, 8)
+            refl = s.get_codebook()
+            # average distortion through the C-ABI == oracle's min distortions summed in frame order
+            test = e.synth.synth_frames(seed, 1, P, 10_000, 700)
+            avg = s.avg_distortion(test)
+        _sym, dmin = oracle.quantize(oracle.reflections_to_cq(refl), test)
+        acc = 0.0
+        for d in dmin:
+            acc += d - 1.0
+        assert avg == acc / len(dmin)
+        cb = tmp_path / "data" / "codebooks" / cls / "eps_0.05_M_0008.cbook"
+        e.formats.write_cbook(str(cb), cls, refl)
+        cb_files.append(str(cb))
+        for i in range(3):
+            f = tmp_path / "data" / "predictors" / cls / f"{i:05d}.prd"
+            e.formats.write_prd(str(f), cls, e.synth.synth_frames(seed, 1, P, 20_000 + 500 * i, 300 + 17 * i))
+            prd_files.append(str(f))
+    capfd.readouterr()
+    e.vq_classify(cb_files, prd_files, show_ranked=True)
+    out = capfd.readouterr().out
+    assert "TOTAL" in out and "100.00%" in out.split("TOTAL")[1]
+    for cls in classes:
+        assert any(line.startswith(cls) and "100.00%" in line for line in out.splitlines())
+    # a deliberately mislabeled file is reported with its ranking
+    bad = tmp_path / "data" / "predictors" / "A" / "bad.prd"
+    e.formats.write_prd(str(bad), "A", e.synth.synth_frames(classes["C3"], 1, P, 30_000, 200))
+    e.vq_classify(cb_files, prd_files + [str(bad)], show_ranked=True)
+    out = capfd.readouterr().out
+    assert "classified as 'C3'; ranked: C3(" in out and "90.00%" in out.split("TOTAL")[1]
