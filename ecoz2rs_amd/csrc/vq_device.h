@@ -37,6 +37,10 @@ void launch_rows_stats(const long long* rows, int M, int NC, const DevScalars* s
                        long long* lstats, hipStream_t s);
 void launch_centroids(const long long* rows, const double* S, int M, int NC, const double* refl_in, double* refl_out,
                       long long* lstats, hipStream_t s);
+bool has_cell_update(int NC);
+void launch_cell_update(const long long* rows, int M, int NC, const DevScalars* sc, const double* refl_in,
+                        double* refl_out, double* cbq, double* cbm, unsigned long long* l1max_bits, double* within,
+                        long long* lstats, hipStream_t s);
 void launch_finish_q(const long long* stats, int NC, DevScalars* sc, hipStream_t s);
 void launch_init_codebook(const long long* stats, int NC, const DevScalars* sc, double* reflections, int* status,
                           hipStream_t s);

@@ -796,6 +796,193 @@ __global__ void k_centroids(const i64* __restrict__ rows, const double* __restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// K3+K4 fused, one wave per cell (NC <= 64): lane n owns coefficient n.
+//   rows != nullptr : limbs -> S -> statistics -> Levinson (lpca_r) -> reflections -> codeword images
+//   rows == nullptr : reflections -> codeword images only (after set_codebook / grow)
+// Every sequential sum of the oracle (the Levinson inner product, sum S^2, raas, L1 norm) is still evaluated
+// term by term in the canonical order: the terms are produced by the lanes in parallel, parked in LDS, and
+// added by a lane-uniform loop of broadcast reads, so all lanes carry the same running value.
+// Element-wise updates (a[i] += akk*a[k-i]) are independent per i and run across lanes as they are.
+// ------------------------------------------------------------------------------------------
+constexpr int CU_WAVES = 4;  // waves (cells) per workgroup of k_cell_update
+
+__global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
+    const i64* __restrict__ rows, int M, int NC, const DevScalars* __restrict__ sc, const double* refl_in,
+    double* refl_out, double* __restrict__ cbq, double* __restrict__ cbm, int MT, u64* __restrict__ l1max_bits,
+    double* __restrict__ within, i64* __restrict__ lstats)
+{
+    __shared__ double lds[CU_WAVES][2][64];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int m = blockIdx.x * CU_WAVES + wib;
+    if (m >= M) return;
+    double* la = lds[wib][0];  // a[] / general staging
+    double* lp = lds[wib][1];  // products
+    const int P = NC - 1, RS = (2 * NC + 5 + 7) & ~7, NPAD = (NC + 7) & ~7;
+    const bool act = lane < NC;
+    const double* src = refl_in + (long)m * NC;
+    double a = 0.0;         // predictor coefficient a[lane]
+    double rcn = 0.0;       // reflection rc[lane]
+    bool have_a = false;    // a[] already holds the step-up of the final reflections
+    bool fresh = false;
+
+    if (rows) {
+        const i64* row = rows + (long)m * RS;
+        const i64 cnt = row[2 * NC];
+        if (lane == 0) {
+            atomicAdd((u64*)&lstats[0], (u64)row[2 * NC + 1]);
+            atomicAdd((u64*)&lstats[1], (u64)row[2 * NC + 2]);
+            atomicAdd((u64*)&lstats[2], (u64)row[2 * NC + 3]);
+            atomicAdd((u64*)&lstats[3], (u64)row[2 * NC + 4]);
+            if (cnt == 0) atomicAdd((u64*)&lstats[4], 1ull);
+        }
+        if (cnt != 0) {  // wave-uniform
+            const double S = act ? unfix(row[2 * lane], row[2 * lane + 1], sc->sh_r) : 0.0;
+            // within-cell term: ss = sum_n S_n^2 (ascending n), / count
+            lp[lane] = S * S;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double ss = 0.0;
+            for (int n0 = 0; n0 < NC; n0 += 8) {
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = lp[(n0 + u) & 63];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (n0 + u < NC) ss += t[u];
+            }
+            if (lane == 0) within[m] = ss / (double)cnt;
+            // ---- lpca_r (src/lpc/lpca_r_rs.rs:8-43) on S ------------------------------------------------
+            const double r0 = __shfl(S, 0, 64);
+            int status = 0;
+            if (0.0 == r0) {
+                status = 1;
+            } else {
+                double pe = r0;
+                a = lane == 0 ? 1.0 : 0.0;
+                for (int k = 1; k <= P; ++k) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    la[lane] = a;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int rev = k - lane;
+                    const double ar = (rev >= 0 && rev < 64) ? la[rev] : 0.0;  // old a[k - lane]
+                    lp[lane] = ar * S;                                        // a[k-i] * r[i] at lane i
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // sum -= lp[i], i = 1..k in order; reads are issued 8 at a time so their LDS latency overlaps
+                    double sum = 0.0;
+                    for (int i0 = 1; i0 <= k; i0 += 8) {
+                        double t[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) t[u] = lp[(i0 + u) & 63];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (i0 + u <= k) sum -= t[u];
+                    }
+                    const double akk = sum / pe;
+                    if (lane == k) {
+                        rcn = akk;
+                        a = akk;
+                    } else if (lane >= 1 && lane < k) {
+                        a = a + akk * ar;
+                    }
+                    pe *= 1.0 - akk * akk;
+                    if (pe <= 0.0) {
+                        status = 2;
+                        break;
+                    }
+                }
+            }
+            if (status == 0) {
+                fresh = true;
+                have_a = true;
+            } else if (lane == 0) {
+                atomicAdd((u64*)&lstats[5], 1ull);
+            }
+        } else if (lane == 0) {
+            within[m] = 0.0;
+        }
+    }
+
+    if (!fresh) rcn = act ? src[lane] : 0.0;  // keep the codeword
+    if (lane == 0) rcn = 0.0;
+    if (refl_out && act && (fresh || refl_out != refl_in)) refl_out[(long)m * NC + lane] = rcn;
+
+    if (!have_a) {  // step-up from the reflections (same element-wise updates as inside lpca_r)
+        a = lane == 0 ? 1.0 : 0.0;
+        for (int k = 1; k <= P; ++k) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            la[lane] = a;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int rev = k - lane;
+            const double ar = (rev >= 0 && rev < 64) ? la[rev] : 0.0;
+            const double akk = __shfl(rcn, k, 64);
+            if (lane == k)
+                a = akk;
+            else if (lane >= 1 && lane < k)
+                a = a + akk * ar;
+        }
+    }
+
+    // ---- raas: raa[n] = sum_{i=0}^{P-n} a[i]*a[i+n]  (ascending i) -> cq ------------------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    la[lane] = act ? a : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double raa = 0.0;
+    for (int i0 = 0; i0 <= P; i0 += 8) {
+        double ai[8], aj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            ai[u] = la[(i0 + u) & 63];
+            aj[u] = la[(i0 + u + lane) & 63];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u + lane <= P) raa += ai[u] * aj[u];
+    }
+    const double c = lane == 0 ? raa : 2.0 * raa;
+    lp[lane] = act ? fabs(c) : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double l1 = 0.0;
+    for (int n0 = 0; n0 <= P; n0 += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = lp[(n0 + u) & 63];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (n0 + u <= P) l1 += t[u];
+    }
+    if (lane == 0) atomicMax(l1max_bits, (u64)__double_as_longlong(l1));
+    if (lane < NPAD) cbq[(long)m * NPAD + lane] = act ? c : 0.0;
+    if (cbm) {
+        const int NS = (NC + 3) >> 2, NP = (NS + 1) >> 1;
+        // this cell's slot, plus (cell 0 only) the padding slots of the last tile: copies of codeword 0
+        const int first = m, last = (m == 0) ? 16 * MT : m + 1;
+        for (int mm = first; mm < last; mm = (mm == first && m == 0) ? M : mm + 1) {
+            if (mm >= 16 * MT) break;
+            double* mt = cbm + (long)(mm >> 4) * NP * 128;
+            const int jm = mm & 15;
+            if (lane < 8 * NP)
+                mt[(((lane >> 3) * 64) + ((lane & 3) * 16 + jm)) * 2 + ((lane >> 2) & 1)] = act ? c : 0.0;
+            if (lane == P) cbm[(long)MT * NP * 128 + (long)(mm >> 4) * 16 + (jm & 3) * 4 + (jm >> 2)] = c;
+        }
+    }
+}
+
 // the M = 1 codeword from the global sums
 __global__ void k_init_codebook(const i64* __restrict__ stats, int NC,
                                                       const DevScalars* __restrict__ sc,
@@ -1054,6 +1241,18 @@ void launch_centroids(const i64* rows, const double* S, int M, int NC, const dou
 void launch_finish_q(const i64* stats, int NC, DevScalars* sc, hipStream_t s)
 {
     hipLaunchKernelGGL(k_finish_q, dim3(1), dim3(64), 0, s, stats, NC, sc);
+}
+
+bool has_cell_update(int NC) { return NC <= 64; }
+
+// fused per-cell update (rows != nullptr) or codeword preparation only (rows == nullptr)
+void launch_cell_update(const i64* rows, int M, int NC, const DevScalars* sc, const double* refl_in, double* refl_out,
+                        double* cbq, double* cbm, u64* l1max_bits, double* within, i64* lstats, hipStream_t s)
+{
+    (void)hipMemsetAsync(l1max_bits, 0, sizeof(u64), s);
+    const int MT = (M + 15) / 16;
+    hipLaunchKernelGGL(k_cell_update, dim3((M + CU_WAVES - 1) / CU_WAVES), dim3(64 * CU_WAVES), 0, s, rows, M, NC, sc,
+                       refl_in, refl_out, cbq, cbm, MT, l1max_bits, within, lstats);
 }
 
 void launch_init_codebook(const i64* stats, int NC, const DevScalars* sc, double* reflections, int* status,

@@ -325,7 +325,11 @@ extern "C" int e2vq_prepare(e2vq_session* s)
 
 static int codebook_prepare(e2vq_session* s)
 {
-    e2vq::launch_codebook_prepare(s->d_refl, s->M, s->NC, s->d_cbq, s->d_l1max, s->d_cbm, s->stream);
+    if (e2vq::has_cell_update(s->NC))
+        e2vq::launch_cell_update(nullptr, s->M, s->NC, s->d_sc, s->d_refl, nullptr, s->d_cbq, s->d_cbm, s->d_l1max,
+                                 nullptr, nullptr, s->stream);
+    else
+        e2vq::launch_codebook_prepare(s->d_refl, s->M, s->NC, s->d_cbq, s->d_l1max, s->d_cbm, s->stream);
     HIPCHK(hipGetLastError());
     s->stats_valid = false;
     s->spec_valid = false;
@@ -432,15 +436,21 @@ extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
         return 0;
     }
     HIPCHK(hipMemsetAsync(s->d_lstats, 0, 8 * 8, s->stream));
-    e2vq::launch_rows_stats(s->d_rows, s->M, s->NC, s->d_sc, s->d_S, s->d_within, s->d_lstats, s->stream);
+    const bool fused = e2vq::has_cell_update(s->NC);
+    if (fused)  // statistics + speculative update into the shadow codebook in ONE wave-per-cell kernel
+        e2vq::launch_cell_update(s->d_rows, s->M, s->NC, s->d_sc, s->d_refl, s->d_refl_spec, s->d_cbq_spec,
+                                 s->d_cbm_spec, s->d_l1max_spec, s->d_within, s->d_lstats, s->stream);
+    else
+        e2vq::launch_rows_stats(s->d_rows, s->M, s->NC, s->d_sc, s->d_S, s->d_within, s->d_lstats, s->stream);
     HIPCHK(hipMemcpyAsync(s->h_stats->l, s->d_lstats, sizeof s->h_stats->l, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipMemcpyAsync(&s->h_stats->l1bits, s->d_l1max, 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipMemcpyAsync(s->h_within, s->d_within, (size_t)s->M * 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipEventRecord(s->ev_stats, s->stream));
-    // speculative centroid update into the shadow codebook: keeps the GPU busy while the host decides
-    e2vq::launch_centroids(s->d_rows, s->d_S, s->M, s->NC, s->d_refl, s->d_refl_spec, s->d_lstats, s->stream);
-    e2vq::launch_codebook_prepare(s->d_refl_spec, s->M, s->NC, s->d_cbq_spec, s->d_l1max_spec, s->d_cbm_spec,
-                                  s->stream);
+    if (!fused) {  // speculative centroid update: keeps the GPU busy while the host decides
+        e2vq::launch_centroids(s->d_rows, s->d_S, s->M, s->NC, s->d_refl, s->d_refl_spec, s->d_lstats, s->stream);
+        e2vq::launch_codebook_prepare(s->d_refl_spec, s->M, s->NC, s->d_cbq_spec, s->d_l1max_spec, s->d_cbm_spec,
+                                      s->stream);
+    }
     HIPCHK(hipGetLastError());
     s->spec_valid = true;
     HIPCHK(hipEventSynchronize(s->ev_stats));

@@ -301,3 +301,20 @@ def test_vq_classify(tmp_path, oracle, capfd):
     e.vq_classify(cb_files, prd_files + [str(bad)], show_ranked=True)
     out = capfd.readouterr().out
     assert "classified as 'C3'; ranked: C3(" in out and "90.00%" in out.split("TOTAL")[1]
+
+
+def test_large_prediction_order_generic_path(oracle):
+    """P = 70 (> 63): generic sweep kernel + thread-per-cell K3/K4 kernels (no wave-per-cell fusion)."""
+    Pn = 70
+    frames = e.synth.synth_frames(43, 2, Pn, 0, 1500)
+    rc, levels_o, cbs_o = oracle.learn(frames, 0.05, 4)
+    assert rc == 0
+    cbs = []
+    with e.VqSession(Pn) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        s.learn(0.05, 4, callback=lambda *a: cbs.append(a))
+        refl = s.get_codebook()
+    assert cbs == cbs_o
+    assert np.array_equal(refl.view(np.uint64), levels_o[-1]["reflections"].view(np.uint64))
