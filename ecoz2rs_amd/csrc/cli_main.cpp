@@ -30,6 +30,8 @@ static int usage()
             "                 [--predictors-dir-template <t>] [--tt <TRAIN|TEST>] [--class-name <class>] [-s]\n"
             "  ecoz2 vq classify [-r] --codebooks <files|dirs>... --tt <TRAIN|TEST> --predictors <files|dirs|tt.csv>...\n"
             "  ecoz2 vq show [-f <from>] [-t <to>] <codebook>\n"
+            "  ecoz2 seq show [-c] [-L] [--full] <file.seq>...\n"
+            "  ecoz2 prd show [--from a] [--to b] <file.prd>\n"
             "  ecoz2 cversion\n");
     return 2;
 }
@@ -168,12 +170,93 @@ static int vq_show(int argc, char** argv)
     return 0;
 }
 
+// `ecoz2 seq show [-c] [-L] [--full] <files...>`: Sequence::show, /root/reference/src/sequence/mod.rs:17-47
+// (reads the C-format .seq exactly as Sequence::load does, :49-75)
+static int seq_show(int argc, char** argv)
+{
+    bool no_sequence = false, only_length = false, full = false;
+    std::vector<std::string> files;
+    for (int i = 0; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "-c") no_sequence = true;
+        else if (a == "-L") only_length = true;
+        else if (a == "--full") full = true;
+        else if (!is_flag(argv[i])) files.push_back(a);
+        else return usage();
+    }
+    if (files.empty()) return usage();
+    for (const auto& f : files) {
+        FILE* fp = fopen(f.c_str(), "rb");
+        unsigned char hdr[120];
+        if (!fp || fread(hdr, 1, sizeof hdr, fp) != sizeof hdr || strncmp((const char*)hdr, "<sequence>", 10) != 0) {
+            printf("%s: Not a sequence\n", f.c_str());
+            if (fp) fclose(fp);
+            continue;
+        }
+        char cls[97] = {0};
+        memcpy(cls, hdr + 16, 96);
+        const unsigned len = hdr[112] | (hdr[113] << 8) | (hdr[114] << 16) | ((unsigned)hdr[115] << 24);
+        const unsigned M = hdr[116] | (hdr[117] << 8) | (hdr[118] << 16) | ((unsigned)hdr[119] << 24);
+        std::vector<unsigned> sym(len);
+        for (unsigned t = 0; t < len; ++t) {
+            unsigned char b[2];
+            if (fread(b, 1, 2, fp) != 2) break;
+            sym[t] = b[0] | (b[1] << 8);
+        }
+        fclose(fp);
+        if (no_sequence) continue;
+        if (only_length) { printf("%u\n", len); continue; }
+        printf("<%s(M=%u,L=%u): ", cls, M, len);
+        if (full || len <= 30) {
+            for (unsigned t = 0; t < len; ++t) printf("%s%u", t ? ", " : "", sym[t]);
+        } else {
+            for (unsigned t = 0; t < 10; ++t) printf("%s%u", t ? ", " : "", sym[t]);
+            printf(", ..., ");
+            for (unsigned t = len - 10; t < len; ++t) printf("%s%u", t > len - 10 ? ", " : "", sym[t]);
+        }
+        printf(">\n");
+    }
+    return 0;
+}
+
+// `ecoz2 prd show [--from a] [--to b] <file>`: header line + coefficient range, as in notes.md:77-85
+static int prd_show(int argc, char** argv)
+{
+    int from = 0, to = -1;
+    std::string file;
+    for (int i = 0; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--from" && i + 1 < argc) from = atoi(argv[++i]);
+        else if (a == "--to" && i + 1 < argc) to = atoi(argv[++i]);
+        else if (!is_flag(argv[i])) file = a;
+        else return usage();
+    }
+    if (file.empty()) return usage();
+    char cls[96];
+    int P;
+    int64_t T;
+    if (e2vq_prd_info(file.c_str(), cls, &P, &T)) return 0;
+    std::vector<double> fr((size_t)T * (P + 1));
+    if (e2vq_prd_read(file.c_str(), fr.data(), T)) return 0;
+    if (to < 0 || to > P) to = P;
+    printf("# %s:\n# className='%s', T=%lld, P=%d\n", file.c_str(), cls, (long long)T, P);
+    for (int n = from; n <= to; ++n) printf("%sr%d", n == from ? "" : ",", n);
+    printf("\n");
+    for (int64_t t = 0; t < T; ++t) {
+        for (int n = from; n <= to; ++n) printf("%s%.5f", n == from ? "" : ",", fr[(size_t)t * (P + 1) + n]);
+        printf("\n");
+    }
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc >= 2 && !strcmp(argv[1], "cversion")) {
         printf("%s\n", ecoz2_version());
         return 0;
     }
+    if (argc >= 3 && !strcmp(argv[1], "seq") && !strcmp(argv[2], "show")) return seq_show(argc - 3, argv + 3);
+    if (argc >= 3 && !strcmp(argv[1], "prd") && !strcmp(argv[2], "show")) return prd_show(argc - 3, argv + 3);
     if (argc < 3 || strcmp(argv[1], "vq") != 0) return usage();
     const std::string cmd = argv[2];
     if (cmd == "learn") return vq_learn(argc - 3, argv + 3);

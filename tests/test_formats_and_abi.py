@@ -121,3 +121,21 @@ def test_cli_file_resolution_mirrors_reference(tmp_path):
     r = _cli("vq", "show", "cb.cbook", cwd=tmp_path)
     assert "className='_', M=2, P=36" in r.stdout
     assert "ecoz2vq" in _cli("cversion", cwd=tmp_path).stdout
+
+
+def test_cli_seq_show_and_prd_show(tmp_path):
+    """Sequence::show output format (src/sequence/mod.rs:17-47); prd show header as in notes.md:77-85."""
+    e.formats.write_seq(str(tmp_path / "a.seq"), "Bm", 256, np.arange(45, dtype=np.uint16))
+    e.formats.write_seq(str(tmp_path / "b.seq"), "C", 4, np.array([3, 1, 2], dtype=np.uint16))
+    r = _cli("seq", "show", "a.seq", "b.seq", cwd=tmp_path)
+    lines = r.stdout.splitlines()
+    assert lines[0] == "<Bm(M=256,L=45): 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, ..., 35, 36, 37, 38, 39, 40, 41, 42, 43, 44>"
+    assert lines[1] == "<C(M=4,L=3): 3, 1, 2>"
+    assert _cli("seq", "show", "-L", "a.seq", cwd=tmp_path).stdout.strip() == "45"
+    assert "44>" in _cli("seq", "show", "--full", "a.seq", cwd=tmp_path).stdout and "..." not in _cli(
+        "seq", "show", "--full", "a.seq", cwd=tmp_path).stdout
+    fr = e.synth.synth_frames(1, 1, 36, 0, 3)
+    e.formats.write_prd(str(tmp_path / "x.prd"), "HB", fr)
+    out = _cli("prd", "show", "--from", "0", "--to", "2", "x.prd", cwd=tmp_path).stdout.splitlines()
+    assert out[1] == "# className='HB', T=3, P=36" and out[2] == "r0,r1,r2"
+    assert out[3] == ",".join(f"{v:.5f}" for v in fr[0, :3])
