@@ -154,11 +154,17 @@ def main():
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
         frames_per_launch = S
-        traffic = None
+        # PMC traffic cannot be collected inside this process: it comes from the separate rocprofv3 --pmc passes
+        # over this same command, recorded in profiles/traffic.json (FETCH_SIZE doubled per the gfx950 note)
+        traffic, traffic_detail = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and S == FRAMES_PER_GPU:
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_detail = {"fetch_bytes": tj.get("fetch_bytes"), "write_bytes": tj.get("write_bytes"),
+                                  "algorithmic_bytes": tj.get("algorithmic_bytes_per_launch"),
+                                  "note": "write side is dominated by the exact accumulate's 79 int64 atomics per frame"}
             except Exception:
                 traffic = None
         achieved_tf = FLOP_PER_FRAME_PASS * frames_per_launch / (k_ms * 1e-3) / 1e12
@@ -195,6 +201,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / FP64_PEAK_TFLOPS,
                 "traffic": traffic,
+                "traffic_detail": traffic_detail,
                 "kernel_ms": k_ms,
             },
             "roofline_hbm": {
