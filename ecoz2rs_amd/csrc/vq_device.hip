@@ -28,6 +28,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef const double __attribute__((address_space(4))) cdouble_k;
 typedef long long i64;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                                                        const DevScalars* __restrict__ sc,
                                                        const u64* __restrict__ l1max_bits,
                                                        unsigned short* __restrict__ sym, double* __restrict__ dmin,
-                                                       i64* __restrict__ rows)
+                                                       i64* __restrict__ rows, int stagger)
 {
     // NS k-steps of 4 cover n < 4*NS; with NC = 4*NSF + 1 the last coefficient (n = NC-1) is not padded to
     // a fifth MFMA k-step but applied as one VALU fma after the MFMA chain: same ascending order, same roundings.
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
     // (its next frame loads queue behind its own atomics in vmcnt order).  Spreading the start phases over one
     // block period turns the bursts into a steady stream; partners differ by half a period.
     if constexpr (MODE != 0 && TPBM == 512) {
-        if (nblocks >= 4 * nwaves) {
+        if (nblocks >= 4 * nwaves && stagger) {
             const int phase = (((int)blockIdx.x + 4 * (wib & 3)) & 7) + 8 * (wib >> 2);  // 0..15
             const int naps = (phase * (MT * NSM * 4 * 64 / 16)) >> 13;  // s_sleep(127) ~ 8k cycles
             for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
@@ -1133,28 +1134,26 @@ static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, c
     if (mode == 0) {
         const int grid = grid_for(nblocks, 4, 512);
         hipLaunchKernelGGL((k_pass_mfma<NC, 0, 256>), dim3(grid), dim3(256), 0, s, blk, T, nblocks, cbm, MT, M, sc,
-                           l1max_bits, sym, dmin, rows);
+                           l1max_bits, sym, dmin, rows, 0);
     } else if (mode == 1) {
         const size_t lds = (size_t)M * RS * 8 + (size_t)8 * 16 * IMG * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)k_pass_mfma<NC, 1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      E2VQ_LDS_BYTES);
-            attr_set = true;
-        }
+        // every launch: the attribute is per device, and sessions may live on several devices of one process
+        (void)hipFuncSetAttribute((const void*)k_pass_mfma<NC, 1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  E2VQ_LDS_BYTES);
         const int grid = grid_for(nblocks, 8, 256);  // one persistent 8-wave workgroup per CU
         hipLaunchKernelGGL((k_pass_mfma<NC, 1, 512>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, MT, M, sc,
-                           l1max_bits, sym, dmin, rows);
+                           l1max_bits, sym, dmin, rows, 0);
     } else if (mode == 3) {  // diagnostics: MODE 2 without the atomics
         const size_t lds = (size_t)8 * 16 * IMG * 4;
         const int grid = grid_for(nblocks, 8, 256);
         hipLaunchKernelGGL((k_pass_mfma<NC, 3, 512>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, MT, M, sc,
-                           l1max_bits, sym, dmin, rows);
+                           l1max_bits, sym, dmin, rows, 0);
     } else {
         const size_t lds = (size_t)8 * 16 * IMG * 4;
         const int grid = grid_for(nblocks, 8, 256);  // one 8-wave workgroup per CU: partner waves are w, w+4
+        static const int stagger = getenv("ECOZ2_VQ_STAGGER") ? atoi(getenv("ECOZ2_VQ_STAGGER")) : 1;  // A/B: ~1 % faster on
         hipLaunchKernelGGL((k_pass_mfma<NC, 2, 512>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, MT, M, sc,
-                           l1max_bits, sym, dmin, rows);
+                           l1max_bits, sym, dmin, rows, stagger);
     }
     return 0;
 }
@@ -1179,12 +1178,8 @@ static int launch_pass_t(int mode, const double* blk, long T, long nblocks, cons
                            sym, dmin, rows);
     } else if (mode == 1) {
         const size_t lds = (size_t)M * RS * 8;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)k_pass<NC, F, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      E2VQ_LDS_BYTES);
-            attr_set = true;
-        }
+        (void)hipFuncSetAttribute((const void*)k_pass<NC, F, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  E2VQ_LDS_BYTES);
         // persistent: few workgroups so the per-workgroup table flush stays small
         const int grid = grid_for(nblocks, waves_per_block, 512);
         hipLaunchKernelGGL((k_pass<NC, F, 1>), dim3(grid), dim3(TPB), lds, s, blk, T, nblocks, cbq, M, sc, l1max_bits,

@@ -1,0 +1,19 @@
+import os, sys, subprocess
+root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+code = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+import ecoz2rs_amd as e
+P, M, S = 36, 1024, 1 << 21
+frames = e.synth.synth_frames(20244, 20, P, 0, S)
+os.environ["ECOZ2_VQ_QUIET"] = "1"
+s = e.VqSession(P); s.set_frames(frames); s.prepare(); s.init_codebook(); s.learn(0.05, 512); s.grow()
+s.enable_timing(True)
+ts = []
+for i in range(12):
+    s.run_pass(None, None); ts.append(s.last_pass_kernel_ms()); s.pass_stats(); s.update()
+print("stagger", os.environ.get("ECOZ2_VQ_STAGGER", "0"), "kernel ms", np.round(ts[2:], 3), "mean", round(float(np.mean(ts[2:])), 4))
+'''
+for st in ("0", "1", "0", "1"):
+    subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, ECOZ2_VQ_STAGGER=st))
