@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-lib_path = os.path.join(_HERE, "csrc", "libecoz2vq.so")
+lib_path = os.environ.get("ECOZ2VQ_LIB") or os.path.join(_HERE, "csrc", "libecoz2vq.so")  # override: A/B builds
 
 
 class Ecoz2Error(RuntimeError):

@@ -316,6 +316,9 @@ __global__ __launch_bounds__(TPB) void k_pass(const double* __restrict__ blk, lo
 //            codewords beyond M are copies of codeword 0 (they can never win a tie)
 // ------------------------------------------------------------------------------------------
 typedef double d4 __attribute__((ext_vector_type(4)));
+#ifndef E2VQ_PRIO
+#define E2VQ_PRIO 1
+#endif
 
 __global__ void k_blockify_mfma(const double* __restrict__ aos, long T, int NC, double* __restrict__ blk,
                                 long nblocks)
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
     // NS k-steps of 4 cover n < 4*NS; with NC = 4*NSF + 1 the last coefficient (n = NC-1) is not padded to
     // a fifth MFMA k-step but applied as one VALU fma after the MFMA chain: same ascending order, same roundings.
     constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2, REM = NC - 4 * (NS - 1);
+    constexpr bool PRIO = E2VQ_PRIO;
     constexpr bool TAILV = REM == 1;           // single trailing coefficient -> VALU
     constexpr int NSM = TAILV ? NS - 1 : NS;   // k-steps run on the matrix pipe
     constexpr int RS = (2 * NC + 5 + 7) & ~7;
@@ -426,32 +430,27 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             code[ft] = 0;
         }
         const double* ctail = cbm + (long)MT * NP * 128;  // [tile][q][rg]: cq[16*tile + 4*rg + q][NC-1]
-        double2 An[NP];
-        d4 Tn = {0.0, 0.0, 0.0, 0.0};
+        // one codeword tile: 36 MFMAs (+ the trailing coefficient on the VALU), then the per-lane running argmin.
+        // The A image is ping-ponged between two register sets (tile loop unrolled by two) so the prefetch of the
+        // next tile lands in the other set and no register copies are needed.
+        auto load_tile = [&](int t, double2 (&An)[NP], d4& Tn) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) An[p] = *(const double2*)(cbm + ((long)p * 64 + lane) * 2);
-        if (TAILV) Tn = *(const d4*)(ctail + q * 4);
-        for (int ct = 0; ct < MT; ++ct) {
-            double A[2 * NP];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                A[2 * p] = An[p].x;
-                A[2 * p + 1] = An[p].y;
-            }
-            const d4 Tc = Tn;
-            const int nt = ct + 1 < MT ? ct + 1 : ct;  // prefetch the next codeword tile (L2 resident)
-#pragma unroll
-            for (int p = 0; p < NP; ++p) An[p] = *(const double2*)(cbm + (((long)nt * NP + p) * 64 + lane) * 2);
-            if (TAILV) Tn = *(const d4*)(ctail + (long)nt * 16 + q * 4);
+            for (int p = 0; p < NP; ++p) An[p] = *(const double2*)(cbm + (((long)t * NP + p) * 64 + lane) * 2);
+            if (TAILV) Tn = *(const d4*)(ctail + (long)t * 16 + q * 4);
+        };
+        auto do_tile = [&](int ct, const double2 (&Ac)[NP], const d4& Tc) {
             d4 acc[4];
+            if (PRIO) __builtin_amdgcn_s_setprio(1);  // the wave feeding the matrix pipe wins issue arbitration
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft)
-                acc[ft] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[0], Bf[ft][0], (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+                acc[ft] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ac[0].x, Bf[ft][0], (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
 #pragma unroll
             for (int st = 1; st < NSM; ++st)
 #pragma unroll
                 for (int ft = 0; ft < 4; ++ft)
-                    acc[ft] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[st], Bf[ft][st], acc[ft], 0, 0, 0);
+                    acc[ft] = __builtin_amdgcn_mfma_f64_16x16x4f64((st & 1) ? Ac[st >> 1].y : Ac[st >> 1].x, Bf[ft][st],
+                                                                   acc[ft], 0, 0, 0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
             if (TAILV) {
 #pragma unroll
                 for (int ft = 0; ft < 4; ++ft)
@@ -460,14 +459,30 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             }
             // lane (q, j) sees codewords 16ct + 4rg + q of frame j: ascending in (ct, rg)
 #pragma unroll
-            for (int ft = 0; ft < 4; ++ft)
+            for (int rg = 0; rg < 4; ++rg) {
+                const int cval = __builtin_amdgcn_readfirstlane(ct * 4 + rg);  // wave-uniform: stays in an SGPR
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
+                for (int ft = 0; ft < 4; ++ft) {
                     const double v = acc[ft][rg];
                     const bool lt = v < best[ft];
-                    code[ft] = lt ? ct * 4 + rg : code[ft];
-                    best[ft] = __builtin_fmin(best[ft], v);
+                    code[ft] = lt ? cval : code[ft];
+                    // raw v_min_f64: min() of finite values needs no NaN canonicalisation (inputs are validated)
+                    asm("v_min_f64 %0, %1, %2" : "=v"(best[ft]) : "v"(best[ft]), "v"(v));
                 }
+            }
+        };
+        {
+            double2 A0[NP], A1[NP];
+            d4 T0 = {0.0, 0.0, 0.0, 0.0}, T1 = {0.0, 0.0, 0.0, 0.0};
+            load_tile(0, A0, T0);
+            int ct = 0;
+            for (; ct + 1 < MT; ct += 2) {
+                load_tile(ct + 1, A1, T1);
+                do_tile(ct, A0, T0);
+                load_tile(ct + 2 < MT ? ct + 2 : ct + 1, A0, T0);
+                do_tile(ct + 1, A1, T1);
+            }
+            if (ct < MT) do_tile(ct, A0, T0);
         }
 
         // ---- combine the four lanes (q = 0..3) that hold one frame: min value, lowest index ---

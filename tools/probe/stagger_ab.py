@@ -15,5 +15,11 @@ for i in range(12):
     s.run_pass(None, None); ts.append(s.last_pass_kernel_ms()); s.pass_stats(); s.update()
 print("stagger", os.environ.get("ECOZ2_VQ_STAGGER", "0"), "kernel ms", np.round(ts[2:], 3), "mean", round(float(np.mean(ts[2:])), 4))
 '''
-for st in ("0", "1", "0", "1"):
-    subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, ECOZ2_VQ_STAGGER=st))
+variants = sys.argv[1:] or ["default"]
+for rnd in range(2):
+    for v in variants:
+        env = dict(os.environ)
+        if v != "default":
+            env["ECOZ2VQ_LIB"] = os.path.join(root, "tools", "probe", "ab", v)
+        print("lib:", v, flush=True)
+        subprocess.run([sys.executable, "-c", code, root], env=env)
