@@ -846,12 +846,15 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
     if (rows) {
         const i64* row = rows + (long)m * RS;
         const i64 cnt = row[2 * NC];
+        // level statistics: 64 slots of 8 words (same-address atomics serialise at the memory side; the host
+        // adds the slots -- integers, so still exact)
+        i64* ls = lstats + (blockIdx.x & 63) * 8;
         if (lane == 0) {
-            atomicAdd((u64*)&lstats[0], (u64)row[2 * NC + 1]);
-            atomicAdd((u64*)&lstats[1], (u64)row[2 * NC + 2]);
-            atomicAdd((u64*)&lstats[2], (u64)row[2 * NC + 3]);
-            atomicAdd((u64*)&lstats[3], (u64)row[2 * NC + 4]);
-            if (cnt == 0) atomicAdd((u64*)&lstats[4], 1ull);
+            atomicAdd((u64*)&ls[0], (u64)row[2 * NC + 1]);
+            atomicAdd((u64*)&ls[1], (u64)row[2 * NC + 2]);
+            atomicAdd((u64*)&ls[2], (u64)row[2 * NC + 3]);
+            atomicAdd((u64*)&ls[3], (u64)row[2 * NC + 4]);
+            if (cnt == 0) atomicAdd((u64*)&ls[4], 1ull);
         }
         if (cnt != 0) {  // wave-uniform
             const double S = act ? unfix(row[2 * lane], row[2 * lane + 1], sc->sh_r) : 0.0;
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
                 fresh = true;
                 have_a = true;
             } else if (lane == 0) {
-                atomicAdd((u64*)&lstats[5], 1ull);
+                atomicAdd((u64*)&ls[5], 1ull);
             }
         } else if (lane == 0) {
             within[m] = 0.0;
@@ -982,7 +985,10 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
         for (int u = 0; u < 8; ++u)
             if (n0 + u <= P) l1 += t[u];
     }
-    if (lane == 0) atomicMax(l1max_bits, (u64)__double_as_longlong(l1));
+    if (lane == 0) {  // monotone max: skip the atomic unless it can still raise the value
+        const u64 bits = (u64)__double_as_longlong(l1);
+        if (bits > __hip_atomic_load(l1max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(l1max_bits, bits);
+    }
     if (lane < NPAD) cbq[(long)m * NPAD + lane] = act ? c : 0.0;
     if (cbm) {
         const int NS = (NC + 3) >> 2, NP = (NS + 1) >> 1;

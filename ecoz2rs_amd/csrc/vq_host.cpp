@@ -83,7 +83,7 @@ struct e2vq_session {
     u64* d_l1max_spec = nullptr;
     bool spec_valid = false;
     hipEvent_t ev_stats = nullptr;
-    struct HostStats { i64 l[8]; u64 l1bits; }* h_stats = nullptr;  // pinned
+    struct HostStats { i64 l[64 * 8]; u64 l1bits; }* h_stats = nullptr;  // pinned
     double* h_within = nullptr;                                      // pinned, M_cap doubles
     // statistics
     DevScalars* d_sc = nullptr;
@@ -94,7 +94,7 @@ struct e2vq_session {
     i64* d_rows = nullptr;    // [M][RS]
     double* d_S = nullptr;    // [M][NC]
     double* d_within = nullptr;
-    i64* d_lstats = nullptr;  // [8]
+    i64* d_lstats = nullptr;  // [64 slots][8]: dist, dist2 limbs, empty, failed (slots are summed on the host)
     bool stats_valid = false;
     e2vq_level_stats last{};
     double DDprv = DBL_MAX / 1e5;  // "e+303" in notes.md:128
@@ -195,7 +195,7 @@ extern "C" int e2vq_session_create(int device, int prediction_order, e2vq_sessio
     HIPCHK(hipMalloc(&s->d_l1max, 8));
     HIPCHK(hipMalloc(&s->d_flags, 2 * sizeof(int)));
     HIPCHK(hipMalloc(&s->d_stats, (size_t)(2 * s->NC + 3) * 8));
-    HIPCHK(hipMalloc(&s->d_lstats, 8 * 8));
+    HIPCHK(hipMalloc(&s->d_lstats, 64 * 8 * 8));
     HIPCHK(hipMemset(s->d_sc, 0, sizeof(DevScalars)));
     HIPCHK(hipEventCreate(&s->ev0));
     HIPCHK(hipEventCreate(&s->ev1));
@@ -435,7 +435,7 @@ extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
         if (out) *out = s->last;
         return 0;
     }
-    HIPCHK(hipMemsetAsync(s->d_lstats, 0, 8 * 8, s->stream));
+    HIPCHK(hipMemsetAsync(s->d_lstats, 0, 64 * 8 * 8, s->stream));
     const bool fused = e2vq::has_cell_update(s->NC);
     if (fused)  // statistics + speculative update into the shadow codebook in ONE wave-per-cell kernel
         e2vq::launch_cell_update(s->d_rows, s->M, s->NC, s->d_sc, s->d_refl, s->d_refl_spec, s->d_cbq_spec,
@@ -454,7 +454,9 @@ extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
     HIPCHK(hipGetLastError());
     s->spec_valid = true;
     HIPCHK(hipEventSynchronize(s->ev_stats));
-    const i64* l = s->h_stats->l;
+    i64 l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int slot = 0; slot < 64; ++slot)
+        for (int k = 0; k < 8; ++k) l[k] += s->h_stats->l[slot * 8 + k];
     double l1max;
     memcpy(&l1max, &s->h_stats->l1bits, 8);
     const int Ed = e2vq::dist_exponent(s->h_sc.maxabs, l1max);
