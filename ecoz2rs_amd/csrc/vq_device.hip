@@ -346,7 +346,9 @@ __global__ void k_blockify_mfma(const double* __restrict__ aos, long T, int NC, 
     }
 }
 
-template <int NC, int MODE, int TPBM>
+// AOS = true (quantize): `blk` is the row-major .prd payload [t][NC]; each wave stages its 64 rows through LDS
+// with coalesced 16-B loads and picks its B operands from there, so no re-layout pass is needed.
+template <int NC, int MODE, int TPBM, bool AOS = false>
 __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict__ blk, long T, long nblocks,
                                                        const double* __restrict__ cbm, int MT, int M,
                                                        const DevScalars* __restrict__ sc,
@@ -403,6 +405,36 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
         // ---- frames -> B operands (resident for the whole sweep) ---------------------------
         double Bf[4][2 * NP];
         const double* fb = blk + b * (long)(NC * 64);
+        if constexpr (AOS) {
+            static_assert(MODE == 0, "the AoS path serves the assignment-only kernel");
+            double* stage = (double*)smem + wib * (NC * 64);  // this wave's 64 rows
+            const long remaining = (T - b * 64) * NC;         // doubles left in the payload from this block on
+            constexpr int CHUNKS = NC * 64 / 2;               // 16-B chunks per block
+#pragma unroll
+            for (int c0 = 0; c0 < CHUNKS; c0 += 64) {
+                const int c = c0 + lane;
+                if (c < CHUNKS) {
+                    double2 v = make_double2(0.0, 0.0);
+                    if (2 * c + 1 < remaining)
+                        v = *(const double2*)(fb + 2 * c);
+                    else if (2 * c < remaining)
+                        v.x = fb[2 * c];
+                    *(double2*)(stage + 2 * c) = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const double* row = stage + (16 * ft + j) * NC;
+#pragma unroll
+                for (int st = 0; st < NS - 1; ++st) Bf[ft][st] = row[4 * st + q];
+                Bf[ft][NS - 1] = TAILV ? row[NC - 1] : (q < REM ? row[4 * (NS - 1) + q] : 0.0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const double* base = fb + u * (NC * 32);
@@ -1155,6 +1187,13 @@ static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, c
     if (mode == 0) {
         const int grid = grid_for(nblocks, 4, 512);
         hipLaunchKernelGGL((k_pass_mfma<NC, 0, 256>), dim3(grid), dim3(256), 0, s, blk, T, nblocks, cbm, MT, M, sc,
+                           l1max_bits, sym, dmin, rows, 0);
+    } else if (mode == 4) {  // assignment only, frames in row-major (.prd) layout
+        const size_t lds = (size_t)4 * NC * 64 * 8;
+        (void)hipFuncSetAttribute((const void*)k_pass_mfma<NC, 0, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  E2VQ_LDS_BYTES);
+        const int grid = grid_for(nblocks, 4, 512);
+        hipLaunchKernelGGL((k_pass_mfma<NC, 0, 256, true>), dim3(grid), dim3(256), lds, s, blk, T, nblocks, cbm, MT, M, sc,
                            l1max_bits, sym, dmin, rows, 0);
     } else if (mode == 1) {
         const size_t lds = (size_t)M * RS * 8 + (size_t)8 * 16 * IMG * 4;

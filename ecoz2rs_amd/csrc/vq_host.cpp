@@ -13,6 +13,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -103,7 +104,7 @@ struct e2vq_session {
     double* d_qblk = nullptr;
     unsigned short* d_qsym = nullptr;
     double* d_qdmin = nullptr;
-    i64 q_cap = 0;
+    i64 q_cap = 0, qblk_cap = 0;
     // HIP events around the sweep kernel (bench.py's roofline figures)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false, timed = false;
@@ -581,25 +582,34 @@ extern "C" int e2vq_learn(e2vq_session* s, double epsilon, int max_M, const char
 
 // ---- quantize --------------------------------------------------------------------------------
 
+// staging buffers of e2vq_quantize_host (row-major frames in, symbols / distortions out)
 static int ensure_quantize_scratch(e2vq_session* s, i64 T, bool need_aos, bool need_out)
 {
-    if (T <= s->q_cap && (!need_aos || s->d_qaos) && (!need_out || s->d_qsym)) return 0;
     HIPCHK(hipSetDevice(s->device));
-    const i64 cap = std::max<i64>(T, s->q_cap);
-    const i64 nb = (cap + s->FB - 1) / s->FB;
-    if (cap > s->q_cap || !s->d_qblk) {
-        if (s->d_qblk) (void)hipFree(s->d_qblk);
-        HIPCHK(hipMalloc(&s->d_qblk, (size_t)nb * s->NC * s->FB * 8));
+    if (T > s->q_cap) {
         if (s->d_qaos) { (void)hipFree(s->d_qaos); s->d_qaos = nullptr; }
         if (s->d_qsym) { (void)hipFree(s->d_qsym); s->d_qsym = nullptr; }
         if (s->d_qdmin) { (void)hipFree(s->d_qdmin); s->d_qdmin = nullptr; }
+        s->q_cap = T;
     }
-    if (need_aos && !s->d_qaos) HIPCHK(hipMalloc(&s->d_qaos, (size_t)cap * s->NC * 8));
+    if (need_aos && !s->d_qaos) HIPCHK(hipMalloc(&s->d_qaos, (size_t)s->q_cap * s->NC * 8));
     if (need_out && !s->d_qsym) {
-        HIPCHK(hipMalloc(&s->d_qsym, (size_t)cap * 2 + 64));
-        HIPCHK(hipMalloc(&s->d_qdmin, (size_t)cap * 8));
+        HIPCHK(hipMalloc(&s->d_qsym, (size_t)s->q_cap * 2 + 64));
+        HIPCHK(hipMalloc(&s->d_qdmin, (size_t)s->q_cap * 8));
     }
-    s->q_cap = cap;
+    return 0;
+}
+
+// re-layout buffer for the kernels that do not read the row-major payload directly (P != 36)
+static int ensure_qblk(e2vq_session* s, i64 T)
+{
+    if (T <= s->qblk_cap && s->d_qblk) return 0;
+    HIPCHK(hipSetDevice(s->device));
+    if (s->d_qblk) (void)hipFree(s->d_qblk);
+    s->d_qblk = nullptr;
+    const i64 nb = (T + s->FB - 1) / s->FB;
+    HIPCHK(hipMalloc(&s->d_qblk, (size_t)nb * s->NC * s->FB * 8));
+    s->qblk_cap = T;
     return 0;
 }
 
@@ -609,8 +619,15 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
     if (s->M < 1) return e2vq_set_error("no codebook");
     if (T < 1) return 0;
     HIPCHK(hipSetDevice(s->device));
-    if (ensure_quantize_scratch(s, T, false, false)) return 1;
     const i64 nb = (T + s->FB - 1) / s->FB;
+    if (e2vq::uses_mfma(s->NC) && ((uintptr_t)device_frames & 15) == 0) {
+        // P = 36: the sweep reads the row-major payload directly (coalesced staging through LDS)
+        e2vq::launch_pass(s->NC, 4, (const double*)device_frames, T, nb, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max,
+                          (unsigned short*)device_sym, (double*)device_dmin, nullptr, s->stream);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    if (ensure_qblk(s, T)) return 1;
     e2vq::launch_blockify((const double*)device_frames, T, s->NC, s->FB, s->d_qblk, nb, s->stream);
     e2vq::launch_pass(s->NC, 0, s->d_qblk, T, nb, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                       (double*)device_dmin, nullptr, s->stream);
