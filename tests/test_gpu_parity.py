@@ -38,7 +38,7 @@ def test_quantize_bit_exact(oracle, T, M):
     assert np.array_equal(dmin.view(np.uint64), dmin_o.view(np.uint64))
 
 
-@pytest.mark.parametrize("T,M", [(1000, 2), (4096, 16), (10000, 128), (7777, 256), (20000, 1024)])
+@pytest.mark.parametrize("T,M", [(1000, 2), (4096, 16), (10000, 128), (7777, 256), (20000, 1024), (9000, 2048), (6000, 4096)])
 def test_pass_rows_bit_exact(oracle, T, M):
     """One LBG pass: per-cell exact sums, counts and distortion sums equal the oracle's."""
     frames = _frames(20242, T)
