@@ -318,3 +318,51 @@ def test_large_prediction_order_generic_path(oracle):
         refl = s.get_codebook()
     assert cbs == cbs_o
     assert np.array_equal(refl.view(np.uint64), levels_o[-1]["reflections"].view(np.uint64))
+
+
+def test_cli_end_to_end(tmp_path, oracle):
+    """`ecoz2 vq learn` -> `vq quantize` -> `vq classify` -> `seq show` through the CLI binary (reference flags)."""
+    exe = os.path.join(ROOT, "ecoz2rs_amd", "csrc", "ecoz2")
+    env = dict(os.environ, ECOZ2_VQ_MAX_CODEBOOK_SIZE="8")
+    env.pop("ECOZ2_VQ_OUT_ROOT", None)
+    env.pop("ECOZ2_VQ_QUIET", None)
+
+    def run(*args):
+        r = subprocess.run([exe, *args], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        return r.stdout
+
+    classes = {"A": 11, "B": 22}
+    rows = ["tt,class,selection"]
+    for cls, seed in classes.items():
+        for i in range(4):
+            fr = e.synth.synth_frames(seed, 1, P, 1000 * i, 400)
+            e.formats.write_prd(str(tmp_path / "data" / "predictors" / cls / f"{i:05d}.prd"), cls, fr)
+            rows.append(f"{'TRAIN' if i < 3 else 'TEST'},{cls},{i:05d}")
+    (tmp_path / "tt.csv").write_text("\n".join(rows) + "\n")
+    for cls in classes:  # one codebook per class from its TRAIN files (tt-list + --class-name, src/vq/mod.rs:50-58)
+        out = run("vq", "learn", "-P", "36", "-e", "0.05", "--class-name", cls, "--predictors", "tt.csv")
+        assert "predictor_filenames: 3" in out and f"codebook_class_name={cls}" in out
+        assert "Ecoz2ObserverRef.step: M=8" in out and "1200 training vectors" in out
+        assert (tmp_path / "data" / "codebooks" / cls / "eps_0.05_M_0008.cbook").exists()
+    # the codebook the CLI wrote equals the oracle's for the same frames in sorted-file order
+    frames_a = np.concatenate([e.formats.read_prd(str(tmp_path / "data" / "predictors" / "A" / f"{i:05d}.prd"))[2]
+                               for i in range(3)])
+    rc, levels_o, _ = oracle.learn(frames_a, 0.05, 8)
+    _c, _p, refl = e.formats.read_cbook(str(tmp_path / "data" / "codebooks" / "A" / "eps_0.05_M_0008.cbook"))
+    assert np.array_equal(refl.view(np.uint64), levels_o[-1]["reflections"].view(np.uint64))
+    out = run("vq", "quantize", "--codebook", "data/codebooks/A/eps_0.05_M_0008.cbook", "--predictors",
+              "data/predictors", "-s")
+    assert "number of predictor files: 8" in out
+    seq = tmp_path / "data" / "sequences" / "M8" / "B" / "00003.seq"
+    assert seq.exists()
+    out = run("seq", "show", str(seq))
+    assert out.startswith("<B(M=8,L=400): ")
+    out = run("vq", "classify", "--codebooks", "data/codebooks/A/eps_0.05_M_0008.cbook",
+              "data/codebooks/B/eps_0.05_M_0008.cbook", "--tt", "TEST", "--predictors", "tt.csv")
+    assert "number of codebooks: 2  number of predictors: 2" in out
+    assert "100.00%" in out.split("TOTAL")[1]
+    # resume from a base codebook with the CLI (-B): next size only
+    env["ECOZ2_VQ_MAX_CODEBOOK_SIZE"] = "16"
+    out = run("vq", "learn", "-B", "data/codebooks/A/eps_0.05_M_0008.cbook", "--predictors", "data/predictors/A")
+    assert "Ecoz2ObserverRef.step: M=16" in out and "M=8 " not in out.split("base codebook")[1]
