@@ -380,10 +380,14 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
         sh_d = 30 - Ed;
         sh_d2 = 30 - 2 * Ed;
     }
-    i64* lacc = (i64*)smem;  // MODE 1: [M][RS] table shared by the workgroup
-    int* img = (int*)(smem + (MODE == 1 ? (size_t)M * RS * 8 : 0)) + wib * (16 * IMG);
-    if constexpr (MODE == 1) {
-        for (int i = threadIdx.x; i < M * RS; i += TPBM) lacc[i] = 0;
+    // LDS accumulator table shared by the workgroup: all cells (MODE 1, M <= 128) or the first HYB_CELLS cells
+    // (MODE 5, 128 < M <= 512: the other cells take global atomics, whose traffic drops accordingly)
+    constexpr int HYB_CELLS = 176;  // 176 x 640 B + 42 KB of images = 151 KB of the 160 KB LDS
+    const int lds_cells = MODE == 1 ? M : (MODE == 5 ? HYB_CELLS : 0);
+    i64* lacc = (i64*)smem;
+    int* img = (int*)(smem + (size_t)lds_cells * RS * 8) + wib * (16 * IMG);
+    if constexpr (MODE == 1 || MODE == 5) {
+        for (int i = threadIdx.x; i < lds_cells * RS; i += TPBM) lacc[i] = 0;
         __syncthreads();
     }
     // Two waves share a SIMD (waves w and w+4 of an 8-wave workgroup).  Left alone they run in lockstep and
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
     // (its next frame loads queue behind its own atomics in vmcnt order).  Spreading the start phases over one
     // block period turns the bursts into a steady stream; partners differ by half a period.
     if constexpr (MODE != 0 && TPBM == 512) {
-        if (nblocks >= 4 * nwaves && stagger) {
+        if (nblocks >= 4 * nwaves && stagger && MT >= 16) {
             const int phase = (((int)blockIdx.x + 4 * (wib & 3)) & 7) + 8 * (wib >> 2);  // 0..15
             const int naps = (phase * (MT * NSM * 4 * 64 / 16)) >> 13;  // s_sleep(127) ~ 8k cycles
             for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
@@ -589,28 +593,49 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                         }
                         const int tv = te < NE - 64 ? img[(j0 + tq) * IMG + 64 + te] : 0;
                         const int tcell = tq == 0 ? cell[0] : tq == 1 ? cell[1] : tq == 2 ? cell[2] : cell[3];
-                        i64* base = MODE == 1 ? lacc : rows;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            if constexpr (MODE == 3)
+                            if constexpr (MODE == 3) {
                                 asm volatile("" ::"v"(v[k]), "s"(cell[k]));
-                            else
-                                atomicAdd((u64*)&base[(long)cell[k] * RS + lane], (u64)(i64)v[k]);
+                            } else if constexpr (MODE == 1) {
+                                atomicAdd((u64*)&lacc[cell[k] * RS + lane], (u64)(i64)v[k]);
+                            } else if constexpr (MODE == 5) {
+                                if (cell[k] < HYB_CELLS)  // wave-uniform
+                                    atomicAdd((u64*)&lacc[cell[k] * RS + lane], (u64)(i64)v[k]);
+                                else
+                                    atomicAdd((u64*)&rows[(long)cell[k] * RS + lane], (u64)(i64)v[k]);
+                            } else {
+                                atomicAdd((u64*)&rows[(long)cell[k] * RS + lane], (u64)(i64)v[k]);
+                            }
                         }
                         if (te < NE - 64) {
-                            if constexpr (MODE == 3)
+                            if constexpr (MODE == 3) {
                                 asm volatile("" ::"v"(tv), "v"(tcell));
-                            else
-                                atomicAdd((u64*)&base[(long)tcell * RS + 64 + te], (u64)(i64)tv);
+                            } else if constexpr (MODE == 1) {
+                                atomicAdd((u64*)&lacc[tcell * RS + 64 + te], (u64)(i64)tv);
+                            } else if constexpr (MODE == 5) {
+                                if (tcell < HYB_CELLS)  // per 16-lane group
+                                    atomicAdd((u64*)&lacc[tcell * RS + 64 + te], (u64)(i64)tv);
+                                else
+                                    atomicAdd((u64*)&rows[(long)tcell * RS + 64 + te], (u64)(i64)tv);
+                            } else {
+                                atomicAdd((u64*)&rows[(long)tcell * RS + 64 + te], (u64)(i64)tv);
+                            }
                         }
                     }
                 } else {
                     for (int jj = 0; jj < nv; ++jj) {
                         const int cell = __builtin_amdgcn_readlane(idx[ft], jj);
-                        i64* row = (MODE == 1 ? lacc : rows) + (long)cell * RS;
                         const int* im = img + jj * IMG;
-                        if (lane < NE) atomicAdd((u64*)&row[lane], (u64)(i64)im[lane]);
-                        if (NE > 64 && lane < NE - 64) atomicAdd((u64*)&row[64 + lane], (u64)(i64)im[64 + lane]);
+                        if (cell < lds_cells) {  // wave-uniform
+                            i64* row = lacc + cell * RS;
+                            if (lane < NE) atomicAdd((u64*)&row[lane], (u64)(i64)im[lane]);
+                            if (NE > 64 && lane < NE - 64) atomicAdd((u64*)&row[64 + lane], (u64)(i64)im[64 + lane]);
+                        } else {
+                            i64* row = rows + (long)cell * RS;
+                            if (lane < NE) atomicAdd((u64*)&row[lane], (u64)(i64)im[lane]);
+                            if (NE > 64 && lane < NE - 64) atomicAdd((u64*)&row[64 + lane], (u64)(i64)im[64 + lane]);
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -620,9 +645,9 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
         }
     }
 
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 1 || MODE == 5) {
         __syncthreads();
-        for (int i = threadIdx.x; i < M * RS; i += TPBM) {
+        for (int i = threadIdx.x; i < lds_cells * RS; i += TPBM) {
             const i64 v = lacc[i];
             if (v != 0) atomicAdd((u64*)&rows[i], (u64)v);
         }
@@ -1203,6 +1228,14 @@ static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, c
         const int grid = grid_for(nblocks, 8, 256);  // one persistent 8-wave workgroup per CU
         hipLaunchKernelGGL((k_pass_mfma<NC, 1, 512>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, MT, M, sc,
                            l1max_bits, sym, dmin, rows, 0);
+    } else if (mode == 5) {  // hybrid: cells < 176 in the LDS table, the rest by global atomics
+        const size_t lds = (size_t)176 * RS * 8 + (size_t)8 * 16 * IMG * 4;
+        (void)hipFuncSetAttribute((const void*)k_pass_mfma<NC, 5, 512>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  E2VQ_LDS_BYTES);
+        const int grid = grid_for(nblocks, 8, 256);
+        static const int stagger = getenv("ECOZ2_VQ_STAGGER") ? atoi(getenv("ECOZ2_VQ_STAGGER")) : 1;
+        hipLaunchKernelGGL((k_pass_mfma<NC, 5, 512>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, MT, M, sc,
+                           l1max_bits, sym, dmin, rows, stagger);
     } else if (mode == 3) {  // diagnostics: MODE 2 without the atomics
         const size_t lds = (size_t)8 * 16 * IMG * 4;
         const int grid = grid_for(nblocks, 8, 256);

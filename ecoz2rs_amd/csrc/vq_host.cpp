@@ -391,7 +391,9 @@ static int pass_mode(const e2vq_session* s)
 {
     if (const char* f = getenv("ECOZ2_VQ_FORCE_MODE")) return atoi(f);  // diagnostics only (0 = assignment only)
     if (!e2vq::has_register_kernel(s->NC)) return 2;
-    return s->M <= e2vq::lds_mode_max_M(s->NC) && s->M <= 128 ? 1 : 2;
+    if (s->M <= e2vq::lds_mode_max_M(s->NC) && s->M <= 128) return 1;
+    if (e2vq::uses_mfma(s->NC) && s->M <= 512) return 5;  // hybrid LDS/global accumulate (atomic-bound levels)
+    return 2;
 }
 
 extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
