@@ -23,6 +23,7 @@
 #include <vector>
 
 using e2vq::DevScalars;
+#define E2VQ_MAX_PASSES 1000  // safety cap per codebook size (same in the oracle)
 typedef long long i64;
 typedef unsigned long long u64;
 
@@ -169,6 +170,27 @@ static int ensure_codebook_capacity(e2vq_session* s, int M)
     return 0;
 }
 
+static int session_init(e2vq_session* s)
+{
+    HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    s->stream = s->own_stream;
+    HIPCHK(hipMalloc(&s->d_sc, sizeof(DevScalars)));
+    HIPCHK(hipMalloc(&s->d_maxabs, 8));
+    HIPCHK(hipMalloc(&s->d_l1max, 8));
+    HIPCHK(hipMalloc(&s->d_flags, 2 * sizeof(int)));
+    HIPCHK(hipMalloc(&s->d_stats, (size_t)(2 * s->NC + 3) * 8));
+    HIPCHK(hipMalloc(&s->d_lstats, 64 * 8 * 8));
+    HIPCHK(hipMemset(s->d_sc, 0, sizeof(DevScalars)));
+    HIPCHK(hipEventCreate(&s->ev0));
+    HIPCHK(hipEventCreate(&s->ev1));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_stats, hipEventDisableTiming));
+    HIPCHK(hipMalloc(&s->d_l1max_spec, 8));
+    HIPCHK(hipHostMalloc(&s->h_stats, sizeof(*s->h_stats)));
+    return 0;
+}
+
+extern "C" void e2vq_session_destroy(e2vq_session* s);
+
 extern "C" int e2vq_session_create(int device, int prediction_order, e2vq_session** out)
 {
     *out = nullptr;
@@ -189,20 +211,10 @@ extern "C" int e2vq_session_create(int device, int prediction_order, e2vq_sessio
     s->FB = 64 * s->F;
     s->RS = e2vq::row_stride(s->NC);
     s->NPAD = e2vq::cb_pad(s->NC);
-    HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
-    s->stream = s->own_stream;
-    HIPCHK(hipMalloc(&s->d_sc, sizeof(DevScalars)));
-    HIPCHK(hipMalloc(&s->d_maxabs, 8));
-    HIPCHK(hipMalloc(&s->d_l1max, 8));
-    HIPCHK(hipMalloc(&s->d_flags, 2 * sizeof(int)));
-    HIPCHK(hipMalloc(&s->d_stats, (size_t)(2 * s->NC + 3) * 8));
-    HIPCHK(hipMalloc(&s->d_lstats, 64 * 8 * 8));
-    HIPCHK(hipMemset(s->d_sc, 0, sizeof(DevScalars)));
-    HIPCHK(hipEventCreate(&s->ev0));
-    HIPCHK(hipEventCreate(&s->ev1));
-    HIPCHK(hipEventCreateWithFlags(&s->ev_stats, hipEventDisableTiming));
-    HIPCHK(hipMalloc(&s->d_l1max_spec, 8));
-    HIPCHK(hipHostMalloc(&s->h_stats, sizeof(*s->h_stats)));
+    if (session_init(s)) {  // message already set; release whatever was created
+        e2vq_session_destroy(s);
+        return 1;
+    }
     *out = s;
     return 0;
 }
@@ -211,7 +223,7 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    (void)hipStreamSynchronize(s->stream);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
     void* ptrs[] = {s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
                     s->d_qdmin};
@@ -525,7 +537,11 @@ extern "C" int e2vq_learn(e2vq_session* s, double epsilon, int max_M, const char
     if (s->M < 1) return e2vq_set_error("no codebook: call e2vq_init_codebook or e2vq_set_codebook");
     const bool verbose = getenv("ECOZ2_VQ_QUIET") == nullptr && s->rank == 0;
     const bool write_files = out_root != nullptr && s->rank == 0;
-    FILE* rpt = nullptr;
+    struct FileCloser {  // the report is closed on every return path
+        FILE* f = nullptr;
+        ~FileCloser() { if (f) fclose(f); }
+    } rpt_guard;
+    FILE*& rpt = rpt_guard.f;
     char path[4096];
     if (write_files) {
         snprintf(path, sizeof path, "%s/data/codebooks/%s/eps_%g.rpt", out_root, class_name, epsilon);
@@ -559,7 +575,8 @@ extern "C" int e2vq_learn(e2vq_session* s, double epsilon, int max_M, const char
                            s->M);
             }
             // pass 0 never ends a level; DDprv carries over between levels (notes.md:128-153)
-            const bool converged = pass > 0 && !(ratio >= epsilon);
+            // (a level also ends after E2VQ_MAX_PASSES passes: eps <= 0 would otherwise never terminate)
+            const bool converged = (pass > 0 && !(ratio >= epsilon)) || pass + 1 >= E2VQ_MAX_PASSES;
             s->DDprv = DD;
             if (converged) break;
             if (e2vq_update(s)) return 1;
@@ -577,7 +594,6 @@ extern "C" int e2vq_learn(e2vq_session* s, double epsilon, int max_M, const char
         ++nlev;
         if (callback && s->rank == 0) callback(target, s->M, ls.avg_distortion, ls.sigma, ls.inertia);
     }
-    if (rpt) fclose(rpt);
     if (num_levels) *num_levels = nlev;
     return 0;
 }

@@ -637,7 +637,8 @@ int e2o_learn(int P, double eps, const char *class_name, const double *frames, i
             const double DD = ls.DD;
             /* notes.md:128-153: pass index starts at 0 and pass 0 never terminates a level;
              * DDprv carries over from the previous level */
-            const int converged = pass > 0 && !(((DDprv - DD) / DD) >= eps);
+            /* safety cap of 1000 passes per level (eps <= 0 would never terminate) */
+            const int converged = (pass > 0 && !(((DDprv - DD) / DD) >= eps)) || pass + 1 >= 1000;
             DDprv = DD;
             if (converged) break;
             e2o_update(P, M, rows, sh_r, refl, &ls);
