@@ -15,7 +15,7 @@
 //    2.39 GHz where a v_fma_f64 stream power-throttles to ~56-60.  P = 36 therefore runs the
 //    chain on the matrix pipe: 16 codewords x 16 frames per MFMA, frames resident in VGPRs,
 //    codeword tiles streamed from L2, per-lane running argmin on the VALU (which idles
-//    otherwise).  Other P use the VALU kernels (lane = frame, codeword via SGPRs).
+//    otherwise).  P = 12, 16, 20, 24 take the same kernel; any other P runs k_pass_generic on the VALU.
 //  * Training frames are resident in HBM in the operand layout of their kernel, so a wave's
 //    loads are fully coalesced 16 B/lane.
 //  * All sums are exact integers (two signed 32-bit limbs per value, 64-bit
@@ -133,179 +133,10 @@ __global__ void k_finish_scalars(const u64* __restrict__ maxabs_bits, DevScalars
 // ------------------------------------------------------------------------------------------
 // K1 + K2: sweep + accumulate
 // ------------------------------------------------------------------------------------------
-//   NC    coefficients per frame (P+1), compile time so the frame sits in registers
-//   F     frames per lane
-//   MODE  0: assignment only (quantize)     1: LDS accumulators (small M)
-//         2: global atomics through an LDS transposition (large M)
+//   MODE  0: assignment only (quantize)   1: LDS accumulator table (small M)   2: global atomics (large M)
+//         5: hybrid LDS/global (mid M)    3: diagnostics (MODE 2 without the atomics)
 constexpr int TPB = 256;
 constexpr int IMG_STRIDE_PAD = 3;  // image row stride 2*NC+5+pad: 82 dwords for NC=37 (conflict-free b64 writes)
-
-template <int NC, int F, int MODE>
-__global__ __launch_bounds__(TPB) void k_pass(const double* __restrict__ blk, long T, long nblocks,
-                                              const double* cbq_, int M, const DevScalars* __restrict__ sc,
-                                              const u64* __restrict__ l1max_bits, unsigned short* __restrict__ sym,
-                                              double* __restrict__ dmin, i64* __restrict__ rows)
-{
-    constexpr int NPAD = (NC + 7) & ~7;
-    constexpr int RS = (2 * NC + 5 + 7) & ~7;
-    constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
-    constexpr int FB = 64 * F;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cdouble_k* cbq = (cdouble_k*)cbq_;
-
-    const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    const long wave = (long)blockIdx.x * (TPB >> 6) + wib;
-    const long nwaves = (long)gridDim.x * (TPB >> 6);
-
-    int sh_r = 0, sh_d = 0, sh_d2 = 0;
-    if constexpr (MODE != 0) {
-        sh_r = sc->sh_r;
-        const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
-        sh_d = 30 - Ed;
-        sh_d2 = 30 - 2 * Ed;
-    }
-    i64* lacc = (i64*)smem;   // MODE 1: [M][RS]
-    int* img = (int*)smem + wib * (32 * IMG);  // MODE 2: per-wave [32][IMG]
-    if constexpr (MODE == 1) {
-        for (int i = threadIdx.x; i < M * RS; i += TPB) lacc[i] = 0;
-        __syncthreads();
-    }
-
-    for (long b = wave; b < nblocks; b += nwaves) {
-        // ---- load the wave's frames: coalesced, lane-major --------------------------------
-        double r[F][NC];
-        const double* fb = blk + b * (long)(NC * FB);
-#pragma unroll
-        for (int n = 0; n < NC; ++n)
-#pragma unroll
-            for (int f = 0; f < F; ++f) r[f][n] = fb[n * FB + lane * F + f];
-
-        // ---- sweep: canonical chain, ascending codeword index, strict '<' -----------------
-        double best[F];
-        int bi[F];
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-            best[f] = __builtin_inf();
-            bi[f] = 0;
-        }
-        for (int m = 0; m < M; ++m) {
-            cdouble_k* c = cbq + (long)m * NPAD;
-            double d[F];
-#pragma unroll
-            for (int f = 0; f < F; ++f) d[f] = __builtin_fma(r[f][0], c[0], 0.0);
-#pragma unroll
-            for (int n = 1; n < NC; ++n)
-#pragma unroll
-                for (int f = 0; f < F; ++f) d[f] = __builtin_fma(r[f][n], c[n], d[f]);
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                const bool lt = d[f] < best[f];
-                best[f] = lt ? d[f] : best[f];
-                bi[f] = lt ? m : bi[f];
-            }
-        }
-
-        // ---- outputs ------------------------------------------------------------------------
-        const long t0 = b * FB + lane * F;
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-            if (t0 + f < T) {
-                if (sym) sym[t0 + f] = (unsigned short)bi[f];
-                if (dmin) dmin[t0 + f] = best[f];
-            }
-        }
-
-        // ---- accumulate -----------------------------------------------------------------------
-        if constexpr (MODE == 1) {
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                if (t0 + f < T) {
-                    i64* row = lacc + bi[f] * RS;
-#pragma unroll
-                    for (int n = 0; n < NC; ++n) {
-                        int hi, lo;
-                        fix2(r[f][n], sh_r, hi, lo);
-                        atomicAdd((u64*)&row[2 * n], (u64)(i64)hi);
-                        atomicAdd((u64*)&row[2 * n + 1], (u64)(i64)lo);
-                    }
-                    const double e = best[f] - 1.0;
-                    int hi, lo;
-                    atomicAdd((u64*)&row[2 * NC], 1ull);
-                    fix2(e, sh_d, hi, lo);
-                    atomicAdd((u64*)&row[2 * NC + 1], (u64)(i64)hi);
-                    atomicAdd((u64*)&row[2 * NC + 2], (u64)(i64)lo);
-                    fix2(e * e, sh_d2, hi, lo);
-                    atomicAdd((u64*)&row[2 * NC + 3], (u64)(i64)hi);
-                    atomicAdd((u64*)&row[2 * NC + 4], (u64)(i64)lo);
-                }
-            }
-        } else if constexpr (MODE == 2) {
-            // transposition: 32 frames at a time become int32 row images [frame][2n+limb | count,d,d2],
-            // then the wave adds each image to its cell row with lanes = row elements
-            // (contiguous 8 B/lane atomics: 512 B + 120 B per frame).
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const bool mine = (lane >> 5) == half;
-                    if (mine) {
-                        int* my = img + (lane & 31) * IMG;
-#pragma unroll
-                        for (int n = 0; n < NC; ++n) {
-                            int hi, lo;
-                            fix2(r[f][n], sh_r, hi, lo);
-                            *(int2*)&my[2 * n] = make_int2(hi, lo);
-                        }
-                        const double e = best[f] - 1.0;
-                        int hi, lo;
-                        my[2 * NC] = 1;
-                        fix2(e, sh_d, hi, lo);
-                        my[2 * NC + 1] = hi;
-                        my[2 * NC + 2] = lo;
-                        fix2(e * e, sh_d2, hi, lo);
-                        my[2 * NC + 3] = hi;
-                        my[2 * NC + 4] = lo;
-                    }
-                    // same wave wrote and reads: program order + lgkmcnt make the image visible
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    for (int j = 0; j < 32; ++j) {
-                        const int src = half * 32 + j;
-                        const long tj = b * FB + (long)src * F + f;
-                        if (tj >= T) break;  // wave-uniform
-                        const int cell = __builtin_amdgcn_readlane(bi[f], src);
-                        i64* row = rows + (long)cell * RS;
-                        const int* im = img + j * IMG;
-                        constexpr int NE = 2 * NC + 5;
-                        if (lane < NE) {
-                            const int v0 = im[lane];
-                            atomicAdd((u64*)&row[lane], (u64)(i64)v0);
-                        }
-                        if (NE > 64 && lane < NE - 64) {
-                            const int v1 = im[64 + lane];
-                            atomicAdd((u64*)&row[64 + lane], (u64)(i64)v1);
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
-            }
-        }
-    }
-
-    if constexpr (MODE == 1) {
-        __syncthreads();
-        // flush the workgroup's table: contiguous 8 B/lane atomics
-        for (int i = threadIdx.x; i < M * RS; i += TPB) {
-            const i64 v = lacc[i];
-            if (v != 0) atomicAdd((u64*)&rows[i], (u64)v);
-        }
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------
 // MFMA path (P = 36): operand layouts
@@ -316,6 +147,11 @@ __global__ __launch_bounds__(TPB) void k_pass(const double* __restrict__ blk, lo
 //            codewords beyond M are copies of codeword 0 (they can never win a tie)
 // ------------------------------------------------------------------------------------------
 typedef double d4 __attribute__((ext_vector_type(4)));
+// cells of the hybrid (MODE 5) LDS table: what fits beside the eight per-wave row images, multiple of 8
+__host__ __device__ constexpr int mfma_hyb_cells(int NC)
+{
+    return (int)((E2VQ_LDS_BYTES - 10240 - 8 * 16 * (2 * NC + 5 + IMG_STRIDE_PAD) * 4) / (((2 * NC + 5 + 7) & ~7) * 8)) & ~7;
+}
 #ifndef E2VQ_PRIO
 #define E2VQ_PRIO 1
 #endif
@@ -382,7 +218,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
     }
     // LDS accumulator table shared by the workgroup: all cells (MODE 1, M <= 128) or the first HYB_CELLS cells
     // (MODE 5, 128 < M <= 512: the other cells take global atomics, whose traffic drops accordingly)
-    constexpr int HYB_CELLS = 176;  // 176 x 640 B + 42 KB of images = 151 KB of the 160 KB LDS
+    constexpr int HYB_CELLS = mfma_hyb_cells(NC);  // NC = 37: 176 x 640 B + 42 KB of images = 151 KB of the 160 KB LDS
     const int lds_cells = MODE == 1 ? M : (MODE == 5 ? HYB_CELLS : 0);
     i64* lacc = (i64*)smem;
     int* img = (int*)(smem + (size_t)lds_cells * RS * 8) + wib * (16 * IMG);
@@ -578,10 +414,11 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                 const long left = T - (b * 64 + ft * 16);
                 const int nv = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
                 if (nv == 16) {
-                    // full tile, 4 frames per step: four full-width adds (elements 0..63 of each frame's row)
-                    // and ONE add carrying the four 15-element row tails (lanes 16k..16k+14 -> frame k),
+                    // full tile, 4 frames per step: four adds of elements 0..63 of each frame's row and, when the
+                    // row is longer (64 < NE <= 80), ONE add carrying the four row tails (lanes 16k.. -> frame k),
                     // so LDS reads and atomics of different frames overlap and no lane-divergent branch remains.
-                    static_assert(NE > 64 && NE <= 80, "row tail must fit 16 lanes");
+                    static_assert(NE <= 80, "row tail must fit 16 lanes");
+                    constexpr bool HAS_TAIL = NE > 64;
                     const int tq = lane >> 4, te = lane & 15;
 #pragma unroll
                     for (int j0 = 0; j0 < 16; j0 += 4) {
@@ -589,12 +426,13 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             cell[k] = __builtin_amdgcn_readlane(idx[ft], j0 + k);
-                            v[k] = img[(j0 + k) * IMG + lane];
+                            v[k] = (HAS_TAIL || lane < NE) ? img[(j0 + k) * IMG + lane] : 0;
                         }
-                        const int tv = te < NE - 64 ? img[(j0 + tq) * IMG + 64 + te] : 0;
+                        const int tv = (HAS_TAIL && te < NE - 64) ? img[(j0 + tq) * IMG + 64 + te] : 0;
                         const int tcell = tq == 0 ? cell[0] : tq == 1 ? cell[1] : tq == 2 ? cell[2] : cell[3];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
+                            if (!HAS_TAIL && lane >= NE) continue;  // short rows: lanes beyond the row sit out
                             if constexpr (MODE == 3) {
                                 asm volatile("" ::"v"(v[k]), "s"(cell[k]));
                             } else if constexpr (MODE == 1) {
@@ -608,7 +446,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                                 atomicAdd((u64*)&rows[(long)cell[k] * RS + lane], (u64)(i64)v[k]);
                             }
                         }
-                        if (te < NE - 64) {
+                        if (HAS_TAIL && te < NE - 64) {
                             if constexpr (MODE == 3) {
                                 asm volatile("" ::"v"(tv), "v"(tcell));
                             } else if constexpr (MODE == 1) {
@@ -1156,7 +994,9 @@ static inline int grid_for(long work_items, int per_block, int cap)
     return (int)g;
 }
 
-bool uses_mfma(int NC) { return NC == 37; }
+// orders whose sweep runs on the FP64 matrix pipe (NC = 4k+1: the trailing coefficient goes to the VALU)
+bool uses_mfma(int NC) { return NC == 37 || NC == 13 || NC == 17 || NC == 21 || NC == 25; }
+int mfma_hybrid_cells(int NC) { return mfma_hyb_cells(NC); }
 
 void launch_blockify(const double* aos, long T, int NC, int FB, double* blk, long nblocks, hipStream_t s)
 {
@@ -1181,10 +1021,14 @@ void launch_finish_scalars(const u64* maxabs_bits, DevScalars* sc, hipStream_t s
 void launch_global_sums(const double* blk, long nblocks, int NC, int FB, const DevScalars* sc, i64* stats,
                         hipStream_t s)
 {
-    if (NC == 37) {
-        hipLaunchKernelGGL((k_global_sums_mfma<37>), dim3(grid_for(2 * nblocks, 4, 2048)), dim3(256), 0, s, blk, nblocks,
-                           sc, stats);
-        return;
+    const dim3 g(grid_for(2 * nblocks, 4, 2048));
+    switch (NC) {
+        case 37: hipLaunchKernelGGL((k_global_sums_mfma<37>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
+        case 25: hipLaunchKernelGGL((k_global_sums_mfma<25>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
+        case 21: hipLaunchKernelGGL((k_global_sums_mfma<21>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
+        case 17: hipLaunchKernelGGL((k_global_sums_mfma<17>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
+        case 13: hipLaunchKernelGGL((k_global_sums_mfma<13>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
+        default: break;
     }
     hipLaunchKernelGGL(k_global_sums, dim3(grid_for(nblocks * NC, 4, 4096)), dim3(256), 0, s, blk, nblocks, NC, FB, sc,
                        stats);
@@ -1196,10 +1040,7 @@ int frames_per_lane(int NC)
     return 1;  // every kernel works on blocks of 64 frames
 }
 
-bool has_register_kernel(int NC)
-{
-    return uses_mfma(NC) || NC == 13 || NC == 17 || NC == 21 || NC == 25;
-}
+bool has_register_kernel(int NC) { return uses_mfma(NC); }
 
 template <int NC>
 static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, const double* cbm, int M,
@@ -1229,7 +1070,7 @@ static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, c
         hipLaunchKernelGGL((k_pass_mfma<NC, 1, 512>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, MT, M, sc,
                            l1max_bits, sym, dmin, rows, 0);
     } else if (mode == 5) {  // hybrid: cells < 176 in the LDS table, the rest by global atomics
-        const size_t lds = (size_t)176 * RS * 8 + (size_t)8 * 16 * IMG * 4;
+        const size_t lds = (size_t)mfma_hyb_cells(NC) * RS * 8 + (size_t)8 * 16 * IMG * 4;
         (void)hipFuncSetAttribute((const void*)k_pass_mfma<NC, 5, 512>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
         const int grid = grid_for(nblocks, 8, 256);
@@ -1251,40 +1092,6 @@ static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, c
     return 0;
 }
 
-int lds_mode_max_M(int NC)
-{
-    const int RS = (2 * NC + 5 + 7) & ~7;
-    return (int)((E2VQ_LDS_BYTES - 1024) / ((long)RS * 8));
-}
-
-template <int NC, int F>
-static int launch_pass_t(int mode, const double* blk, long T, long nblocks, const double* cbq, int M,
-                         const DevScalars* sc, const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows,
-                         hipStream_t s)
-{
-    constexpr int RS = (2 * NC + 5 + 7) & ~7;
-    constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
-    const int waves_per_block = TPB / 64;
-    if (mode == 0) {
-        const int grid = grid_for(nblocks, waves_per_block, 2048);
-        hipLaunchKernelGGL((k_pass<NC, F, 0>), dim3(grid), dim3(TPB), 0, s, blk, T, nblocks, cbq, M, sc, l1max_bits,
-                           sym, dmin, rows);
-    } else if (mode == 1) {
-        const size_t lds = (size_t)M * RS * 8;
-        (void)hipFuncSetAttribute((const void*)k_pass<NC, F, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  E2VQ_LDS_BYTES);
-        // persistent: few workgroups so the per-workgroup table flush stays small
-        const int grid = grid_for(nblocks, waves_per_block, 512);
-        hipLaunchKernelGGL((k_pass<NC, F, 1>), dim3(grid), dim3(TPB), lds, s, blk, T, nblocks, cbq, M, sc, l1max_bits,
-                           sym, dmin, rows);
-    } else {
-        const size_t lds = (size_t)waves_per_block * 32 * IMG * 4;
-        const int grid = grid_for(nblocks, waves_per_block, 2048);
-        hipLaunchKernelGGL((k_pass<NC, F, 2>), dim3(grid), dim3(TPB), lds, s, blk, T, nblocks, cbq, M, sc, l1max_bits,
-                           sym, dmin, rows);
-    }
-    return 0;
-}
 
 int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const double* cbq, const double* cbm,
                 int M, const DevScalars* sc, const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows,
@@ -1292,10 +1099,10 @@ int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const
 {
     switch (NC) {
         case 37: return launch_pass_mfma<37>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
-        case 13: return launch_pass_t<13, 1>(mode, blk, T, nblocks, cbq, M, sc, l1max_bits, sym, dmin, rows, s);
-        case 17: return launch_pass_t<17, 1>(mode, blk, T, nblocks, cbq, M, sc, l1max_bits, sym, dmin, rows, s);
-        case 21: return launch_pass_t<21, 1>(mode, blk, T, nblocks, cbq, M, sc, l1max_bits, sym, dmin, rows, s);
-        case 25: return launch_pass_t<25, 1>(mode, blk, T, nblocks, cbq, M, sc, l1max_bits, sym, dmin, rows, s);
+        case 25: return launch_pass_mfma<25>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
+        case 21: return launch_pass_mfma<21>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
+        case 17: return launch_pass_mfma<17>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
+        case 13: return launch_pass_mfma<13>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
         default: break;
     }
     // generic: 64 frames per block, global atomics for the accumulation

@@ -402,10 +402,15 @@ extern "C" int e2vq_grow(e2vq_session* s)
 static int pass_mode(const e2vq_session* s)
 {
     if (const char* f = getenv("ECOZ2_VQ_FORCE_MODE")) return atoi(f);  // diagnostics only (0 = assignment only)
-    if (!e2vq::has_register_kernel(s->NC)) return 2;
-    if (s->M <= e2vq::lds_mode_max_M(s->NC) && s->M <= 128) return 1;
-    if (e2vq::uses_mfma(s->NC) && s->M <= 512) return 5;  // hybrid LDS/global accumulate (atomic-bound levels)
-    return 2;
+    if (e2vq::uses_mfma(s->NC)) {
+        // all cells in the workgroup's LDS table while it fits beside the row images (NC = 37: M <= 128) ...
+        const long images = 8L * 16 * (2 * s->NC + 5 + 3) * 4;
+        if ((long)s->M * s->RS * 8 + images + 2048 <= E2VQ_LDS_BYTES && s->M <= 128) return 1;
+        // ... then the hybrid, while its LDS share is worth having (atomic-bound levels)
+        if (s->M <= 4 * e2vq::mfma_hybrid_cells(s->NC)) return 5;
+        return 2;
+    }
+    return 2;  // generic kernel: global atomics
 }
 
 extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)

@@ -91,18 +91,19 @@ def test_invalid_inputs_fail_loudly():
         e.vq_quantize("/nonexistent.cbook", [])
 
 
-@pytest.mark.parametrize("Pn", [12, 20, 30])
+@pytest.mark.parametrize("Pn", [12, 16, 20, 24, 30])
 def test_other_prediction_orders(oracle, Pn):
-    """P = 36 runs on the matrix pipe; other orders use the VALU register kernels (12, 20) or the generic one (30)."""
+    """P = 12, 16, 20, 24, 36 run on the matrix pipe (NC = 4k+1); other orders use the generic VALU kernel (30)."""
     frames = e.synth.synth_frames(41, 3, Pn, 0, 3000)
-    rc, levels_o, cbs_o = oracle.learn(frames, 0.05, 8)
+    max_m = 256 if Pn in (12, 24) else 8  # 256: all three accumulate modes (LDS table, hybrid) of the MFMA kernel
+    rc, levels_o, cbs_o = oracle.learn(frames, 0.05, max_m)
     assert rc == 0
     cbs = []
     with e.VqSession(Pn) as s:
         s.set_frames(frames)
         s.prepare()
         s.init_codebook()
-        s.learn(0.05, 8, callback=lambda *a: cbs.append(a))
+        s.learn(0.05, max_m, callback=lambda *a: cbs.append(a))
         refl = s.get_codebook()
         sym, dmin = s.quantize(frames)
     assert cbs == cbs_o
