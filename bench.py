@@ -157,6 +157,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- secondary figures (SURVEY 8d ii / iii), outside the timed region, informational --------------------
+    sess.enable_timing(False)
+    sess.init_codebook()
+    fence()
+    t0 = time.perf_counter()
+    e2e_levels = sess.learn(0.05, M)  # the whole ladder 2..1024 with the real convergence rule
+    fence()
+    e2e_s = time.perf_counter() - t0
+    q_rate = None
+    if world == 1:
+        fr = torch.from_numpy(e.synth.synth_frames(SEED, N_CLASSES, P, lo, S)).cuda()
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sess.quantize_device(fr, S, sym, dmin)
+            sess.synchronize()
+            q_rate = max(q_rate or 0.0, S / (time.perf_counter() - t0))
+        del fr
+
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
         frames_per_launch = S
@@ -197,6 +216,13 @@ def main():
                 "parallelism": f"frames sharded over {world} rank(s); int64 all-reduce of cell sums per iteration",
                 "ladder_seconds_untimed": round(t_ladder, 3),
                 "final_avg_distortion": st.avg_distortion,
+                "learn_end_to_end": {
+                    "what": f"whole LBG ladder M=2..{M}, eps=0.05, resident frames, all ranks",
+                    "seconds": round(e2e_s, 4),
+                    "frames_per_sec": world * S / e2e_s,
+                    "passes_per_level": [lv.passes for lv in e2e_levels],
+                },
+                "quantize_frames_per_sec_device_resident": q_rate,
             },
             # the sweep is FP64-FMA bound (248 flop/B): useful flops 2*M*(P+1) per frame against the 78.6 TF FP64 peak
             "roofline": {
