@@ -235,7 +235,9 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
     // block period turns the bursts into a steady stream; partners differ by half a period.
     if constexpr (MODE != 0 && TPBM == 512) {
         if (nblocks >= 4 * nwaves && stagger && MT >= 16) {
-            const int phase = (((int)blockIdx.x + 4 * (wib & 3)) & 7) + 8 * (wib >> 2);  // 0..15
+            int phase = (((int)blockIdx.x + 4 * (wib & 3)) & 7) + 8 * (wib >> 2);  // 0..15 of 16
+            if (stagger == 2) phase >>= 1;                                            // half amplitude
+            if (stagger == 3) phase = 8 * (wib >> 2);                                 // partners only
             const int naps = (phase * (MT * NSM * 4 * 64 / 16)) >> 13;  // s_sleep(127) ~ 8k cycles
             for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
         }

@@ -19,7 +19,9 @@ variants = sys.argv[1:] or ["default"]
 for rnd in range(2):
     for v in variants:
         env = dict(os.environ)
-        if v != "default":
+        if v.startswith("stagger="):
+            env["ECOZ2_VQ_STAGGER"] = v.split("=")[1]
+        elif v != "default":
             env["ECOZ2VQ_LIB"] = os.path.join(root, "tools", "probe", "ab", v)
-        print("lib:", v, flush=True)
+        print("variant:", v, flush=True)
         subprocess.run([sys.executable, "-c", code, root], env=env)
