@@ -30,7 +30,7 @@ static int usage()
             "                 [--predictors-dir-template <t>] [--tt <TRAIN|TEST>] [--class-name <class>] [-s]\n"
             "  ecoz2 vq classify [-r] --codebooks <files|dirs>... --tt <TRAIN|TEST> --predictors <files|dirs|tt.csv>...\n"
             "  ecoz2 vq show [-f <from>] [-t <to>] <codebook>\n"
-            "  ecoz2 seq show [-c] [-L] [--full] <file.seq>...\n"
+            "  ecoz2 seq show [-c] [-L] [--full] [--pickle out.pkl -M <M> --tt <TRAIN|TEST> [--class-name c]] <file.seq|tt.csv>...\n"
             "  ecoz2 prd show [--from a] [--to b] <file.prd>\n"
             "  ecoz2 cversion\n");
     return 2;
@@ -172,38 +172,104 @@ static int vq_show(int argc, char** argv)
 
 // `ecoz2 seq show [-c] [-L] [--full] <files...>`: Sequence::show, /root/reference/src/sequence/mod.rs:17-47
 // (reads the C-format .seq exactly as Sequence::load does, :49-75)
+static bool load_seq(const std::string& f, std::string& cls, unsigned& M, std::vector<unsigned>& sym)
+{
+    FILE* fp = fopen(f.c_str(), "rb");
+    unsigned char hdr[120];
+    if (!fp || fread(hdr, 1, sizeof hdr, fp) != sizeof hdr || strncmp((const char*)hdr, "<sequence>", 10) != 0) {
+        if (fp) fclose(fp);
+        return false;
+    }
+    char c[97] = {0};
+    memcpy(c, hdr + 16, 96);
+    cls = c;
+    const unsigned len = hdr[112] | (hdr[113] << 8) | (hdr[114] << 16) | ((unsigned)hdr[115] << 24);
+    M = hdr[116] | (hdr[117] << 8) | (hdr[118] << 16) | ((unsigned)hdr[119] << 24);
+    sym.assign(len, 0);
+    for (unsigned t = 0; t < len; ++t) {
+        unsigned char b[2];
+        if (fread(b, 1, 2, fp) != 2) break;
+        sym[t] = b[0] | (b[1] << 8);
+    }
+    fclose(fp);
+    return true;
+}
+
+// pickle (protocol 2) of a list of lists of ints: what `utl::to_pickle(&list_of_sequences, ..)` exports
+// (/root/reference/src/seq/mod.rs:88-112, src/utl/mod.rs:277-283); loads with Python's pickle.load
+static bool write_pickle(const std::string& path, const std::vector<std::vector<unsigned>>& seqs)
+{
+    FILE* fp = fopen(path.c_str(), "wb");
+    if (!fp) return false;
+    auto put_int = [&](unsigned v) {
+        if (v < 256) { fputc('K', fp); fputc((int)v, fp); }                                   // BININT1
+        else if (v < 65536) { fputc('M', fp); fputc(v & 255, fp); fputc(v >> 8, fp); }        // BININT2
+        else { fputc('J', fp); for (int k = 0; k < 4; ++k) fputc((v >> (8 * k)) & 255, fp); } // BININT
+    };
+    fputc(0x80, fp); fputc(2, fp);  // PROTO 2
+    fputc(']', fp);                 // EMPTY_LIST
+    fputc('(', fp);                 // MARK
+    for (const auto& s : seqs) {
+        fputc(']', fp);
+        fputc('(', fp);
+        for (unsigned v : s) put_int(v);
+        fputc('e', fp);             // APPENDS
+    }
+    fputc('e', fp);
+    fputc('.', fp);                 // STOP
+    return fclose(fp) == 0;
+}
+
 static int seq_show(int argc, char** argv)
 {
     bool no_sequence = false, only_length = false, full = false;
+    std::string pickle, cls_filter, tt;
+    int codebook_size = -1;
     std::vector<std::string> files;
     for (int i = 0; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "-c") no_sequence = true;
         else if (a == "-L") only_length = true;
         else if (a == "--full") full = true;
+        else if (a == "--pickle" && i + 1 < argc) pickle = argv[++i];
+        else if (a == "--class-name" && i + 1 < argc) cls_filter = argv[++i];
+        else if (a == "--tt" && i + 1 < argc) tt = argv[++i];
+        else if ((a == "-M" || a == "--codebook-size") && i + 1 < argc) codebook_size = atoi(argv[++i]);
         else if (!is_flag(argv[i])) files.push_back(a);
         else return usage();
     }
     if (files.empty()) return usage();
+    if (!pickle.empty()) {  // src/seq/mod.rs:88-118
+        if (codebook_size < 0 || tt.empty()) {
+            printf("--codebook-size and --tt required when --pickle given\n");
+            return 0;
+        }
+        std::vector<std::string> seq_files;
+        const bool tt_list = files.size() == 1 && files[0].size() > 4 && files[0].compare(files[0].size() - 4, 4, ".csv") == 0;
+        const std::string subdir = "sequences/M" + std::to_string(codebook_size);
+        int rc = tt_list ? e2vq_io::files_from_csv(files[0], tt, cls_filter, subdir, ".seq", nullptr, seq_files)
+                         : e2vq_io::resolve_filenames(files, ".seq", seq_files);
+        if (rc) { printf("%s\n", e2vq_last_error()); return 0; }
+        std::vector<std::vector<unsigned>> seqs;
+        for (const auto& f : seq_files) {
+            std::string cls; unsigned M; std::vector<unsigned> sym;
+            if (!load_seq(f, cls, M, sym)) { printf("%s: Not a sequence\n", f.c_str()); return 0; }
+            seqs.push_back(sym);
+        }
+        if (!write_pickle(pickle, seqs)) { printf("%s: cannot write\n", pickle.c_str()); return 0; }
+        printf("%zu sequence(s) saved to \"%s\"\n", seqs.size(), pickle.c_str());
+        return 0;
+    }
     for (const auto& f : files) {
-        FILE* fp = fopen(f.c_str(), "rb");
-        unsigned char hdr[120];
-        if (!fp || fread(hdr, 1, sizeof hdr, fp) != sizeof hdr || strncmp((const char*)hdr, "<sequence>", 10) != 0) {
+        std::string cls_s;
+        unsigned M = 0;
+        std::vector<unsigned> sym;
+        if (!load_seq(f, cls_s, M, sym)) {
             printf("%s: Not a sequence\n", f.c_str());
-            if (fp) fclose(fp);
             continue;
         }
-        char cls[97] = {0};
-        memcpy(cls, hdr + 16, 96);
-        const unsigned len = hdr[112] | (hdr[113] << 8) | (hdr[114] << 16) | ((unsigned)hdr[115] << 24);
-        const unsigned M = hdr[116] | (hdr[117] << 8) | (hdr[118] << 16) | ((unsigned)hdr[119] << 24);
-        std::vector<unsigned> sym(len);
-        for (unsigned t = 0; t < len; ++t) {
-            unsigned char b[2];
-            if (fread(b, 1, 2, fp) != 2) break;
-            sym[t] = b[0] | (b[1] << 8);
-        }
-        fclose(fp);
+        const char* cls = cls_s.c_str();
+        const unsigned len = (unsigned)sym.size();
         if (no_sequence) continue;
         if (only_length) { printf("%u\n", len); continue; }
         printf("<%s(M=%u,L=%u): ", cls, M, len);

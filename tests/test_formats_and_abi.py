@@ -139,3 +139,25 @@ def test_cli_seq_show_and_prd_show(tmp_path):
     out = _cli("prd", "show", "--from", "0", "--to", "2", "x.prd", cwd=tmp_path).stdout.splitlines()
     assert out[1] == "# className='HB', T=3, P=36" and out[2] == "r0,r1,r2"
     assert out[3] == ",".join(f"{v:.5f}" for v in fr[0, :3])
+
+
+def test_cli_seq_show_pickle(tmp_path):
+    """`seq show --pickle` (src/seq/mod.rs:88-118): list of symbol lists, resolved from a tt-list; read back with pickle."""
+    import pickle
+
+    rng = np.random.default_rng(0)
+    want = []
+    rows = ["tt,class,selection"]
+    for cls, sel, n in (("A", "00001", 5), ("A", "00002", 300), ("B", "00003", 70000)):
+        sym = rng.integers(0, 2048, n).astype(np.uint16)
+        e.formats.write_seq(str(tmp_path / "data" / "sequences" / "M2048" / cls / f"{sel}.seq"), cls, 2048, sym)
+        rows.append(f"TRAIN,{cls},{sel}")
+        want.append(sym.tolist())
+    (tmp_path / "tt.csv").write_text("\n".join(rows) + "\n")
+    r = _cli("seq", "show", "--pickle", "out.pkl", "-M", "2048", "--tt", "TRAIN", "tt.csv", cwd=tmp_path)
+    assert '3 sequence(s) saved to "out.pkl"' in r.stdout
+    assert pickle.load(open(tmp_path / "out.pkl", "rb")) == want
+    r = _cli("seq", "show", "--pickle", "a.pkl", "-M", "2048", "--tt", "TRAIN", "--class-name", "A", "tt.csv", cwd=tmp_path)
+    assert pickle.load(open(tmp_path / "a.pkl", "rb")) == want[:2]
+    r = _cli("seq", "show", "--pickle", "x.pkl", "tt.csv", cwd=tmp_path)
+    assert "--codebook-size and --tt required when --pickle given" in r.stdout
