@@ -165,6 +165,29 @@ int get_header(FILE* f, const char* path, const char* ident, const char* what, c
     return 0;
 }
 
+// The order of the two u32 header fields of .prd / .cbook is not pinned by anything in the reference (the C
+// reader/writer is absent; only .seq is pinned).  This repo writes (count, order) for .prd and (order, count) for
+// .cbook; on reading, the payload size decides: 120 + count*(order+1)*8 must equal the file size, and if only the
+// swapped reading satisfies it the fields are taken swapped.  Anything else is rejected.
+int resolve_fields(FILE* f, const char* path, uint32_t a, uint32_t b, bool a_is_count, uint32_t* count, uint32_t* order)
+{
+    struct stat st;
+    if (fstat(fileno(f), &st) != 0) return e2vq_set_error("%s: cannot stat", path);
+    const unsigned long long payload = (unsigned long long)st.st_size - 120ull;
+    const uint32_t c0 = a_is_count ? a : b, o0 = a_is_count ? b : a;
+    if ((unsigned long long)c0 * (o0 + 1ull) * 8ull == payload && o0 >= 1 && o0 <= 200) {
+        *count = c0;
+        *order = o0;
+        return 0;
+    }
+    if ((unsigned long long)o0 * (c0 + 1ull) * 8ull == payload && c0 >= 1 && c0 <= 200) {
+        *count = o0;
+        *order = c0;
+        return 0;
+    }
+    return e2vq_set_error("%s: header fields (%u, %u) do not match the payload size %llu", path, a, b, payload);
+}
+
 }  // namespace
 
 extern "C" int e2vq_prd_info(const char* path, char class_name[96], int* P, int64_t* T)
@@ -174,6 +197,7 @@ extern "C" int e2vq_prd_info(const char* path, char class_name[96], int* P, int6
     uint32_t t = 0, p = 0;
     int rc = get_header(f, path, "<predictor>", "predictor", class_name);
     if (!rc && (!get_u32(f, &t) || !get_u32(f, &p))) rc = e2vq_set_error("%s: truncated header", path);
+    if (!rc) rc = resolve_fields(f, path, t, p, true, &t, &p);
     fclose(f);
     if (rc) return rc;
     *P = (int)p;
@@ -189,6 +213,7 @@ extern "C" int e2vq_prd_read(const char* path, double* frames, int64_t capacity_
     uint32_t t = 0, p = 0;
     int rc = get_header(f, path, "<predictor>", "predictor", cls);
     if (!rc && (!get_u32(f, &t) || !get_u32(f, &p))) rc = e2vq_set_error("%s: truncated header", path);
+    if (!rc) rc = resolve_fields(f, path, t, p, true, &t, &p);
     if (!rc && (int64_t)t > capacity_frames) rc = e2vq_set_error("%s: %u vectors exceed the buffer", path, t);
     if (!rc && fread(frames, sizeof(double), (size_t)t * (p + 1), f) != (size_t)t * (p + 1))
         rc = e2vq_set_error("%s: truncated payload", path);
@@ -217,6 +242,7 @@ extern "C" int e2vq_cbook_info(const char* path, char class_name[96], int* P, in
     uint32_t p = 0, m = 0;
     int rc = get_header(f, path, "<codebook>", "codebook", class_name);
     if (!rc && (!get_u32(f, &p) || !get_u32(f, &m))) rc = e2vq_set_error("%s: truncated header", path);
+    if (!rc) rc = resolve_fields(f, path, p, m, false, &m, &p);
     fclose(f);
     if (rc) return rc;
     if (p < 1 || p > 200 || m < 1 || m > 65536) return e2vq_set_error("%s: implausible P=%u M=%u", path, p, m);
@@ -233,6 +259,7 @@ extern "C" int e2vq_cbook_read(const char* path, double* reflections, int capaci
     uint32_t p = 0, m = 0;
     int rc = get_header(f, path, "<codebook>", "codebook", cls);
     if (!rc && (!get_u32(f, &p) || !get_u32(f, &m))) rc = e2vq_set_error("%s: truncated header", path);
+    if (!rc) rc = resolve_fields(f, path, p, m, false, &m, &p);
     if (!rc && (int)m > capacity_codewords) rc = e2vq_set_error("%s: %u codewords exceed the buffer", path, m);
     if (!rc && fread(reflections, sizeof(double), (size_t)m * (p + 1), f) != (size_t)m * (p + 1))
         rc = e2vq_set_error("%s: truncated payload", path);

@@ -161,3 +161,31 @@ def test_cli_seq_show_pickle(tmp_path):
     assert pickle.load(open(tmp_path / "a.pkl", "rb")) == want[:2]
     r = _cli("seq", "show", "--pickle", "x.pkl", "tt.csv", cwd=tmp_path)
     assert "--codebook-size and --tt required when --pickle given" in r.stdout
+
+
+def test_prd_cbook_header_field_order_is_resolved_by_payload_size(tmp_path):
+    """Only .seq is pinned by the reference; for .prd/.cbook the reader accepts either order of the two u32 header
+    fields (decided by the payload size) and rejects anything inconsistent."""
+    import struct
+
+    frames = e.synth.synth_frames(1, 1, 12, 0, 40)
+    hdr = lambda ident, cls: ident.encode().ljust(16, b"\0") + cls.encode().ljust(96, b"\0")
+    swapped = tmp_path / "swapped.prd"
+    swapped.write_bytes(hdr("<predictor>", "Z") + struct.pack("<II", 12, 40) + frames.tobytes())  # (P, T) order
+    name = (C.c_char * 96)()
+    Pn, Tn = C.c_int(), C.c_int64()
+    e.check(e.lib.e2vq_prd_info(str(swapped).encode(), name, C.byref(Pn), C.byref(Tn)))
+    assert (Pn.value, Tn.value) == (12, 40)
+    buf = np.zeros((40, 13))
+    e.check(e.lib.e2vq_prd_read(str(swapped).encode(), buf.ctypes.data, 40))
+    assert np.array_equal(buf, frames)
+    bad = tmp_path / "bad.prd"
+    bad.write_bytes(hdr("<predictor>", "Z") + struct.pack("<II", 41, 12) + frames.tobytes())
+    assert e.lib.e2vq_prd_info(str(bad).encode(), name, C.byref(Pn), C.byref(Tn)) != 0
+    assert "do not match the payload size" in e.lib.e2vq_last_error().decode()
+    refl = np.random.default_rng(1).uniform(-0.4, 0.4, (8, 13))
+    cb = tmp_path / "swapped.cbook"
+    cb.write_bytes(hdr("<codebook>", "_") + struct.pack("<II", 8, 12) + refl.tobytes())  # (M, P) order
+    Mn = C.c_int()
+    e.check(e.lib.e2vq_cbook_info(str(cb).encode(), name, C.byref(Pn), C.byref(Mn)))
+    assert (Pn.value, Mn.value) == (12, 8)
