@@ -15,7 +15,8 @@
 //    2.39 GHz where a v_fma_f64 stream power-throttles to ~56-60.  P = 36 therefore runs the
 //    chain on the matrix pipe: 16 codewords x 16 frames per MFMA, frames resident in VGPRs,
 //    codeword tiles streamed from L2, per-lane running argmin on the VALU (which idles
-//    otherwise).  P = 12, 16, 20, 24 take the same kernel; any other P runs k_pass_generic on the VALU.
+//    otherwise).  P = 12, 16, 20, 24, 30, 40 take the same kernel template; any other P runs k_pass_generic
+//    on the VALU.
 //  * Training frames are resident in HBM in the operand layout of their kernel, so a wave's
 //    loads are fully coalesced 16 B/lane.
 //  * All sums are exact integers (two signed 32-bit limbs per value, 64-bit
@@ -415,12 +416,11 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                 // padding frames (t >= T) are never counted; nv is wave-uniform
                 const long left = T - (b * 64 + ft * 16);
                 const int nv = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
-                if (nv == 16) {
+                if (nv == 16 && NE <= 80) {
                     // full tile, 4 frames per step: four adds of elements 0..63 of each frame's row and, when the
                     // row is longer (64 < NE <= 80), ONE add carrying the four row tails (lanes 16k.. -> frame k),
                     // so LDS reads and atomics of different frames overlap and no lane-divergent branch remains.
-                    static_assert(NE <= 80, "row tail must fit 16 lanes");
-                    constexpr bool HAS_TAIL = NE > 64;
+                    constexpr bool HAS_TAIL = NE > 64;  // (rows longer than 80 elements take the per-frame loop below)
                     const int tq = lane >> 4, te = lane & 15;
 #pragma unroll
                     for (int j0 = 0; j0 < 16; j0 += 4) {
@@ -996,8 +996,9 @@ static inline int grid_for(long work_items, int per_block, int cap)
     return (int)g;
 }
 
-// orders whose sweep runs on the FP64 matrix pipe (NC = 4k+1: the trailing coefficient goes to the VALU)
-bool uses_mfma(int NC) { return NC == 37 || NC == 13 || NC == 17 || NC == 21 || NC == 25; }
+// orders whose sweep runs on the FP64 matrix pipe: P = 12, 16, 20, 24, 36, 40 (NC = 4k+1: the trailing coefficient
+// goes to the VALU) and P = 30 (NC = 31: the last k-step is zero padded)
+bool uses_mfma(int NC) { return NC == 37 || NC == 13 || NC == 17 || NC == 21 || NC == 25 || NC == 31 || NC == 41; }
 int mfma_hybrid_cells(int NC) { return mfma_hyb_cells(NC); }
 
 void launch_blockify(const double* aos, long T, int NC, int FB, double* blk, long nblocks, hipStream_t s)
@@ -1030,6 +1031,8 @@ void launch_global_sums(const double* blk, long nblocks, int NC, int FB, const D
         case 21: hipLaunchKernelGGL((k_global_sums_mfma<21>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
         case 17: hipLaunchKernelGGL((k_global_sums_mfma<17>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
         case 13: hipLaunchKernelGGL((k_global_sums_mfma<13>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
+        case 31: hipLaunchKernelGGL((k_global_sums_mfma<31>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
+        case 41: hipLaunchKernelGGL((k_global_sums_mfma<41>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
         default: break;
     }
     hipLaunchKernelGGL(k_global_sums, dim3(grid_for(nblocks * NC, 4, 4096)), dim3(256), 0, s, blk, nblocks, NC, FB, sc,
@@ -1105,6 +1108,8 @@ int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const
         case 21: return launch_pass_mfma<21>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
         case 17: return launch_pass_mfma<17>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
         case 13: return launch_pass_mfma<13>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
+        case 31: return launch_pass_mfma<31>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
+        case 41: return launch_pass_mfma<41>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
         default: break;
     }
     // generic: 64 frames per block, global atomics for the accumulation
