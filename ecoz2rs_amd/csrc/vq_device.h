@@ -24,7 +24,8 @@ inline long cbm_doubles(int NC, int M) { return (long)((M + 15) / 16) * (((((NC 
 int frames_per_lane(int NC);       // F of the kernel that will serve this NC (block = 64*F frames)
 bool has_register_kernel(int NC);
 
-void launch_blockify(const double* aos, long T, int NC, int FB, double* blk, long nblocks, hipStream_t s);
+bool launch_blockify(const double* aos, long T, int NC, int FB, double* blk, long nblocks,
+                     unsigned long long* maxabs_bits, int* bad, hipStream_t s);
 void launch_maxabs(const double* blk, long count, unsigned long long* out_bits, int* bad, hipStream_t s);
 void launch_finish_scalars(const unsigned long long* maxabs_bits, DevScalars* sc, hipStream_t s);
 void launch_global_sums(const double* blk, long nblocks, int NC, int FB, const DevScalars* sc, long long* stats,

@@ -157,11 +157,14 @@ __host__ __device__ constexpr int mfma_hyb_cells(int NC)
 #define E2VQ_PRIO 1
 #endif
 
+// (also scans max |x| and non-finite values on the way: the data statistics need no separate pass)
 __global__ void k_blockify_mfma(const double* __restrict__ aos, long T, int NC, double* __restrict__ blk,
-                                long nblocks)
+                                long nblocks, u64* __restrict__ maxabs_bits, int* __restrict__ bad)
 {
     const int NS = (NC + 3) >> 2;
     const long total = nblocks * (long)NC * 64;
+    u64 mx = 0;
+    int isbad = 0;
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
         const long b = o / ((long)NC * 64);
         const int w = (int)(o - b * (long)NC * 64);
@@ -179,7 +182,22 @@ __global__ void k_blockify_mfma(const double* __restrict__ aos, long T, int NC, 
             n = 4 * (NS - 1) + (z >> 4);
         }
         const long t = b * 64 + u * 32 + h * 16 + j;
-        blk[o] = t < T ? aos[t * NC + n] : 0.0;
+        const double v = t < T ? aos[t * NC + n] : 0.0;
+        blk[o] = v;
+        const double av = fabs(v);
+        if (!(av <= 1.7976931348623157e308)) isbad = 1;
+        const u64 bits = (u64)__double_as_longlong(av);
+        mx = bits > mx ? bits : mx;
+    }
+    if (maxabs_bits) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const u64 ot = __shfl_xor(mx, off, 64);
+            mx = ot > mx ? ot : mx;
+        }
+        if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(maxabs_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(maxabs_bits, mx);
+        if (isbad) atomicOr(bad, 1);
     }
 }
 
@@ -1001,14 +1019,19 @@ static inline int grid_for(long work_items, int per_block, int cap)
 bool uses_mfma(int NC) { return NC == 37 || NC == 13 || NC == 17 || NC == 21 || NC == 25 || NC == 31 || NC == 41; }
 int mfma_hybrid_cells(int NC) { return mfma_hyb_cells(NC); }
 
-void launch_blockify(const double* aos, long T, int NC, int FB, double* blk, long nblocks, hipStream_t s)
+// maxabs_bits / bad (optional): when given and the MFMA layout is used, the scan of max |x| rides along; returns
+// true in that case (the caller then skips launch_maxabs)
+bool launch_blockify(const double* aos, long T, int NC, int FB, double* blk, long nblocks, u64* maxabs_bits, int* bad,
+                     hipStream_t s)
 {
-    if (uses_mfma(NC))
+    if (uses_mfma(NC)) {
         hipLaunchKernelGGL(k_blockify_mfma, dim3(grid_for(nblocks * NC * 64, 256, 8192)), dim3(256), 0, s, aos, T, NC,
-                           blk, nblocks);
-    else
-        hipLaunchKernelGGL(k_blockify, dim3(grid_for(nblocks * NC * FB, 256, 8192)), dim3(256), 0, s, aos, T, NC, FB,
-                           blk, nblocks);
+                           blk, nblocks, maxabs_bits, bad);
+        return maxabs_bits != nullptr;
+    }
+    hipLaunchKernelGGL(k_blockify, dim3(grid_for(nblocks * NC * FB, 256, 8192)), dim3(256), 0, s, aos, T, NC, FB, blk,
+                       nblocks);
+    return false;
 }
 
 void launch_maxabs(const double* blk, long count, u64* out_bits, int* bad, hipStream_t s)

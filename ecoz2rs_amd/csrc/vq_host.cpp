@@ -70,6 +70,7 @@ struct e2vq_session {
     double* d_blk = nullptr;
     i64 T = 0, nblocks = 0, T_total = 0;
     bool prepared = false;
+    bool maxabs_scanned = false;  // d_maxabs / d_flags hold this rank's scan from the re-layout kernel
     // codebook
     int M = 0, M_cap = 0;
     double* d_refl = nullptr;      // current reflections [M][NC]
@@ -281,7 +282,10 @@ extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames
     s->T = T;
     s->nblocks = (T + s->FB - 1) / s->FB;
     HIPCHK(hipMalloc(&s->d_blk, (size_t)s->nblocks * s->NC * s->FB * 8));
-    e2vq::launch_blockify((const double*)device_frames, T, s->NC, s->FB, s->d_blk, s->nblocks, s->stream);
+    HIPCHK(hipMemsetAsync(s->d_maxabs, 0, 8, s->stream));
+    HIPCHK(hipMemsetAsync(s->d_flags, 0, 2 * sizeof(int), s->stream));
+    s->maxabs_scanned = e2vq::launch_blockify((const double*)device_frames, T, s->NC, s->FB, s->d_blk, s->nblocks,
+                                              s->d_maxabs, s->d_flags, s->stream);
     HIPCHK(hipGetLastError());
     s->prepared = false;
     s->stats_valid = false;
@@ -308,9 +312,12 @@ extern "C" int e2vq_prepare(e2vq_session* s)
     if (!s->d_blk) return e2vq_set_error("no training set");
     HIPCHK(hipSetDevice(s->device));
     const long count = (long)s->nblocks * s->NC * s->FB;
-    HIPCHK(hipMemsetAsync(s->d_maxabs, 0, 8, s->stream));
-    HIPCHK(hipMemsetAsync(s->d_flags, 0, 2 * sizeof(int), s->stream));
-    e2vq::launch_maxabs(s->d_blk, count, s->d_maxabs, s->d_flags, s->stream);
+    if (!s->maxabs_scanned) {  // (the re-layout kernel of the MFMA path already scanned max |x|)
+        HIPCHK(hipMemsetAsync(s->d_maxabs, 0, 8, s->stream));
+        HIPCHK(hipMemsetAsync(s->d_flags, 0, 2 * sizeof(int), s->stream));
+        e2vq::launch_maxabs(s->d_blk, count, s->d_maxabs, s->d_flags, s->stream);
+    }
+    s->maxabs_scanned = false;  // the all-reduce below overwrites the local maximum: rescan if prepare runs again
     if (reduce(s, s->d_maxabs, 1, 1)) return 1;
     e2vq::launch_finish_scalars(s->d_maxabs, s->d_sc, s->stream);
     HIPCHK(hipMemsetAsync(s->d_stats, 0, (size_t)(2 * s->NC + 3) * 8, s->stream));
@@ -651,7 +658,7 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
         return 0;
     }
     if (ensure_qblk(s, T)) return 1;
-    e2vq::launch_blockify((const double*)device_frames, T, s->NC, s->FB, s->d_qblk, nb, s->stream);
+    e2vq::launch_blockify((const double*)device_frames, T, s->NC, s->FB, s->d_qblk, nb, nullptr, nullptr, s->stream);
     e2vq::launch_pass(s->NC, 0, s->d_qblk, T, nb, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                       (double*)device_dmin, nullptr, s->stream);
     HIPCHK(hipGetLastError());
