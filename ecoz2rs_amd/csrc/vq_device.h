@@ -18,7 +18,7 @@ struct DevScalars {
 inline int row_stride(int NC) { return (2 * NC + 5 + 7) & ~7; }
 inline int cb_pad(int NC) { return (NC + 7) & ~7; }
 
-bool uses_mfma(int NC);            // P = 36 (and 12, 16, 20, 24): the sweep runs on the FP64 matrix pipe
+bool uses_mfma(int NC);            // P = 4 .. 40: the sweep runs on the FP64 matrix pipe
 int mfma_hybrid_cells(int NC);     // cells of the hybrid accumulate's LDS table
 inline long cbm_doubles(int NC, int M) { return (long)((M + 15) / 16) * (((((NC + 3) / 4) + 1) / 2) * 128 + 16); }
 int frames_per_lane(int NC);       // F of the kernel that will serve this NC (block = 64*F frames)

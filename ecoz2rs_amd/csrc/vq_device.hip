@@ -15,8 +15,7 @@
 //    2.39 GHz where a v_fma_f64 stream power-throttles to ~56-60.  P = 36 therefore runs the
 //    chain on the matrix pipe: 16 codewords x 16 frames per MFMA, frames resident in VGPRs,
 //    codeword tiles streamed from L2, per-lane running argmin on the VALU (which idles
-//    otherwise).  P = 12, 16, 20, 24, 30, 40 take the same kernel template; any other P runs k_pass_generic
-//    on the VALU.
+//    otherwise).  The template is instantiated for every P = 4 .. 40; larger P run k_pass_generic on the VALU.
 //  * Training frames are resident in HBM in the operand layout of their kernel, so a wave's
 //    loads are fully coalesced 16 B/lane.
 //  * All sums are exact integers (two signed 32-bit limbs per value, 64-bit
@@ -1014,9 +1013,12 @@ static inline int grid_for(long work_items, int per_block, int cap)
     return (int)g;
 }
 
-// orders whose sweep runs on the FP64 matrix pipe: P = 12, 16, 20, 24, 36, 40 (NC = 4k+1: the trailing coefficient
-// goes to the VALU) and P = 30 (NC = 31: the last k-step is zero padded)
-bool uses_mfma(int NC) { return NC == 37 || NC == 13 || NC == 17 || NC == 21 || NC == 25 || NC == 31 || NC == 41; }
+// Every prediction order P = 4 .. 40 (NC = 5 .. 41) has an instantiation of the MFMA sweep: NC = 4k+1 runs the
+// trailing coefficient on the VALU, the others zero-pad the last k-step.  Larger P take k_pass_generic.
+#define E2VQ_MFMA_NC_LIST(X) \
+    X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) \
+    X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41)
+bool uses_mfma(int NC) { return NC >= 5 && NC <= 41; }
 int mfma_hybrid_cells(int NC) { return mfma_hyb_cells(NC); }
 
 // maxabs_bits / bad (optional): when given and the MFMA layout is used, the scan of max |x| rides along; returns
@@ -1049,13 +1051,10 @@ void launch_global_sums(const double* blk, long nblocks, int NC, int FB, const D
 {
     const dim3 g(grid_for(2 * nblocks, 4, 2048));
     switch (NC) {
-        case 37: hipLaunchKernelGGL((k_global_sums_mfma<37>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
-        case 25: hipLaunchKernelGGL((k_global_sums_mfma<25>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
-        case 21: hipLaunchKernelGGL((k_global_sums_mfma<21>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
-        case 17: hipLaunchKernelGGL((k_global_sums_mfma<17>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
-        case 13: hipLaunchKernelGGL((k_global_sums_mfma<13>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
-        case 31: hipLaunchKernelGGL((k_global_sums_mfma<31>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
-        case 41: hipLaunchKernelGGL((k_global_sums_mfma<41>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
+#define X(N) \
+    case N: hipLaunchKernelGGL((k_global_sums_mfma<N>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
+        E2VQ_MFMA_NC_LIST(X)
+#undef X
         default: break;
     }
     hipLaunchKernelGGL(k_global_sums, dim3(grid_for(nblocks * NC, 4, 4096)), dim3(256), 0, s, blk, nblocks, NC, FB, sc,
@@ -1126,13 +1125,10 @@ int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const
                 hipStream_t s)
 {
     switch (NC) {
-        case 37: return launch_pass_mfma<37>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
-        case 25: return launch_pass_mfma<25>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
-        case 21: return launch_pass_mfma<21>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
-        case 17: return launch_pass_mfma<17>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
-        case 13: return launch_pass_mfma<13>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
-        case 31: return launch_pass_mfma<31>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
-        case 41: return launch_pass_mfma<41>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
+#define X(N) \
+    case N: return launch_pass_mfma<N>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
+        E2VQ_MFMA_NC_LIST(X)
+#undef X
         default: break;
     }
     // generic: 64 frames per block, global atomics for the accumulation

@@ -91,12 +91,12 @@ def test_invalid_inputs_fail_loudly():
         e.vq_quantize("/nonexistent.cbook", [])
 
 
-@pytest.mark.parametrize("Pn", [12, 16, 20, 24, 30, 40, 33])
+@pytest.mark.parametrize("Pn", [4, 7, 10, 12, 16, 20, 24, 30, 33, 35, 38, 40, 44])
 def test_other_prediction_orders(oracle, Pn):
-    """P = 12, 16, 20, 24, 36, 40 (NC = 4k+1) and 30 (padded last k-step) run on the matrix pipe; any other order
-    (33 here) uses the generic VALU kernel."""
+    """Every P = 4..40 runs on the matrix pipe (NC = 4k+1: trailing coefficient on the VALU; otherwise a zero-padded
+    last k-step with 2, 3 or 4 live coefficients); larger orders (44 here) use the generic VALU kernel."""
     frames = e.synth.synth_frames(41, 3, Pn, 0, 3000)
-    max_m = 256 if Pn in (12, 24, 30, 40) else 8  # 256: LDS-table and hybrid accumulate modes of the MFMA kernel
+    max_m = 256 if Pn in (7, 10, 12, 24, 30, 33, 35, 38, 40) else 8  # 256: LDS-table and hybrid accumulate modes
     rc, levels_o, cbs_o = oracle.learn(frames, 0.05, max_m)
     assert rc == 0
     cbs = []
