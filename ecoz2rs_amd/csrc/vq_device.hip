@@ -1164,6 +1164,24 @@ void launch_finish_q(const i64* stats, int NC, DevScalars* sc, hipStream_t s)
     hipLaunchKernelGGL(k_finish_q, dim3(1), dim3(64), 0, s, stats, NC, sc);
 }
 
+// in-process multi-GPU exchange: dst[i] (op)= src_k[i] for k < nsrc, 64-bit integers (sum or max), exact
+__global__ void k_combine_i64(i64* __restrict__ dst, const i64* __restrict__ stage, int nsrc, long count, int op)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        i64 v = dst[i];
+        for (int k = 0; k < nsrc; ++k) {
+            const i64 o = stage[(long)k * count + i];
+            v = op == 0 ? v + o : ((u64)o > (u64)v ? o : v);
+        }
+        dst[i] = v;
+    }
+}
+
+void launch_combine_i64(i64* dst, const i64* stage, int nsrc, long count, int op, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_combine_i64, dim3(grid_for(count, 256, 1024)), dim3(256), 0, s, dst, stage, nsrc, count, op);
+}
+
 bool has_cell_update(int NC) { return NC <= 64; }
 
 // fused per-cell update (rows != nullptr) or codeword preparation only (rows == nullptr)

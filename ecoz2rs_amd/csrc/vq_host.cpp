@@ -19,7 +19,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using e2vq::DevScalars;
@@ -695,6 +698,114 @@ extern "C" int e2vq_avg_distortion_host(e2vq_session* s, const double* frames, i
     return 0;
 }
 
+
+// ==========================================================================================
+// In-process group: N sessions (one per GPU, one host thread each) behind the single-process entry points.
+// The per-pass exchange of the int64 cell sums runs GPU-to-GPU: every rank copies its buffer to a staging area on
+// rank 0's device (hipMemcpyPeerAsync: xGMI between the GPUs of a node), rank 0 combines with an integer kernel
+// and the result is copied back.  Integer sums: the outcome is bit-identical for any N.
+// Opt-in: ECOZ2_VQ_GPUS=N (ranks beyond the device count share devices, which is how the single-GPU tests run it).
+// ==========================================================================================
+namespace {
+
+struct LocalGroup {
+    int n = 1;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    long generation = 0;
+    bool failed = false;
+    // exchange state
+    int dev0 = 0;
+    i64* stage = nullptr;  // on dev0: (n-1) x stage_cap words
+    long stage_cap = 0;
+    i64* buf0 = nullptr;
+    std::vector<hipEvent_t> ev_up, ev_back;
+    hipEvent_t ev_done = nullptr;
+
+    // reusable barrier; returns false if the group has failed
+    bool barrier()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (failed) return false;
+        const long gen = generation;
+        if (++arrived == n) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen || failed; });
+        }
+        return !failed;
+    }
+    void fail()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        cv.notify_all();
+    }
+};
+
+struct LocalRank {
+    LocalGroup* g;
+    int rank;
+    int device;
+};
+
+#define GRPCHK(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            e2vq_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            g->fail();                                                                            \
+            return 1;                                                                             \
+        }                                                                                         \
+    } while (0)
+
+int local_allreduce(void* user, void* buf, int64_t count, int op, void* stream_)
+{
+    LocalRank* lr = (LocalRank*)user;
+    LocalGroup* g = lr->g;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int r = lr->rank;
+    const size_t bytes = (size_t)count * 8;
+    if (r == 0) {
+        GRPCHK(hipSetDevice(g->dev0));
+        if (count > g->stage_cap) {  // (grown before anyone copies: ranks > 0 wait at barrier A0)
+            if (g->stage) (void)hipFree(g->stage);
+            g->stage = nullptr;
+            GRPCHK(hipMalloc(&g->stage, (size_t)(g->n - 1) * bytes));
+            g->stage_cap = count;
+        }
+        g->buf0 = (i64*)buf;
+    }
+    if (!g->barrier()) return 1;  // A0: staging area and buf0 published
+    if (r > 0) {
+        GRPCHK(hipSetDevice(lr->device));
+        GRPCHK(hipMemcpyPeerAsync(g->stage + (size_t)(r - 1) * count, g->dev0, buf, lr->device, bytes, stream));
+        GRPCHK(hipEventRecord(g->ev_up[r], stream));
+    }
+    if (!g->barrier()) return 1;  // A: every upload is enqueued and its event recorded
+    if (r == 0) {
+        for (int k = 1; k < g->n; ++k) GRPCHK(hipStreamWaitEvent(stream, g->ev_up[k], 0));
+        e2vq::launch_combine_i64((i64*)buf, g->stage, g->n - 1, count, op, stream);
+        GRPCHK(hipGetLastError());
+        GRPCHK(hipEventRecord(g->ev_done, stream));
+    }
+    if (!g->barrier()) return 1;  // B: the combine is enqueued on rank 0's stream
+    if (r > 0) {
+        GRPCHK(hipStreamWaitEvent(stream, g->ev_done, 0));
+        GRPCHK(hipMemcpyPeerAsync(buf, lr->device, g->buf0, g->dev0, bytes, stream));
+        GRPCHK(hipEventRecord(g->ev_back[r], stream));
+    }
+    if (!g->barrier()) return 1;  // C: every copy-back is enqueued
+    if (r == 0)  // later work on rank 0's stream (e.g. zeroing the rows) must not overtake the copy-backs
+        for (int k = 1; k < g->n; ++k) GRPCHK(hipStreamWaitEvent(stream, g->ev_back[k], 0));
+    return 0;
+}
+
+}  // namespace
+
 // ==========================================================================================
 // Part 1: the reference's entry points
 // ==========================================================================================
@@ -740,6 +851,26 @@ static int load_predictors(const char* const* files, int n, int P_expected, std:
     return 0;
 }
 
+// one rank of a learn: session on `device`, frames [lo, hi) of the training set
+static int learn_rank(int device, int P, double eps, const char* class_name, const double* base_refl, int base_M,
+                      const double* frames, i64 lo, i64 hi, LocalRank* lr, int world, void* target,
+                      ecoz2_vq_learn_callback_t cb)
+{
+    e2vq_session* s = nullptr;
+    if (e2vq_session_create(device, P, &s)) return 1;
+    int rc = 0;
+    if (lr) rc = e2vq_set_allreduce(s, local_allreduce, lr, lr->rank, world);
+    if (!rc) rc = e2vq_set_frames_host(s, frames + (size_t)lo * (P + 1), hi - lo);
+    if (!rc) rc = e2vq_prepare(s);
+    if (!rc) rc = base_refl ? e2vq_set_codebook(s, base_refl, base_M) : e2vq_init_codebook(s);
+    if (!rc)
+        rc = e2vq_learn(s, eps, env_int("ECOZ2_VQ_MAX_CODEBOOK_SIZE", 2048), class_name,
+                        env_str("ECOZ2_VQ_OUT_ROOT", "."), target, cb, nullptr, 0, nullptr);
+    if (rc && lr) lr->g->fail();
+    e2vq_session_destroy(s);
+    return rc;
+}
+
 static int learn_common(int P, double eps, const char* class_name, const double* base_refl, int base_M,
                         const char* const* files, int n, void* target, ecoz2_vq_learn_callback_t cb)
 {
@@ -748,17 +879,70 @@ static int learn_common(int P, double eps, const char* class_name, const double*
     int Pf = 0;
     if (load_predictors(files, n, P, frames, &T, &Pf)) return 1;
     printf("Codebook generation:\n\n%lld training vectors (ε=%g)\n", (long long)T, eps);
-    e2vq_session* s = nullptr;
-    if (e2vq_session_create(env_int("ECOZ2_VQ_DEVICE", 0), P, &s)) return 1;
-    int rc = e2vq_set_frames_host(s, frames.data(), T);
-    std::vector<double>().swap(frames);
-    if (!rc) rc = e2vq_prepare(s);
-    if (!rc) rc = base_refl ? e2vq_set_codebook(s, base_refl, base_M) : e2vq_init_codebook(s);
-    if (!rc)
-        rc = e2vq_learn(s, eps, env_int("ECOZ2_VQ_MAX_CODEBOOK_SIZE", 2048), class_name,
-                        env_str("ECOZ2_VQ_OUT_ROOT", "."), target, cb, nullptr, 0, nullptr);
-    e2vq_session_destroy(s);
-    return rc;
+    const int ndev = e2vq_device_count();
+    if (ndev < 1) return e2vq_set_error("no HIP device available; this library has no CPU path");
+    const int dev0 = env_int("ECOZ2_VQ_DEVICE", 0);
+    int world = env_int("ECOZ2_VQ_GPUS", 1);
+    if (world < 1) world = 1;
+    if ((i64)world > T) world = (int)T;  // every rank needs at least one training vector
+    if (world == 1) return learn_rank(dev0, P, eps, class_name, base_refl, base_M, frames.data(), 0, T, nullptr, 1, target, cb);
+
+    // ---- in-process group: rank r on device (dev0 + r) % ndev, contiguous frame shards --------------------------
+    printf("sharding over %d rank(s) on %d device(s)\n", world, ndev);
+    LocalGroup g;
+    g.n = world;
+    g.dev0 = dev0 % ndev;
+    g.ev_up.assign((size_t)world, nullptr);
+    g.ev_back.assign((size_t)world, nullptr);
+    std::vector<LocalRank> ranks((size_t)world);
+    for (int r = 0; r < world; ++r) {
+        ranks[r] = LocalRank{&g, r, (dev0 + r) % ndev};
+        HIPCHK(hipSetDevice(ranks[r].device));
+        HIPCHK(hipEventCreateWithFlags(&g.ev_up[r], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&g.ev_back[r], hipEventDisableTiming));
+        if (ranks[r].device != g.dev0) {  // peer access both ways (ignored if already enabled / same device)
+            (void)hipDeviceEnablePeerAccess(g.dev0, 0);
+            (void)hipSetDevice(g.dev0);
+            (void)hipDeviceEnablePeerAccess(ranks[r].device, 0);
+            (void)hipGetLastError();
+        }
+    }
+    HIPCHK(hipSetDevice(g.dev0));
+    HIPCHK(hipEventCreateWithFlags(&g.ev_done, hipEventDisableTiming));
+    std::vector<int> rcs((size_t)world, 0);
+    std::vector<std::thread> th;
+    auto shard = [&](int r, i64* lo, i64* hi) {
+        const i64 base = T / world, rem = T % world;
+        *lo = r * base + std::min<i64>(r, rem);
+        *hi = *lo + base + (r < rem ? 1 : 0);
+    };
+    for (int r = 1; r < world; ++r) {
+        th.emplace_back([&, r]() {
+            i64 lo, hi;
+            shard(r, &lo, &hi);
+            rcs[r] = learn_rank(ranks[r].device, P, eps, class_name, base_refl, base_M, frames.data(), lo, hi, &ranks[r],
+                                world, nullptr, nullptr);
+        });
+    }
+    {  // rank 0 runs on the calling thread: files, messages and the callback come from here
+        i64 lo, hi;
+        shard(0, &lo, &hi);
+        rcs[0] = learn_rank(ranks[0].device, P, eps, class_name, base_refl, base_M, frames.data(), lo, hi, &ranks[0], world,
+                            target, cb);
+    }
+    for (auto& t : th) t.join();
+    for (int r = 0; r < world; ++r) {
+        (void)hipEventDestroy(g.ev_up[r]);
+        (void)hipEventDestroy(g.ev_back[r]);
+    }
+    (void)hipEventDestroy(g.ev_done);
+    if (g.stage) {
+        (void)hipSetDevice(g.dev0);
+        (void)hipFree(g.stage);
+    }
+    for (int rc : rcs)
+        if (rc) return rc;
+    return 0;
 }
 
 extern "C" int ecoz2_vq_learn(int prediction_order, double epsilon, const char* codebook_class_name,

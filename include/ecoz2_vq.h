@@ -79,6 +79,7 @@ int ecoz2_vq_classify(const char *const *cb_filenames, int num_codebooks,
 /* Knobs the reference has no argument for (environment):
  *   ECOZ2_VQ_MAX_CODEBOOK_SIZE  last codebook size trained (default 2048, notes.md:147)
  *   ECOZ2_VQ_DEVICE             HIP device ordinal (default 0)
+ *   ECOZ2_VQ_GPUS               vq learn only: shard over this many in-process ranks / GPUs (default 1)
  *   ECOZ2_VQ_OUT_ROOT           prefix for data/... outputs (default ".")               */
 
 /* ========================================================================================

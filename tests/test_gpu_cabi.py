@@ -368,3 +368,24 @@ def test_cli_end_to_end(tmp_path, oracle):
     env["ECOZ2_VQ_MAX_CODEBOOK_SIZE"] = "16"
     out = run("vq", "learn", "-B", "data/codebooks/A/eps_0.05_M_0008.cbook", "--predictors", "data/predictors/A")
     assert "Ecoz2ObserverRef.step: M=16" in out and "M=8 " not in out.split("base codebook")[1]
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 5])
+def test_in_process_group_reproduces_golden_codebooks(tmp_path, monkeypatch, ranks):
+    """ECOZ2_VQ_GPUS=N: ecoz2_vq_learn shards the frames over N in-process ranks (sharing the one GPU here) and
+    exchanges the int64 cell sums device-to-device; the codebooks must equal the single-rank / oracle fixtures."""
+    meta = json.load(open(os.path.join(GOLD, "config1.json")))
+    frames = e.synth.synth_frames(meta["seed"], meta["classes"], P, 0, meta["T"])
+    f = tmp_path / "data" / "predictors" / "_" / "all.prd"
+    e.formats.write_prd(str(f), "_", frames)
+    monkeypatch.setenv("ECOZ2_VQ_OUT_ROOT", str(tmp_path))
+    monkeypatch.setenv("ECOZ2_VQ_MAX_CODEBOOK_SIZE", str(meta["max_M"]))
+    monkeypatch.setenv("ECOZ2_VQ_GPUS", str(ranks))
+    seen = []
+    e.vq_learn(None, P, meta["eps"], "_", [str(f)], callback=lambda *a: seen.append(a))
+    assert [s[0] for s in seen] == [g["M"] for g in meta["levels"]]
+    for s, g in zip(seen, meta["levels"]):
+        assert (s[1].hex(), s[2].hex(), s[3].hex()) == (g["avg"], g["sigma"], g["inertia"])
+        name = f"eps_0.05_M_{g['M']:04d}.cbook"
+        got = open(tmp_path / "data" / "codebooks" / "_" / name, "rb").read()
+        assert got == open(os.path.join(GOLD, "config1_" + name), "rb").read()
