@@ -1,0 +1,150 @@
+// vq_accum.h -- the accumulate half of a pass (K2), shared by the FP64 sweep kernel (vq_device.hip) and the
+// prefiltered sweep kernel (vq_prefilter.hip): a wave's 64 frames, resident in registers in the FP64 MFMA operand
+// layout, are added to their cells as exact 64-bit integers.
+#pragma once
+#include "vq_device.h"
+#include "vq_fixed.h"
+
+#include <hip/hip_runtime.h>
+
+namespace e2vq {
+
+typedef long long i64;
+typedef unsigned long long u64;
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int IMG_STRIDE_PAD = 3;  // image row stride 2*NC+5+pad: 82 dwords for NC=37 (conflict-free b64 writes)
+
+// cells of the hybrid (MODE 5) LDS table: what fits beside the eight per-wave row images, multiple of 8
+__host__ __device__ constexpr int mfma_hyb_cells(int NC)
+{
+    return (int)((E2VQ_LDS_BYTES - 10240 - 8 * 16 * (2 * NC + 5 + IMG_STRIDE_PAD) * 4) / (((2 * NC + 5 + 7) & ~7) * 8)) & ~7;
+}
+
+// offset (in doubles) of r[t][n] in the blocked FP64 MFMA frame layout written by k_blockify_mfma
+__host__ __device__ __forceinline__ long mfma_blk_offset(int NC, long t, int n)
+{
+    const int NS = (NC + 3) >> 2;
+    const long b = t >> 6;
+    const int w = (int)(t & 63), u = w >> 5, h = (w >> 4) & 1, j = w & 15;
+    const int st = n >> 2 < NS - 1 ? n >> 2 : NS - 1;
+    const int x = st * 128 + ((n - 4 * st) * 16 + j) * 2 + h;
+    return b * (long)NC * 64 + (long)u * NC * 32 + x;
+}
+
+// Bf[ft][st]: lane (q, j) holds r[frame 16 ft + j][4 st + q] (with NC = 4k+1 every q lane holds r[NC-1] in the
+// last slot); best / idx: min distortion and cell of frame 16 ft + j, in all four q lanes.  img: this wave's 16 row
+// images in LDS.  MODE 1: all cells in the LDS table lacc; 5: cells < lds_cells there; 2: global atomics; 3: none.
+// SKIP: frames flagged in skip[] (handled by the fallback launch) contribute an all-zero image (their idx must be 0).
+// NFT: 16-frame tiles per block (4 everywhere but in the one-tile-per-wave fallback sweep).
+template <int NC, int MODE, bool SKIP = false, int NFT = 4>
+__device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((NC + 3) / 4) + 1) / 2)],
+                                                 const double (&best)[4], const int (&idx)[4], int* __restrict__ img,
+                                                 i64* __restrict__ lacc, i64* __restrict__ rows, int lds_cells, int sh_r,
+                                                 int sh_d, int sh_d2, long b, long T, int lane, const bool (&skip)[4])
+{
+    constexpr int NS = (NC + 3) / 4, REM = NC - 4 * (NS - 1);
+    constexpr int RS = (2 * NC + 5 + 7) & ~7;
+    constexpr int NE = 2 * NC + 5;
+    constexpr int IMG = NE + IMG_STRIDE_PAD;
+    constexpr int HYB_CELLS = mfma_hyb_cells(NC);
+    const int q = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) {
+        int* my = img + j * IMG;
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            if (st < NS - 1 || q < REM) {  // with TAILV only q = 0 writes r[NC-1] (all q lanes hold it)
+                int hi, lo;
+                fix2(Bf[ft][st], sh_r, hi, lo);
+                if (SKIP && skip[ft]) hi = lo = 0;
+                *(int2*)&my[2 * (4 * st + q)] = make_int2(hi, lo);
+            }
+        }
+        if (q == 0) {
+            const double e = (SKIP && skip[ft]) ? 0.0 : best[ft] - 1.0;
+            int hi, lo;
+            my[2 * NC] = (SKIP && skip[ft]) ? 0 : 1;
+            fix2(e, sh_d, hi, lo);
+            my[2 * NC + 1] = hi;
+            my[2 * NC + 2] = lo;
+            fix2(e * e, sh_d2, hi, lo);
+            my[2 * NC + 3] = hi;
+            my[2 * NC + 4] = lo;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // padding frames (t >= T) are never counted; nv is wave-uniform
+        const long left = T - (b * (16 * NFT) + ft * 16);
+        const int nv = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
+        if (nv == 16 && NE <= 80) {
+            // full tile, 4 frames per step: four adds of elements 0..63 of each frame's row and, when the
+            // row is longer (64 < NE <= 80), ONE add carrying the four row tails (lanes 16k.. -> frame k),
+            // so LDS reads and atomics of different frames overlap and no lane-divergent branch remains.
+            constexpr bool HAS_TAIL = NE > 64;  // (rows longer than 80 elements take the per-frame loop below)
+            const int tq = lane >> 4, te = lane & 15;
+#pragma unroll
+            for (int j0 = 0; j0 < 16; j0 += 4) {
+                int v[4], cell[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    cell[k] = __builtin_amdgcn_readlane(idx[ft], j0 + k);
+                    v[k] = (HAS_TAIL || lane < NE) ? img[(j0 + k) * IMG + lane] : 0;
+                }
+                const int tv = (HAS_TAIL && te < NE - 64) ? img[(j0 + tq) * IMG + 64 + te] : 0;
+                const int tcell = tq == 0 ? cell[0] : tq == 1 ? cell[1] : tq == 2 ? cell[2] : cell[3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!HAS_TAIL && lane >= NE) continue;  // short rows: lanes beyond the row sit out
+                    if constexpr (MODE == 3) {
+                        asm volatile("" ::"v"(v[k]), "s"(cell[k]));
+                    } else if constexpr (MODE == 1) {
+                        atomicAdd((u64*)&lacc[cell[k] * RS + lane], (u64)(i64)v[k]);
+                    } else if constexpr (MODE == 5) {
+                        if (cell[k] < HYB_CELLS)  // wave-uniform
+                            atomicAdd((u64*)&lacc[cell[k] * RS + lane], (u64)(i64)v[k]);
+                        else
+                            atomicAdd((u64*)&rows[(long)cell[k] * RS + lane], (u64)(i64)v[k]);
+                    } else {
+                        atomicAdd((u64*)&rows[(long)cell[k] * RS + lane], (u64)(i64)v[k]);
+                    }
+                }
+                if (HAS_TAIL && te < NE - 64) {
+                    if constexpr (MODE == 3) {
+                        asm volatile("" ::"v"(tv), "v"(tcell));
+                    } else if constexpr (MODE == 1) {
+                        atomicAdd((u64*)&lacc[tcell * RS + 64 + te], (u64)(i64)tv);
+                    } else if constexpr (MODE == 5) {
+                        if (tcell < HYB_CELLS)  // per 16-lane group
+                            atomicAdd((u64*)&lacc[tcell * RS + 64 + te], (u64)(i64)tv);
+                        else
+                            atomicAdd((u64*)&rows[(long)tcell * RS + 64 + te], (u64)(i64)tv);
+                    } else {
+                        atomicAdd((u64*)&rows[(long)tcell * RS + 64 + te], (u64)(i64)tv);
+                    }
+                }
+            }
+        } else {
+            for (int jj = 0; jj < nv; ++jj) {
+                const int cell = __builtin_amdgcn_readlane(idx[ft], jj);
+                const int* im = img + jj * IMG;
+                if (cell < lds_cells) {  // wave-uniform
+                    i64* row = lacc + cell * RS;
+                    if (lane < NE) atomicAdd((u64*)&row[lane], (u64)(i64)im[lane]);
+                    if (NE > 64 && lane < NE - 64) atomicAdd((u64*)&row[64 + lane], (u64)(i64)im[64 + lane]);
+                } else {
+                    i64* row = rows + (long)cell * RS;
+                    if (lane < NE) atomicAdd((u64*)&row[lane], (u64)(i64)im[lane]);
+                    if (NE > 64 && lane < NE - 64) atomicAdd((u64*)&row[64 + lane], (u64)(i64)im[64 + lane]);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+}
+
+}  // namespace e2vq

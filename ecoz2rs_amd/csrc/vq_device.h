@@ -34,6 +34,22 @@ void launch_global_sums(const double* blk, long nblocks, int NC, int FB, const D
 int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const double* cbq, const double* cbm,
                 int M, const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                 long long* rows, hipStream_t s);
+// prefiltered pass (vq_prefilter.hip; P = 36): f16 limb images + exact candidate evaluation + fallback list
+bool prefilter_supports(int NC, int M);
+size_t prefilter_frame_image_bytes(long nblocks64);
+size_t prefilter_codebook_image_bytes(int M);
+size_t prefilter_scalars_bytes();
+void launch_prefilter_frames(const double* blk, long T, long nblocks64, int NC, unsigned long long* colmax_bits, int* ea,
+                             void* fimg, float* fg, hipStream_t s);
+void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, void* ps, void* cimg, hipStream_t s);
+const int* prefilter_fallback_count(const void* ps);
+int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, long nblocks, const void* fimg,
+                            const float* fg, const void* cimg, void* ps, const double* cbq, int M,
+                            const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
+                            long long* rows, int* fb_list, hipStream_t s);
+int launch_pass_fallback(int NC, bool accumulate, const double* blk, const double* cbm, int M, const DevScalars* sc,
+                         const unsigned long long* l1max_bits, unsigned short* sym, double* dmin, long long* rows,
+                         const int* fb_list, const int* fb_count, hipStream_t s);
 void launch_rows_stats(const long long* rows, int M, int NC, const DevScalars* sc, double* S, double* within,
                        long long* lstats, hipStream_t s);
 void launch_centroids(const long long* rows, const double* S, int M, int NC, const double* refl_in, double* refl_out,

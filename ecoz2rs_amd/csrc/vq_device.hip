@@ -23,6 +23,7 @@
 //    bit-identical cell sums; RCCL all-reduce runs on int64.
 //
 // Compiled with -ffp-contract=off: every FMA below is explicit.
+#include "vq_accum.h"
 #include "vq_device.h"
 #include "vq_fixed.h"
 
@@ -31,8 +32,6 @@
 #include <stdlib.h>
 
 typedef const double __attribute__((address_space(4))) cdouble_k;
-typedef long long i64;
-typedef unsigned long long u64;
 
 namespace e2vq {
 
@@ -136,7 +135,6 @@ __global__ void k_finish_scalars(const u64* __restrict__ maxabs_bits, DevScalars
 //   MODE  0: assignment only (quantize)   1: LDS accumulator table (small M)   2: global atomics (large M)
 //         5: hybrid LDS/global (mid M)    3: diagnostics (MODE 2 without the atomics)
 constexpr int TPB = 256;
-constexpr int IMG_STRIDE_PAD = 3;  // image row stride 2*NC+5+pad: 82 dwords for NC=37 (conflict-free b64 writes)
 
 // ------------------------------------------------------------------------------------------
 // MFMA path (P = 36): operand layouts
@@ -146,12 +144,6 @@ constexpr int IMG_STRIDE_PAD = 3;  // image row stride 2*NC+5+pad: 82 dwords for
 //   codebook: cbm[tile][p][lane][2] = cq[16*tile + j][4*(2p+e) + q], zero beyond n = P,
 //            codewords beyond M are copies of codeword 0 (they can never win a tie)
 // ------------------------------------------------------------------------------------------
-typedef double d4 __attribute__((ext_vector_type(4)));
-// cells of the hybrid (MODE 5) LDS table: what fits beside the eight per-wave row images, multiple of 8
-__host__ __device__ constexpr int mfma_hyb_cells(int NC)
-{
-    return (int)((E2VQ_LDS_BYTES - 10240 - 8 * 16 * (2 * NC + 5 + IMG_STRIDE_PAD) * 4) / (((2 * NC + 5 + 7) & ~7) * 8)) & ~7;
-}
 #ifndef E2VQ_PRIO
 #define E2VQ_PRIO 1
 #endif
@@ -202,14 +194,27 @@ __global__ void k_blockify_mfma(const double* __restrict__ aos, long T, int NC, 
 
 // AOS = true (quantize): `blk` is the row-major .prd payload [t][NC]; each wave stages its 64 rows through LDS
 // with coalesced 16-B loads and picks its B operands from there, so no re-layout pass is needed.
-template <int NC, int MODE, int TPBM, bool AOS = false>
+// SRC = 2 (fallback of the prefiltered pass): the frames are those listed in fb_list[0 .. *fb_count), read from the
+// blocked layout one coefficient at a time; T and nblocks come from the device-side count.
+template <int NC, int MODE, int TPBM, int SRC = 0>
 __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict__ blk, long T, long nblocks,
                                                        const double* __restrict__ cbm, int MT, int M,
                                                        const DevScalars* __restrict__ sc,
                                                        const u64* __restrict__ l1max_bits,
                                                        unsigned short* __restrict__ sym, double* __restrict__ dmin,
-                                                       i64* __restrict__ rows, int stagger)
+                                                       i64* __restrict__ rows, int stagger,
+                                                       const int* __restrict__ fb_list = nullptr,
+                                                       const int* __restrict__ fb_count = nullptr)
 {
+    constexpr bool AOS = SRC == 1;
+    // frame tiles (of 16) per wave: the fallback list is short, so its waves take one tile each -- four times as
+    // many waves, each a quarter of the latency of a full 64-frame sweep
+    constexpr int NFT = SRC == 2 ? 1 : 4;
+    constexpr int FPB = 16 * NFT;
+    if constexpr (SRC == 2) {
+        T = *fb_count;
+        nblocks = (T + FPB - 1) / FPB;
+    }
     // NS k-steps of 4 cover n < 4*NS; with NC = 4*NSF + 1 the last coefficient (n = NC-1) is not padded to
     // a fifth MFMA k-step but applied as one VALU fma after the MFMA chain: same ascending order, same roundings.
     constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2, REM = NC - 4 * (NS - 1);
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int ft = 0; ft < 4; ++ft) {
+            for (int ft = 0; ft < NFT; ++ft) {
                 const double* row = stage + (16 * ft + j) * NC;
 #pragma unroll
                 for (int st = 0; st < NS - 1; ++st) Bf[ft][st] = row[4 * st + q];
@@ -294,6 +299,21 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+        } else if constexpr (SRC == 2) {
+#pragma unroll
+            for (int ft = NFT; ft < 4; ++ft)
+#pragma unroll
+                for (int st = 0; st < 2 * NP; ++st) Bf[ft][st] = 0.0;
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) {
+                const long slot = b * FPB + 16 * ft + j;
+                const long t = slot < T ? fb_list[slot] : -1;
+#pragma unroll
+                for (int st = 0; st < NS; ++st) {
+                    const int n = st < NS - 1 ? 4 * st + q : (TAILV ? NC - 1 : (q < REM ? 4 * (NS - 1) + q : -1));
+                    Bf[ft][st] = (t >= 0 && n >= 0) ? blk[mfma_blk_offset(NC, t, n)] : 0.0;
+                }
+            }
         } else
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -334,18 +354,18 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             d4 acc[4];
             if (PRIO) __builtin_amdgcn_s_setprio(1);  // the wave feeding the matrix pipe wins issue arbitration
 #pragma unroll
-            for (int ft = 0; ft < 4; ++ft)
+            for (int ft = 0; ft < NFT; ++ft)
                 acc[ft] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ac[0].x, Bf[ft][0], (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
 #pragma unroll
             for (int st = 1; st < NSM; ++st)
 #pragma unroll
-                for (int ft = 0; ft < 4; ++ft)
+                for (int ft = 0; ft < NFT; ++ft)
                     acc[ft] = __builtin_amdgcn_mfma_f64_16x16x4f64((st & 1) ? Ac[st >> 1].y : Ac[st >> 1].x, Bf[ft][st],
                                                                    acc[ft], 0, 0, 0);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
             if (TAILV) {
 #pragma unroll
-                for (int ft = 0; ft < 4; ++ft)
+                for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) acc[ft][rg] = __builtin_fma(Bf[ft][NS - 1], Tc[rg], acc[ft][rg]);
             }
@@ -354,7 +374,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             for (int rg = 0; rg < 4; ++rg) {
                 const int cval = __builtin_amdgcn_readfirstlane(ct * 4 + rg);  // wave-uniform: stays in an SGPR
 #pragma unroll
-                for (int ft = 0; ft < 4; ++ft) {
+                for (int ft = 0; ft < NFT; ++ft) {
                     const double v = acc[ft][rg];
                     const bool lt = v < best[ft];
                     code[ft] = lt ? cval : code[ft];
@@ -378,9 +398,9 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
         }
 
         // ---- combine the four lanes (q = 0..3) that hold one frame: min value, lowest index ---
-        int idx[4];
+        int idx[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft) {
+        for (int ft = 0; ft < NFT; ++ft) {
             idx[ft] = ((code[ft] >> 2) << 4) + ((code[ft] & 3) << 2) + q;
 #pragma unroll
             for (int off = 16; off <= 32; off <<= 1) {
@@ -396,110 +416,19 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
         {
             const double bs = q == 0 ? best[0] : q == 1 ? best[1] : q == 2 ? best[2] : best[3];
             const int is = q == 0 ? idx[0] : q == 1 ? idx[1] : q == 2 ? idx[2] : idx[3];
-            const long t = b * 64 + lane;
-            if (t < T) {
+            long t = b * FPB + lane;
+            const bool live = t < T && lane < FPB;
+            if constexpr (SRC == 2) t = live ? fb_list[t] : 0;
+            if (live) {
                 if (sym) sym[t] = (unsigned short)is;
                 if (dmin) dmin[t] = bs;
             }
         }
 
         // ---- accumulate: int32 row images [frame][2n+limb | count, d, d2] -> exact 64-bit adds ----
-        if constexpr (MODE != 0) {
-#pragma unroll
-            for (int ft = 0; ft < 4; ++ft) {
-                int* my = img + j * IMG;
-#pragma unroll
-                for (int st = 0; st < NS; ++st) {
-                    if (st < NS - 1 || q < REM) {  // with TAILV only q = 0 writes r[NC-1] (all q lanes hold it)
-                        int hi, lo;
-                        fix2(Bf[ft][st], sh_r, hi, lo);
-                        *(int2*)&my[2 * (4 * st + q)] = make_int2(hi, lo);
-                    }
-                }
-                if (q == 0) {
-                    const double e = best[ft] - 1.0;
-                    int hi, lo;
-                    my[2 * NC] = 1;
-                    fix2(e, sh_d, hi, lo);
-                    my[2 * NC + 1] = hi;
-                    my[2 * NC + 2] = lo;
-                    fix2(e * e, sh_d2, hi, lo);
-                    my[2 * NC + 3] = hi;
-                    my[2 * NC + 4] = lo;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // padding frames (t >= T) are never counted; nv is wave-uniform
-                const long left = T - (b * 64 + ft * 16);
-                const int nv = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
-                if (nv == 16 && NE <= 80) {
-                    // full tile, 4 frames per step: four adds of elements 0..63 of each frame's row and, when the
-                    // row is longer (64 < NE <= 80), ONE add carrying the four row tails (lanes 16k.. -> frame k),
-                    // so LDS reads and atomics of different frames overlap and no lane-divergent branch remains.
-                    constexpr bool HAS_TAIL = NE > 64;  // (rows longer than 80 elements take the per-frame loop below)
-                    const int tq = lane >> 4, te = lane & 15;
-#pragma unroll
-                    for (int j0 = 0; j0 < 16; j0 += 4) {
-                        int v[4], cell[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            cell[k] = __builtin_amdgcn_readlane(idx[ft], j0 + k);
-                            v[k] = (HAS_TAIL || lane < NE) ? img[(j0 + k) * IMG + lane] : 0;
-                        }
-                        const int tv = (HAS_TAIL && te < NE - 64) ? img[(j0 + tq) * IMG + 64 + te] : 0;
-                        const int tcell = tq == 0 ? cell[0] : tq == 1 ? cell[1] : tq == 2 ? cell[2] : cell[3];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            if (!HAS_TAIL && lane >= NE) continue;  // short rows: lanes beyond the row sit out
-                            if constexpr (MODE == 3) {
-                                asm volatile("" ::"v"(v[k]), "s"(cell[k]));
-                            } else if constexpr (MODE == 1) {
-                                atomicAdd((u64*)&lacc[cell[k] * RS + lane], (u64)(i64)v[k]);
-                            } else if constexpr (MODE == 5) {
-                                if (cell[k] < HYB_CELLS)  // wave-uniform
-                                    atomicAdd((u64*)&lacc[cell[k] * RS + lane], (u64)(i64)v[k]);
-                                else
-                                    atomicAdd((u64*)&rows[(long)cell[k] * RS + lane], (u64)(i64)v[k]);
-                            } else {
-                                atomicAdd((u64*)&rows[(long)cell[k] * RS + lane], (u64)(i64)v[k]);
-                            }
-                        }
-                        if (HAS_TAIL && te < NE - 64) {
-                            if constexpr (MODE == 3) {
-                                asm volatile("" ::"v"(tv), "v"(tcell));
-                            } else if constexpr (MODE == 1) {
-                                atomicAdd((u64*)&lacc[tcell * RS + 64 + te], (u64)(i64)tv);
-                            } else if constexpr (MODE == 5) {
-                                if (tcell < HYB_CELLS)  // per 16-lane group
-                                    atomicAdd((u64*)&lacc[tcell * RS + 64 + te], (u64)(i64)tv);
-                                else
-                                    atomicAdd((u64*)&rows[(long)tcell * RS + 64 + te], (u64)(i64)tv);
-                            } else {
-                                atomicAdd((u64*)&rows[(long)tcell * RS + 64 + te], (u64)(i64)tv);
-                            }
-                        }
-                    }
-                } else {
-                    for (int jj = 0; jj < nv; ++jj) {
-                        const int cell = __builtin_amdgcn_readlane(idx[ft], jj);
-                        const int* im = img + jj * IMG;
-                        if (cell < lds_cells) {  // wave-uniform
-                            i64* row = lacc + cell * RS;
-                            if (lane < NE) atomicAdd((u64*)&row[lane], (u64)(i64)im[lane]);
-                            if (NE > 64 && lane < NE - 64) atomicAdd((u64*)&row[64 + lane], (u64)(i64)im[64 + lane]);
-                        } else {
-                            i64* row = rows + (long)cell * RS;
-                            if (lane < NE) atomicAdd((u64*)&row[lane], (u64)(i64)im[lane]);
-                            if (NE > 64 && lane < NE - 64) atomicAdd((u64*)&row[64 + lane], (u64)(i64)im[64 + lane]);
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-        }
+        if constexpr (MODE != 0)
+            accumulate_block<NC, MODE, false, NFT>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2, b, T, lane,
+                                                   {false, false, false, false});
     }
 
     if constexpr (MODE == 1 || MODE == 5) {
@@ -1083,10 +1012,10 @@ static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, c
                            l1max_bits, sym, dmin, rows, 0);
     } else if (mode == 4) {  // assignment only, frames in row-major (.prd) layout
         const size_t lds = (size_t)4 * NC * 64 * 8;
-        (void)hipFuncSetAttribute((const void*)k_pass_mfma<NC, 0, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)k_pass_mfma<NC, 0, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
         const int grid = grid_for(nblocks, 4, 512);
-        hipLaunchKernelGGL((k_pass_mfma<NC, 0, 256, true>), dim3(grid), dim3(256), lds, s, blk, T, nblocks, cbm, MT, M, sc,
+        hipLaunchKernelGGL((k_pass_mfma<NC, 0, 256, 1>), dim3(grid), dim3(256), lds, s, blk, T, nblocks, cbm, MT, M, sc,
                            l1max_bits, sym, dmin, rows, 0);
     } else if (mode == 1) {
         const size_t lds = (size_t)M * RS * 8 + (size_t)8 * 16 * IMG * 4;
@@ -1139,6 +1068,23 @@ int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const
     else
         hipLaunchKernelGGL((k_pass_generic<2>), dim3(grid), dim3(TPB), 0, s, blk, T, nblocks, NC, cbq, M, sc,
                            l1max_bits, sym, dmin, rows);
+    return 0;
+}
+
+// full FP64 sweep of the frames a prefiltered pass could not certify (vq_prefilter.hip): fb_list[0 .. *fb_count)
+int launch_pass_fallback(int NC, bool accumulate, const double* blk, const double* cbm, int M, const DevScalars* sc,
+                         const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows, const int* fb_list,
+                         const int* fb_count, hipStream_t s)
+{
+    if (NC != 37) return 1;
+    constexpr int IMG = 2 * 37 + 5 + IMG_STRIDE_PAD;
+    const int MT = (M + 15) / 16;
+    if (accumulate)
+        hipLaunchKernelGGL((k_pass_mfma<37, 2, 512, 2>), dim3(256), dim3(512), (size_t)8 * 16 * IMG * 4, s, blk, 0L, 0L, cbm,
+                           MT, M, sc, l1max_bits, sym, dmin, rows, 0, fb_list, fb_count);
+    else
+        hipLaunchKernelGGL((k_pass_mfma<37, 0, 256, 2>), dim3(512), dim3(256), 0, s, blk, 0L, 0L, cbm, MT, M, sc, l1max_bits,
+                           sym, dmin, rows, 0, fb_list, fb_count);
     return 0;
 }
 

@@ -113,6 +113,18 @@ struct e2vq_session {
     // HIP events around the sweep kernel (bench.py's roofline figures)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false, timed = false;
+    // prefiltered sweep (P = 36, M >= pre_min_M): f16 limb images of the frames / the codebook, fallback list
+    bool pre_enabled = false;
+    int pre_min_M = 256;
+    unsigned long long* d_colmax = nullptr;
+    int* d_ea = nullptr;
+    void* d_fimg = nullptr;
+    float* d_fg = nullptr;
+    void* d_cimg = nullptr;
+    int cimg_cap = 0;
+    void* d_ps = nullptr;
+    int* d_fblist = nullptr;
+    bool last_prefiltered = false;
     // collective hook
     e2vq_allreduce_fn allreduce = nullptr;
     void* ar_user = nullptr;
@@ -190,6 +202,15 @@ static int session_init(e2vq_session* s)
     HIPCHK(hipEventCreateWithFlags(&s->ev_stats, hipEventDisableTiming));
     HIPCHK(hipMalloc(&s->d_l1max_spec, 8));
     HIPCHK(hipHostMalloc(&s->h_stats, sizeof(*s->h_stats)));
+    // ECOZ2_VQ_PREFILTER=0 keeps every pass on the FP64 sweep; ECOZ2_VQ_PREFILTER_MIN_M moves the switch-over size
+    const char* pf = getenv("ECOZ2_VQ_PREFILTER");
+    s->pre_enabled = e2vq::prefilter_supports(s->NC, 64) && !(pf && atoi(pf) == 0);
+    if (const char* mm = getenv("ECOZ2_VQ_PREFILTER_MIN_M")) s->pre_min_M = std::max(64, atoi(mm));
+    if (s->pre_enabled) {
+        HIPCHK(hipMalloc(&s->d_colmax, (size_t)s->NC * 8));
+        HIPCHK(hipMalloc(&s->d_ea, (size_t)s->NC * sizeof(int)));
+        HIPCHK(hipMalloc(&s->d_ps, e2vq::prefilter_scalars_bytes()));
+    }
     return 0;
 }
 
@@ -230,7 +251,7 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     void* ptrs[] = {s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
-                    s->d_qdmin};
+                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg, s->d_ps, s->d_fblist};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev_stats) (void)hipEventDestroy(s->ev_stats);
@@ -290,6 +311,19 @@ extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames
     s->maxabs_scanned = e2vq::launch_blockify((const double*)device_frames, T, s->NC, s->FB, s->d_blk, s->nblocks,
                                               s->d_maxabs, s->d_flags, s->stream);
     HIPCHK(hipGetLastError());
+    if (s->pre_enabled) {
+        if (s->d_fimg) HIPCHK(hipFree(s->d_fimg));
+        if (s->d_fg) HIPCHK(hipFree(s->d_fg));
+        if (s->d_fblist) HIPCHK(hipFree(s->d_fblist));
+        s->d_fimg = nullptr;
+        s->d_fg = nullptr;
+        s->d_fblist = nullptr;
+        HIPCHK(hipMalloc(&s->d_fimg, e2vq::prefilter_frame_image_bytes(s->nblocks)));
+        HIPCHK(hipMalloc(&s->d_fg, (size_t)s->nblocks * 64 * sizeof(float)));
+        HIPCHK(hipMalloc(&s->d_fblist, (size_t)s->nblocks * 64 * sizeof(int)));
+        e2vq::launch_prefilter_frames(s->d_blk, T, s->nblocks, s->NC, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->stream);
+        HIPCHK(hipGetLastError());
+    }
     s->prepared = false;
     s->stats_valid = false;
     return 0;
@@ -423,23 +457,75 @@ static int pass_mode(const e2vq_session* s)
     return 2;  // generic kernel: global atomics
 }
 
+// the prefiltered sweep serves the accumulate-by-global-atomics and assignment-only passes of large codebooks
+static bool use_prefilter(const e2vq_session* s, int mode)
+{
+    return s->pre_enabled && s->d_fimg && (mode == 1 || mode == 2 || mode == 5 || mode == 0) && s->M >= s->pre_min_M &&
+           e2vq::prefilter_supports(s->NC, s->M);
+}
+
+static int ensure_codebook_image(e2vq_session* s)
+{
+    if (s->M <= s->cimg_cap) return 0;
+    if (s->d_cimg) HIPCHK(hipFree(s->d_cimg));
+    s->d_cimg = nullptr;
+    s->cimg_cap = std::max(s->M, 2048);
+    HIPCHK(hipMalloc(&s->d_cimg, e2vq::prefilter_codebook_image_bytes(s->cimg_cap)));
+    return 0;
+}
+
 extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
 {
     if (!s->prepared) return e2vq_set_error("e2vq_prepare has not run");
     if (s->M < 1) return e2vq_set_error("no codebook");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipMemsetAsync(s->d_rows, 0, (size_t)s->M * s->RS * 8, s->stream));
-    if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
-    e2vq::launch_pass(s->NC, pass_mode(s), s->d_blk, s->T, s->nblocks, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max,
-                      (unsigned short*)device_sym, (double*)device_dmin, s->d_rows, s->stream);
-    if (s->timing) {
-        HIPCHK(hipEventRecord(s->ev1, s->stream));
-        s->timed = true;
+    const int mode = pass_mode(s);
+    s->last_prefiltered = use_prefilter(s, mode);
+    if (s->last_prefiltered) {
+        // f16 limb image of the current codebook, prefiltered sweep (exact evaluation of the certified top two),
+        // then the full FP64 sweep of whatever it could not certify
+        if (ensure_codebook_image(s)) return 1;
+        e2vq::launch_prefilter_codebook(s->d_cbq, s->M, s->NC, s->d_ea, s->d_ps, s->d_cimg, s->stream);
+        if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
+        e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, s->d_cimg, s->d_ps,
+                                      s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
+                                      (double*)device_dmin, s->d_rows, s->d_fblist, s->stream);
+        if (s->timing) {
+            HIPCHK(hipEventRecord(s->ev1, s->stream));
+            s->timed = true;
+        }
+        e2vq::launch_pass_fallback(s->NC, mode != 0, s->d_blk, s->d_cbm, s->M, s->d_sc, s->d_l1max,
+                                   (unsigned short*)device_sym, (double*)device_dmin, s->d_rows, s->d_fblist,
+                                   e2vq::prefilter_fallback_count(s->d_ps), s->stream);
+    } else {
+        if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
+        e2vq::launch_pass(s->NC, mode, s->d_blk, s->T, s->nblocks, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max,
+                          (unsigned short*)device_sym, (double*)device_dmin, s->d_rows, s->stream);
+        if (s->timing) {
+            HIPCHK(hipEventRecord(s->ev1, s->stream));
+            s->timed = true;
+        }
     }
     HIPCHK(hipGetLastError());
     if (reduce(s, s->d_rows, (i64)s->M * s->RS, 0)) return 1;
     s->stats_valid = false;
     s->spec_valid = false;
+    return 0;
+}
+
+extern "C" int e2vq_last_pass_info(e2vq_session* s, int* prefiltered, int64_t* fallback_frames)
+{
+    HIPCHK(hipSetDevice(s->device));
+    if (prefiltered) *prefiltered = s->last_prefiltered ? 1 : 0;
+    if (fallback_frames) {
+        int n = 0;
+        if (s->last_prefiltered) {
+            HIPCHK(hipMemcpyAsync(&n, e2vq::prefilter_fallback_count(s->d_ps), sizeof(int), hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+        }
+        *fallback_frames = n;
+    }
     return 0;
 }
 

@@ -1,0 +1,571 @@
+// vq_prefilter.hip -- the prefiltered sweep: same results as the FP64 sweep (bit for bit), ~1/3 of its time.
+//
+// Idea.  argmin_m d(r, c_m) needs the FP64 chain only for the codewords that can win.  A cheap approximation
+// d~ with a PROVEN error bound eps finds them: every codeword whose d~ exceeds the smallest d~ by more than
+// 2 eps is out.  The approximation runs on the f16 matrix pipe and is made of exact integer arithmetic, so the
+// bound needs no assumption about the hardware's summation order:
+//
+//   * per coefficient n a power of two a_n >= max_t |r_t[n]| (data statistic), per frame a power of two A_t,
+//     per codebook a power of two C:   xi = r / (a A_t),  eta = c a / C,  both in (-1, 1),  d = A_t C sum xi eta
+//   * xi -> three integer limbs  X1 = rint(xi 2^9) (|X1| <= 512), X2, X3 (|.| <= 256):
+//         xi = X1 2^-9 + X2 2^-18 + X3 2^-27 + rho,  |rho| <= 2^-28;   eta likewise (Y1, Y2, Y3, sigma)
+//   * the limb products of equal weight are summed by v_mfma_f32_32x32x16_f16 into separate f32 accumulators
+//         W0 = sum X1 Y1,   W1 = sum X1 Y2 + X2 Y1,   W2 = sum X1 Y3 + X2 Y2 + X3 Y1
+//     every partial sum is an integer below 2^24 (37 * 2^18, 74 * 2^17, 37 * 5 * 2^16), i.e. exactly representable:
+//     the MFMA results are exact in any summation order (checked on hardware: tools/probe/pre_sweep.hip)
+//   * v = W0 2^18 + W1 2^9 + W2 (two f32 fmas), key = v with its low mantissa bits replaced by the codeword index;
+//     a running (min, 2nd, 3rd) of the keys per frame costs three VALU ops per value
+//   * |2^36 sum xi eta - key| <= 2^8 (sum|xi| + max_m sum|eta_m| + 41) + |key| 2^-(22 - idxbits)     
+//     If the third key is farther from the first than twice that (x1.27), the true argmin is one of the first two:
+//     both are evaluated with the canonical FP64 chain (on the FP64 matrix pipe, as the diagonal of a 16x16 tile of
+//     gathered codewords -- the same instruction sequence as the full sweep, so bit-identical values) and compared
+//     exactly (ties: lower index).  Otherwise -- or if the smallest key is not a positive normal number -- the frame
+//     goes to a list that k_pass_mfma<SRC = 2> sweeps in full FP64 right after.  Nothing is ever decided by d~.
+//
+// NC = 37 (P = 36, the reference's default) only: the K-slot packing below is specific to 37 = 32 + 5.
+#include "vq_accum.h"
+#include "vq_device.h"
+#include "vq_fixed.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+namespace e2vq {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int PRE_NSTEP = 15;     // MFMA k-steps of 16: 3 (W0) + 5 (W1) + 7 (W2)
+constexpr int PRE_TILE_E = 1024;  // h8 granules per 32-codeword tile image (15 KB used, padded to 16 KB)
+constexpr int PRE_PAIRS = 7;      // frame granule pairs per 32-frame block: 14 granules of 8 halves = 224 B/frame
+
+__host__ __device__ constexpr int pre_step_level(int s) { return s < 3 ? 0 : (s < 8 ? 1 : 2); }
+// frame granule pair used by k-step s:  W0: p0 p1 p6 | W1: p0 p1 p2 p3 p6 | W2: p0 .. p6
+__host__ __device__ constexpr int pre_step_pair(int s)
+{
+    return s < 3 ? (s == 2 ? 6 : s) : (s < 8 ? (s == 7 ? 6 : s - 3) : (s - 8));
+}
+// element e of the granule (pair p, lane half h) of a frame: limb index fl (0..2) and coefficient n, or n = -1 (zero)
+//   p < 6 : limb p/2, coefficients 16 (p&1) + 8 h + e              (n < 32)
+//   p = 6 : h = 0: [X1[32..36], X2[32..34]]   h = 1: [X2[35..36], X3[32..36], 0]
+__host__ __device__ __forceinline__ void pre_slot(int p, int h, int e, int& fl, int& n)
+{
+    if (p < 6) {
+        fl = p >> 1;
+        n = 16 * (p & 1) + 8 * h + e;
+    } else if (h == 0) {
+        fl = e < 5 ? 0 : 1;
+        n = e < 5 ? 32 + e : 27 + e;
+    } else {
+        fl = e < 2 ? 1 : 2;
+        n = e < 2 ? 35 + e : (e < 7 ? 30 + e : -1);
+    }
+}
+
+// x in [-1, 1] -> limbs; returns the three integers
+__device__ __forceinline__ void pre_split(double x, int& L1, int& L2, int& L3)
+{
+    const double s1 = x * 512.0, l1 = __builtin_rint(s1);
+    const double s2 = (s1 - l1) * 512.0, l2 = __builtin_rint(s2);
+    const double s3 = (s2 - l2) * 512.0, l3 = __builtin_rint(s3);
+    L1 = (int)l1;
+    L2 = (int)l2;
+    L3 = (int)l3;
+}
+
+// ---- data statistic: per-coefficient max |r[n]| over the blocked training set -----------------------------
+__global__ void k_pre_colmax(const double* __restrict__ blk, long nblocks, int NC, u64* __restrict__ colmax_bits)
+{
+    __shared__ u64 smax[E2VQ_MAX_P + 1];
+    for (int i = threadIdx.x; i < NC; i += blockDim.x) smax[i] = 0;
+    __syncthreads();
+    const int NS = (NC + 3) >> 2;
+    const long total = nblocks * (long)NC * 64;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(o % ((long)NC * 64));
+        const int x = w % (NC * 32);
+        const int n = x < (NS - 1) * 128 ? 4 * (x >> 7) + ((x & 127) >> 5) : 4 * (NS - 1) + ((x - (NS - 1) * 128) >> 5);
+        const u64 bits = (u64)__double_as_longlong(fabs(blk[o]));
+        if (bits > smax[n]) atomicMax(&smax[n], bits);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NC; i += blockDim.x)
+        if (smax[i]) atomicMax(&colmax_bits[i], smax[i]);
+}
+
+// a_n = 2^ea[n] > max |r[n]|   (ea = 0 for an all-zero coefficient)
+__global__ void k_pre_exponents(const u64* __restrict__ colmax_bits, int NC, int* __restrict__ ea)
+{
+    const int n = threadIdx.x;
+    if (n < NC) {
+        const double m = __longlong_as_double((i64)colmax_bits[n]);
+        ea[n] = m > 0.0 ? ilogb(m) + 1 : 0;
+    }
+}
+
+// ---- frame image: [blk32][pair][h*32 + col][8 halves], fg[t] = sum_n |xi_n| (rounded up) -----------------
+__global__ __launch_bounds__(64) void k_pre_frames(const double* __restrict__ blk, long T, long nblk32, int NC,
+                                                   const int* __restrict__ ea, h8* __restrict__ fimg,
+                                                   float* __restrict__ fg)
+{
+    __shared__ short X[3][32][40];
+    const int col = threadIdx.x & 31, hh = threadIdx.x >> 5;
+    for (long b = blockIdx.x; b < nblk32; b += gridDim.x) {
+        const long t = b * 32 + col;
+        // frame scale: A_t = 2^eA > max_n |r[n]| 2^-ea[n]  (both halves of the workgroup compute it; cheap)
+        int eA = -100000;
+        if (t < T)
+            for (int n = 0; n < NC; ++n) {
+                const double v = blk[mfma_blk_offset(NC, t, n)];
+                if (v != 0.0) {
+                    const int e = ilogb(v) - ea[n] + 1;
+                    eA = e > eA ? e : eA;
+                }
+            }
+        if (eA == -100000) eA = 0;
+        double g = 0.0;
+        for (int n = hh; n < 40; n += 2) {
+            int l1 = 0, l2 = 0, l3 = 0;
+            if (n < NC && t < T) {
+                const double xi = ldexp(blk[mfma_blk_offset(NC, t, n)], -ea[n] - eA);
+                g += fabs(xi);
+                pre_split(xi, l1, l2, l3);
+            }
+            X[0][col][n] = (short)l1;
+            X[1][col][n] = (short)l2;
+            X[2][col][n] = (short)l3;
+        }
+        g += __shfl_xor(g, 32, 64);
+        if (hh == 0 && t < T) fg[t] = (float)g * 1.000001f;
+        __syncthreads();
+        for (int p = 0; p < PRE_PAIRS; ++p) {
+            h8 out;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int fl, n;
+                pre_slot(p, hh, e, fl, n);
+                out[e] = n >= 0 ? (_Float16)(int)X[fl][col][n] : (_Float16)0;
+            }
+            fimg[(b * PRE_PAIRS + p) * 64 + threadIdx.x] = out;
+        }
+        __syncthreads();
+    }
+}
+
+// per-pass scalars, zeroed by one memset before the codebook image is built
+struct PreScalars {
+    int eC_biased;  // codebook scale C = 2^eC > max |c[m][n]| a_n, stored as eC + PRE_EBIAS (0 = empty)
+    int ymax_bits;  // max_m sum_n |eta[m][n]| as float bits (positive -> ordered like ints)
+    int fb_count;   // frames handed to the fallback sweep
+};
+constexpr int PRE_EBIAS = 1 << 20;
+
+// ---- codebook scale: eC = max ilogb(c a) + 1 over the codebook -------------------------------------------
+__global__ void k_pre_cmax(const double* __restrict__ cbq, int M, int NC, int NPAD, const int* __restrict__ ea,
+                           PreScalars* __restrict__ ps)
+{
+    __shared__ int smax;
+    if (threadIdx.x == 0) smax = 0;
+    __syncthreads();
+    int mx = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M * NC; i += gridDim.x * blockDim.x) {
+        const int m = i / NC, n = i - m * NC;
+        const double c = cbq[(long)m * NPAD + n];
+        if (c != 0.0) {
+            const int e = ilogb(c) + ea[n] + 1 + PRE_EBIAS;
+            mx = e > mx ? e : mx;
+        }
+    }
+    if (mx) atomicMax(&smax, mx);
+    __syncthreads();
+    if (threadIdx.x == 0 && smax) atomicMax(&ps->eC_biased, smax);
+}
+
+// ---- codebook image: [tile][step][h*32 + row][8 halves] (+ 64 zero granules of padding per tile) ---------
+__global__ __launch_bounds__(256) void k_pre_codebook(const double* __restrict__ cbq, int M, int NC, int NPAD,
+                                                      const int* __restrict__ ea, PreScalars* __restrict__ ps,
+                                                      h8* __restrict__ cimg)
+{
+    __shared__ short Y[3][32][40];
+    const int tile = blockIdx.x;
+    const int eC = ps->eC_biased ? ps->eC_biased - PRE_EBIAS : 0;
+    for (int i = threadIdx.x; i < 32 * 40; i += 256) {
+        const int row = i / 40, n = i - row * 40;
+        const int m = tile * 32 + row;
+        int l1 = 0, l2 = 0, l3 = 0;
+        if (n < NC && m < M) pre_split(ldexp(cbq[(long)m * NPAD + n], ea[n] - eC), l1, l2, l3);
+        Y[0][row][n] = (short)l1;
+        Y[1][row][n] = (short)l2;
+        Y[2][row][n] = (short)l3;
+    }
+    if (threadIdx.x < 32) {  // sum_n |eta| of this tile's codewords -> global max (float bits, rounded up)
+        const int m = tile * 32 + threadIdx.x;
+        double g = 0.0;
+        if (m < M)
+            for (int n = 0; n < NC; ++n) g += fabs(ldexp(cbq[(long)m * NPAD + n], ea[n] - eC));
+        atomicMax(&ps->ymax_bits, __float_as_int((float)g * 1.000001f));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PRE_TILE_E; i += 256) {
+        h8 out = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int s = i >> 6, l = i & 63, hh = l >> 5, row = l & 31;
+        if (s < PRE_NSTEP) {
+            const int lv = pre_step_level(s), pr = pre_step_pair(s);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int fl, n;
+                pre_slot(pr, hh, e, fl, n);
+                const int cl = lv - fl;  // codeword limb that meets frame limb fl at this weight
+                if (n >= 0 && cl >= 0 && cl <= 2) out[e] = (_Float16)(int)Y[cl][row][n];
+            }
+        }
+        cimg[(long)tile * PRE_TILE_E + i] = out;
+    }
+}
+
+// ---- the pass ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float med3f(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
+// canonical FP64 chain of frame j of tile ft against codeword `cand` (per lane: the candidate of frame lane&15),
+// evaluated as the diagonal of one 16x16 MFMA tile: the instruction sequence of k_pass_mfma, hence its values.
+// The codeword row comes from the row-major cbq: the four q lanes of a frame read adjacent 8 bytes, so a gather
+// instruction touches 16 rows; the rows are L2-resident (303 KB at M = 1024).
+template <int NC>
+struct PreCand {
+    double a[(NC + 3) / 4];
+    double tail;
+};
+template <int NC>
+__device__ __forceinline__ PreCand<NC> pre_gather(int cand, const double* __restrict__ cbq, int q)
+{
+    constexpr int NS = (NC + 3) / 4, REM = NC - 4 * (NS - 1), NPAD = (NC + 7) & ~7;
+    constexpr int NSM = REM == 1 ? NS - 1 : NS;
+    PreCand<NC> c;
+    const double* row = cbq + (long)cand * NPAD;
+#pragma unroll
+    for (int st = 0; st < NSM; ++st) c.a[st] = row[4 * st + q];
+    c.tail = REM == 1 ? row[NC - 1] : 0.0;
+    return c;
+}
+template <int NC>
+__device__ __forceinline__ double pre_exact(const double (&Bft)[2 * ((((NC + 3) / 4) + 1) / 2)], const PreCand<NC>& c, int j)
+{
+    constexpr int NS = (NC + 3) / 4, REM = NC - 4 * (NS - 1);
+    constexpr bool TAILV = REM == 1;
+    constexpr int NSM = TAILV ? NS - 1 : NS;
+    d4 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a[0], Bft[0], (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+#pragma unroll
+    for (int st = 1; st < NSM; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a[st], Bft[st], acc, 0, 0, 0);
+    const int rg = j >> 2;
+    double v = rg == 0 ? acc[0] : rg == 1 ? acc[1] : rg == 2 ? acc[2] : acc[3];  // D[row 4 rg + q][col j], row = j
+    if (TAILV) v = __builtin_fma(Bft[NS - 1], c.tail, v);
+    return __shfl(v, 16 * (j & 3) + j, 64);  // the lane with q = j & 3 holds the diagonal element of frame j
+}
+
+// WPB waves per workgroup share the codeword tiles through an NSLOT-deep LDS ring.  WPB = 4, NSLOT = 3 lets two
+// workgroups live on a CU (2 x (48 KB ring + 21 KB row images)): they drift apart, so one sweeps (matrix pipe) while
+// the other verifies and accumulates (memory pipe) -- eight lock-stepped waves would all leave the matrix pipe idle
+// at the same time.
+template <int NC, int MODE, int WPB, int NSLOT>
+__global__ __launch_bounds__(64 * WPB, 2) void k_pass_pre(const double* __restrict__ blk, long T, long nblocks,
+                                                  const h8* __restrict__ fimg, const float* __restrict__ fg,
+                                                  const h8* __restrict__ cimg, PreScalars* __restrict__ ps,
+                                                  const double* __restrict__ cbq, int MT, int idxmask,
+                                                  const DevScalars* __restrict__ sc, const u64* __restrict__ l1max_bits,
+                                                  unsigned short* __restrict__ sym, double* __restrict__ dmin,
+                                                  i64* __restrict__ rows, int* __restrict__ fb_list, int stagger)
+{
+    static_assert(NC == 37, "the K-slot packing of the prefilter is laid out for P = 36");
+    constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2, REM = NC - 4 * (NS - 1);
+    constexpr bool TAILV = REM == 1;
+    constexpr int NE = 2 * NC + 5, IMG = NE + IMG_STRIDE_PAD;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TPB = 64 * WPB;
+    static_assert(NSLOT >= 3 && PRE_TILE_E % TPB == 0, "ring depth / copy split");
+    h8* lds = (h8*)smem;                                     // [NSLOT][PRE_TILE_E]
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int q = lane >> 4, j = lane & 15;
+    int* img = (int*)(smem + (size_t)NSLOT * PRE_TILE_E * 16) + wib * (16 * IMG);
+
+    int sh_r = 0, sh_d = 0, sh_d2 = 0;
+    if constexpr (MODE != 0) {
+        sh_r = sc->sh_r;
+        const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
+        sh_d = 30 - Ed;
+        sh_d2 = 30 - 2 * Ed;
+    }
+    int maskv = idxmask;
+    asm volatile("" : "+v"(maskv));
+    float ninf = -__builtin_inff();
+    asm volatile("" : "+v"(ninf));
+    const float ymax1 = __int_as_float(ps->ymax_bits);
+    const float relk = 2.0f / (float)(1u << (22 - __builtin_popcount(~idxmask)));  // 2 rho, rho = 2^-(22-idxbits)
+
+    // Two workgroups share a CU (the second half of the grid lands on the CUs of the first).  Started together they
+    // stay in lockstep -- both sweeping, then both in the memory-bound verify/accumulate phase with the matrix pipe
+    // idle.  Delaying the second half by about half a block period makes the phases alternate.
+    if (stagger && blockIdx.x >= gridDim.x / 2 && nblocks > (long)WPB * gridDim.x)
+        for (int i = 0; i < stagger * MT / 8; ++i) __builtin_amdgcn_s_sleep(127);  // ~8k cycles each; a tile pair ~2k
+
+    for (long sb = blockIdx.x; sb * WPB < nblocks; sb += gridDim.x) {
+        const long b = sb * WPB + wib;
+        const bool active = b < nblocks;
+
+        // ---- f16 limb images of the wave's 64 frames: B operands, resident for the sweep ----------
+        h8 B[2][PRE_PAIRS];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int p = 0; p < PRE_PAIRS; ++p) {
+                const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                B[cb][p] = active ? fimg[((b * 2 + cb) * PRE_PAIRS + p) * 64 + lane] : z;
+            }
+        float k1[2], k2[2], k3[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) k1[cb] = k2[cb] = k3[cb] = __int_as_float(0x7f7fffff);
+
+        // ---- sweep: codeword tiles stream through a 4-slot LDS ring, one workgroup barrier per tile ----
+        constexpr int PER_T = PRE_TILE_E / TPB;
+        h8 pre[PER_T];
+        auto gload = [&](int t) {
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) pre[i] = cimg[(long)t * PRE_TILE_E + i * TPB + threadIdx.x];
+        };
+        auto lstore = [&](int slot) {
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) lds[slot * PRE_TILE_E + i * TPB + threadIdx.x] = pre[i];
+        };
+        gload(0);
+        lstore(0);
+        gload(MT > 1 ? 1 : 0);
+        lstore(1);
+        __syncthreads();
+
+        f16v acc0[3], acc1[3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[l][r] = l == 2 ? 3.0e38f : 0.f;
+
+        // one job = the 15 MFMAs of (tile, column block) interleaved with the key epilogue of the previous job:
+        // 1 MFMA (32 cycles, 8 of them blocking issue) : 6 VALU ops, pinned by sched_group_barrier
+#define E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
+    {                                                                                                             \
+        const int sidx = __builtin_amdgcn_readfirstlane((PTILE) * 32 + 8 * (r >> 2) + (r & 3));                   \
+        const float v = __builtin_fmaf(PREV[0][r], 262144.f, __builtin_fmaf(PREV[1][r], 512.f, PREV[2][r]));     \
+        const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);                                     \
+        k3[PCB] = med3f(k2[PCB], k3[PCB], key);                                                                   \
+        k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                                   \
+        k1[PCB] = med3f(k1[PCB], key, ninf);                                                                      \
+    }
+#define E2VQ_PRE_JOB(ACC, BC, PREV, PTILE, PCB)                                                                   \
+    {                                                                                                             \
+        const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
+        _Pragma("unroll") for (int s = 0; s < PRE_NSTEP; ++s)                                                     \
+        {                                                                                                         \
+            const int lv = pre_step_level(s), pr = pre_step_pair(s);                                              \
+            const bool first = s == 0 || s == 3 || s == 8;                                                        \
+            ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
+        }                                                                                                         \
+        E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
+        _Pragma("unroll") for (int s = 0; s < PRE_NSTEP; ++s)                                                     \
+        {                                                                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                    \
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                                    \
+        }                                                                                                         \
+    }
+        for (int t = 0; t < MT; ++t) {
+            gload(t + 2 < MT ? t + 2 : MT - 1);
+            const h8* cur = lds + (t % NSLOT) * PRE_TILE_E;
+            h8 A[PRE_NSTEP];
+#pragma unroll
+            for (int s = 0; s < PRE_NSTEP; ++s) A[s] = cur[s * 64 + lane];
+            E2VQ_PRE_JOB(acc0, B[0], acc1, (t - 1) & 0xffff, 1)  // (t = 0: the "previous" accumulators hold 3e38)
+            E2VQ_PRE_JOB(acc1, B[1], acc0, t, 0)
+            lstore((t + 2) % NSLOT);
+            __syncthreads();
+        }
+        E2VQ_PRE_EPILOGUE(acc1, MT - 1, 1)
+#undef E2VQ_PRE_JOB
+#undef E2VQ_PRE_EPILOGUE
+        if (!active) continue;
+
+        // ---- per frame: merge the two lane halves (rows 4h..4h+3 of every 8), certify the top two -------------
+        int c1[2], c2[2];
+        bool cert[2], amb[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int hb = (lane >> 5) << 2;
+            const float a1 = __int_as_float(__float_as_int(k1[cb]) | hb), a2 = __int_as_float(__float_as_int(k2[cb]) | hb),
+                        a3 = __int_as_float(__float_as_int(k3[cb]) | hb);
+            const float b1 = __shfl_xor(a1, 32, 64), b2 = __shfl_xor(a2, 32, 64), b3 = __shfl_xor(a3, 32, 64);
+            const float t3 = med3f(a2, a3, b1), t2 = med3f(a1, a2, b1), t1 = med3f(a1, b1, ninf);
+            const float u3 = med3f(t2, t3, b2), u2 = med3f(t1, t2, b2);
+            const float w3 = med3f(u2, u3, b3);
+            // t1 <= u2 <= w3: the three smallest keys of frame 32 cb + (lane & 31)
+            const long t = b * 64 + 32 * cb + (lane & 31);
+            const float g = t < T ? fg[t] : 0.f;
+            const float tau = 1.27f * (512.f * (g + ymax1 + 41.f) + relk * t1);
+            cert[cb] = t1 >= 1.0e-30f && t1 < 1.0e37f && w3 > t1 + tau;
+            amb[cb] = !(u2 > t1 + tau);  // the runner-up is within reach: it needs the exact evaluation too
+            c1[cb] = __float_as_int(t1) & ~idxmask;
+            c2[cb] = __float_as_int(u2) & ~idxmask;
+        }
+
+        // ---- FP64 frames (MFMA operand layout of k_pass_mfma), exact evaluation of the two candidates -----------
+        double Bf[4][2 * NP];
+        const double* fb = blk + b * (long)(NC * 64);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const double* base = fb + u * (NC * 32);
+#pragma unroll
+            for (int st = 0; st < NS - 1; ++st) {
+                const double2 v = *(const double2*)(base + (st * 64 + lane) * 2);
+                Bf[2 * u][st] = v.x;
+                Bf[2 * u + 1][st] = v.y;
+            }
+            double2 v = make_double2(0.0, 0.0);
+            if (TAILV)
+                v = *(const double2*)(base + (NS - 1) * 128 + j * 2);
+            else if (q < REM)
+                v = *(const double2*)(base + (NS - 1) * 128 + (q * 16 + j) * 2);
+            Bf[2 * u][NS - 1] = v.x;
+            Bf[2 * u + 1][NS - 1] = v.y;
+        }
+        double best[4];
+        int idx[4];
+        bool skip[4];
+        {
+            int ca[4], cbx[4];
+            bool two[4];
+            PreCand<NC> g[4];
+            // the four gathers of a round are issued together: two exposed L2 latencies per block instead of eight
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const int src = 16 * (ft & 1) + j;  // a lane of half 0 that holds frame 16 ft + j of column block ft / 2
+                ca[ft] = __shfl(c1[ft >> 1], src, 64);
+                cbx[ft] = __shfl(c2[ft >> 1], src, 64);
+                skip[ft] = __shfl((int)cert[ft >> 1], src, 64) == 0;
+                two[ft] = __ballot(__shfl((int)amb[ft >> 1], src, 64) != 0) != 0;  // wave-uniform
+                g[ft] = pre_gather<NC>(ca[ft], cbq, q);
+            }
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+#ifdef E2VQ_PRE_ABLATE_VERIFY  // diagnostics only (tools/probe): wrong results, shows what the exact evaluation costs
+                best[ft] = Bf[ft][0] + g[ft].a[0];
+#else
+                best[ft] = pre_exact<NC>(Bf[ft], g[ft], j);
+#endif
+                idx[ft] = ca[ft];
+            }
+#ifndef E2VQ_PRE_ABLATE_VERIFY
+            if (two[0] || two[1] || two[2] || two[3]) {
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+                    if (two[ft]) g[ft] = pre_gather<NC>(cbx[ft], cbq, q);
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+                    if (two[ft]) {
+                        const double db = pre_exact<NC>(Bf[ft], g[ft], j);
+                        const bool take_b = db < best[ft] || (db == best[ft] && cbx[ft] < ca[ft]);
+                        best[ft] = take_b ? db : best[ft];
+                        idx[ft] = take_b ? cbx[ft] : ca[ft];
+                    }
+            }
+#endif
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) idx[ft] = skip[ft] ? 0 : idx[ft];
+        }
+
+        // ---- outputs: lane 16q + j owns frame b*64 + lane; uncertified frames go to the fallback list ---------
+        {
+            const double bs = q == 0 ? best[0] : q == 1 ? best[1] : q == 2 ? best[2] : best[3];
+            const int is = q == 0 ? idx[0] : q == 1 ? idx[1] : q == 2 ? idx[2] : idx[3];
+            const bool sk = q == 0 ? skip[0] : q == 1 ? skip[1] : q == 2 ? skip[2] : skip[3];
+            const long t = b * 64 + lane;
+            if (t < T) {
+                if (sk) {
+                    fb_list[atomicAdd(&ps->fb_count, 1)] = (int)t;
+                } else {
+                    if (sym) sym[t] = (unsigned short)is;
+                    if (dmin) dmin[t] = bs;
+                }
+            }
+        }
+        if constexpr (MODE != 0)
+            // (no LDS table here: lds_cells = 0; a null table pointer crashes the ROCm 7.2 optimizer, so pass the LDS base)
+            accumulate_block<NC, MODE, true>(Bf, best, idx, img, (i64*)smem, rows, 0, sh_r, sh_d, sh_d2, b, T, lane, skip);
+    }
+}
+
+// ---- launch wrappers ---------------------------------------------------------------------------------------
+static inline int pre_grid(long items, int per_block, int cap)
+{
+    long g = (items + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+bool prefilter_supports(int NC, int M) { return NC == 37 && M >= 64 && M % 32 == 0 && M <= 32768; }
+size_t prefilter_frame_image_bytes(long nblocks64) { return (size_t)nblocks64 * 2 * PRE_PAIRS * 64 * 16; }
+size_t prefilter_codebook_image_bytes(int M) { return (size_t)((M + 31) / 32) * PRE_TILE_E * 16; }
+size_t prefilter_scalars_bytes() { return sizeof(PreScalars); }
+
+void launch_prefilter_frames(const double* blk, long T, long nblocks64, int NC, unsigned long long* colmax_bits, int* ea,
+                             void* fimg, float* fg, hipStream_t s)
+{
+    (void)hipMemsetAsync(colmax_bits, 0, (size_t)NC * 8, s);
+    hipLaunchKernelGGL(k_pre_colmax, dim3(pre_grid(nblocks64 * NC * 64, 256 * 8, 2048)), dim3(256), 0, s, blk, nblocks64,
+                       NC, (u64*)colmax_bits);
+    hipLaunchKernelGGL(k_pre_exponents, dim3(1), dim3(256), 0, s, (const u64*)colmax_bits, NC, ea);
+    hipLaunchKernelGGL(k_pre_frames, dim3(pre_grid(nblocks64 * 2, 1, 16384)), dim3(64), 0, s, blk, T, nblocks64 * 2, NC,
+                       (const int*)ea, (h8*)fimg, fg);
+}
+
+const int* prefilter_fallback_count(const void* ps) { return &((const PreScalars*)ps)->fb_count; }
+
+// zeroes the per-pass scalars (fallback count included) and builds the limb image of the current codebook
+void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, void* ps, void* cimg, hipStream_t s)
+{
+    const int NPAD = (NC + 7) & ~7;
+    (void)hipMemsetAsync(ps, 0, sizeof(PreScalars), s);
+    hipLaunchKernelGGL(k_pre_cmax, dim3(pre_grid((long)M * NC, 1024, 32)), dim3(256), 0, s, cbq, M, NC, NPAD, ea,
+                       (PreScalars*)ps);
+    hipLaunchKernelGGL(k_pre_codebook, dim3((M + 31) / 32), dim3(256), 0, s, cbq, M, NC, NPAD, ea, (PreScalars*)ps,
+                       (h8*)cimg);
+}
+
+// accumulate = false: assignment only.  Runs after launch_prefilter_codebook of the same pass; afterwards
+// *prefilter_fallback_count(ps) frames wait in fb_list for launch_pass_fallback.
+int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, long nblocks, const void* fimg,
+                            const float* fg, const void* cimg, void* ps, const double* cbq, int M,
+                            const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
+                            long long* rows, int* fb_list, hipStream_t s)
+{
+    if (!prefilter_supports(NC, M)) return 1;
+    constexpr int IMG = 2 * 37 + 5 + IMG_STRIDE_PAD;
+    constexpr int WPB = 4, NSLOT = 3;
+    const size_t lds = (size_t)NSLOT * PRE_TILE_E * 16 + (size_t)WPB * 16 * IMG * 4;
+    int bits = 0;
+    while ((1 << bits) < M) ++bits;
+    const int idxmask = ~((1 << bits) - 1);
+    const int grid = pre_grid(nblocks, WPB, 512);  // two persistent 4-wave workgroups per CU
+    static const int stagger = getenv("ECOZ2_VQ_PRE_STAGGER") ? atoi(getenv("ECOZ2_VQ_PRE_STAGGER")) : 1;
+    if (accumulate) {
+        (void)hipFuncSetAttribute((const void*)k_pass_pre<37, 2, WPB, NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  E2VQ_LDS_BYTES);
+        hipLaunchKernelGGL((k_pass_pre<37, 2, WPB, NSLOT>), dim3(grid), dim3(64 * WPB), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
+                           (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
+                           dmin, rows, fb_list, stagger);
+    } else {
+        (void)hipFuncSetAttribute((const void*)k_pass_pre<37, 0, WPB, NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  E2VQ_LDS_BYTES);
+        hipLaunchKernelGGL((k_pass_pre<37, 0, WPB, NSLOT>), dim3(grid), dim3(64 * WPB), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
+                           (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
+                           dmin, rows, fb_list, stagger);
+    }
+    return 0;
+}
+
+}  // namespace e2vq

@@ -194,6 +194,12 @@ class VqSession:
         check(lib.e2vq_last_pass_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def last_pass_info(self):
+        """(prefiltered sweep used?, frames it left to the full FP64 sweep) of the last run_pass."""
+        used, n = C.c_int(), C.c_int64()
+        check(lib.e2vq_last_pass_info(self._h, C.byref(used), C.byref(n)))
+        return bool(used.value), n.value
+
     def get_rows(self):
         rs = lib.e2vq_row_stride(self.P)
         out = np.empty((self.codebook_size(), rs), dtype=np.int64)

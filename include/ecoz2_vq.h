@@ -80,6 +80,8 @@ int ecoz2_vq_classify(const char *const *cb_filenames, int num_codebooks,
  *   ECOZ2_VQ_MAX_CODEBOOK_SIZE  last codebook size trained (default 2048, notes.md:147)
  *   ECOZ2_VQ_DEVICE             HIP device ordinal (default 0)
  *   ECOZ2_VQ_GPUS               vq learn only: shard over this many in-process ranks / GPUs (default 1)
+ *   ECOZ2_VQ_PREFILTER          0 = every pass on the FP64 sweep (default 1: prefiltered sweep for P = 36, M >= 256)
+ *   ECOZ2_VQ_PREFILTER_MIN_M    smallest codebook the prefiltered sweep serves (default 256, at least 64)
  *   ECOZ2_VQ_OUT_ROOT           prefix for data/... outputs (default ".")               */
 
 /* ========================================================================================
@@ -132,6 +134,9 @@ int e2vq_pass_stats(e2vq_session *s, e2vq_level_stats *out);
 /* HIP events around the sweep kernel of e2vq_pass, on the session's stream */
 int e2vq_enable_timing(e2vq_session *s, int on);
 int e2vq_last_pass_kernel_ms(e2vq_session *s, float *ms);
+/* which sweep served the last e2vq_pass: *prefiltered = 1 when the f16-prefiltered sweep ran (P = 36, large M),
+ * *fallback_frames = frames it handed to the full FP64 sweep (synchronises the stream) */
+int e2vq_last_pass_info(e2vq_session *s, int *prefiltered, int64_t *fallback_frames);
 int e2vq_update(e2vq_session *s);
 /* the reduced accumulator rows of the last pass (M x row_stride int64) copied to the host */
 int e2vq_row_stride(int prediction_order);

@@ -1,0 +1,169 @@
+"""GPU parity of the prefiltered sweep (f16 limb prefilter + exact FP64 evaluation + fallback list).
+
+Every case runs one LBG pass through the C-ABI with the prefilter forced on (from M = 64) and compares symbols,
+minimum distortions and the per-cell integer rows bit for bit with the CPU oracle; the adversarial cases are built
+to defeat a prefilter that decides anything by itself (ties, twins, zero / negative / badly scaled data)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ecoz2rs_amd as e
+
+pytestmark = pytest.mark.gpu
+
+P = 36
+
+
+def _frames(seed, T, classes=8):
+    return e.synth.synth_frames(seed, classes, P, 0, T)
+
+
+def _codebook(oracle, frames, M, seed=0):
+    rng = np.random.default_rng(seed)
+    idx = rng.choice(frames.shape[0], size=M, replace=frames.shape[0] < M)
+    refl = np.zeros((M, P + 1))
+    for i, t in enumerate(idx):
+        st, _pe, rc, _a = oracle.lpca_r(frames[t], P)
+        assert st == 0
+        refl[i, 1:] = rc[1:]
+    return refl
+
+
+def _oracle_pass(oracle, frames, refl):
+    cq = oracle.reflections_to_cq(refl)
+    rc, st = oracle.data_stats(frames)
+    assert rc == 0
+    sh_r, _ = oracle.shifts(st.maxabs)
+    Ed = oracle.dist_exponent(cq, st.maxabs)
+    return oracle.run_pass(cq, frames, sh_r, Ed)
+
+
+class _DeviceBuffer:
+    """Device memory through the HIP runtime libecoz2vq.so itself is linked to: dlsym on the library's handle
+    searches its dependencies, so no second copy of the runtime (torch bundles one) can get involved."""
+
+    def __init__(self, nbytes):
+        self.hip = e.lib
+        self.nbytes = nbytes
+        self.ptr = C.c_void_p()
+        assert self.hip.hipSetDevice(0) == 0  # (this thread may never have touched the runtime)
+        assert self.hip.hipMalloc(C.byref(self.ptr), C.c_size_t(nbytes)) == 0
+        assert self.hip.hipMemset(self.ptr, 0xFF, C.c_size_t(nbytes)) == 0
+
+    def to_host(self, dtype):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        assert self.hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), self.ptr, C.c_size_t(self.nbytes), 2) == 0  # D2H
+        return out
+
+    def free(self):
+        self.hip.hipFree(self.ptr)
+
+
+def _gpu_pass(frames, refl, monkeypatch, prefilter=True):
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER", "1" if prefilter else "0")
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
+    T = frames.shape[0]
+    sym, dmin = _DeviceBuffer(2 * T), _DeviceBuffer(8 * T)
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.set_codebook(refl)
+        s.run_pass(sym.ptr.value, dmin.ptr.value)
+        rows = s.get_rows()
+        used, nfb = s.last_pass_info()
+        s.synchronize()
+    assert used == prefilter
+    _gpu_pass.fallback = nfb
+    out = sym.to_host(np.uint16), dmin.to_host(np.float64), rows
+    sym.free()
+    dmin.free()
+    return out
+
+
+def _check(oracle, frames, refl, monkeypatch):
+    sym_o, dmin_o, rows_o = _oracle_pass(oracle, frames, refl)
+    sym, dmin, rows = _gpu_pass(frames, refl, monkeypatch)
+    assert np.array_equal(sym, sym_o)
+    assert np.array_equal(dmin.view(np.uint64), dmin_o.view(np.uint64))
+    assert np.array_equal(rows, rows_o)
+
+
+@pytest.mark.parametrize("T,M", [(5000, 64), (7777, 256), (20000, 1024), (9001, 2048), (6000, 4096)])
+def test_prefiltered_pass_bit_exact(oracle, monkeypatch, T, M):
+    frames = _frames(20250, T)
+    _check(oracle, frames, _codebook(oracle, frames, M, seed=3), monkeypatch)
+    print(f"T={T} M={M}: {_gpu_pass.fallback} frames to the FP64 fallback")
+    assert _gpu_pass.fallback < 0.1 * T  # the prefilter certifies nearly every frame of ordinary data
+
+
+def test_prefilter_off_gives_the_same_rows(oracle, monkeypatch):
+    frames = _frames(20251, 6000)
+    refl = _codebook(oracle, frames, 512, seed=4)
+    a = _gpu_pass(frames, refl, monkeypatch, prefilter=True)
+    b = _gpu_pass(frames, refl, monkeypatch, prefilter=False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+
+
+def test_twin_and_duplicate_codewords(oracle, monkeypatch):
+    """Every codeword appears twice (exact ties: the lower index must win) next to 1 % twins of the LBG split."""
+    frames = _frames(20252, 4000)
+    base = _codebook(oracle, frames, 64, seed=5)
+    refl = np.concatenate([base, base, oracle.grow(base)], axis=0)  # 256 codewords, pairs (i, i + 64) identical
+    sym_o, _d, _r = _oracle_pass(oracle, frames, refl)
+    assert (sym_o < 64).sum() > 0 and not ((sym_o >= 64) & (sym_o < 128)).any()
+    _check(oracle, frames, refl, monkeypatch)
+    assert _gpu_pass.fallback > 0  # exact ties between three codewords cannot be certified from two candidates
+
+
+def test_codebook_made_of_the_frames(oracle, monkeypatch):
+    """Many near-ties: the codebook is the LPC of the first 256 frames, and the frames repeat."""
+    frames = _frames(20253, 256)
+    frames = np.concatenate([frames] * 9 + [frames[:77]], axis=0)
+    _check(oracle, frames, _codebook(oracle, frames[:256], 256, seed=6), monkeypatch)
+
+
+def test_badly_scaled_zero_and_negative_frames(oracle, monkeypatch):
+    """Frames spanning 40 orders of magnitude, all-zero frames, sign-flipped frames (negative distortions) and
+    coefficients that are zero in every frame: the prefilter must hand what it cannot certify to the FP64 sweep."""
+    frames = _frames(20254, 3000)
+    rng = np.random.default_rng(7)
+    refl = _codebook(oracle, frames, 128, seed=7)
+    frames = frames.copy()
+    frames[::7] *= 10.0 ** rng.integers(-20, 20, size=frames[::7].shape[0])[:, None]
+    frames[5::11] = 0.0
+    frames[3::13] *= -1.0
+    frames[:, 30] = 0.0
+    frames[100:200, 1:] = rng.standard_normal((100, P)) * frames[100:200, :1]
+    _check(oracle, frames, refl, monkeypatch)
+
+
+def test_identical_frames_and_constant_codebook(oracle, monkeypatch):
+    """One frame repeated against a codebook whose codewords differ in the last reflection coefficient only."""
+    one = _frames(20255, 1)
+    frames = np.repeat(one, 1000, axis=0)
+    st, _pe, rc, _a = oracle.lpca_r(one[0], P)
+    assert st == 0
+    refl = np.zeros((64, P + 1))
+    refl[:, 1:] = rc[1:]
+    refl[:, P] += np.linspace(-1e-9, 1e-9, 64)
+    _check(oracle, frames, refl, monkeypatch)
+
+
+def test_learn_ladder_with_prefilter_matches_oracle(oracle, monkeypatch):
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER", "1")
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
+    frames = _frames(20256, 20000, classes=6)
+    rc, levels_o, cbs_o = oracle.learn(frames, 0.05, 512)
+    assert rc == 0
+    cbs = []
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        levels = s.learn(0.05, 512, callback=lambda M, a, sg, i: cbs.append((M, a, sg, i)))
+        refl = s.get_codebook()
+    assert [(l.M, l.passes) for l in levels] == [(l["M"], l["passes"]) for l in levels_o]
+    assert cbs == cbs_o
+    assert np.array_equal(refl.view(np.uint64), levels_o[-1]["reflections"].view(np.uint64))
