@@ -27,6 +27,8 @@ SEED = 20244  # 20240 + config# 
 N_CLASSES = 20
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 peak (vector == matrix on CDNA4), AMD spec
+F16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense BF16/F16 MFMA peak ~2.5 PF (the prefilter's limb products)
+F16_MFMA_FLOP_PER_FRAME_CODEWORD = 2 * 16 * 15  # 15 k-steps of v_mfma_f32_32x32x16_f16 per (frame, codeword) pair
 BYTES_PER_FRAME_PASS = 306  # 296 B frame + 2 B symbol + 8 B min distortion
 FLOP_PER_FRAME_PASS = 2 * M * (P + 1)
 
@@ -81,10 +83,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefilter", action="store_true",
+                    help="keep every pass on the plain FP64 sweep (A/B against the prefiltered sweep; same results)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL over xGMI; "
                     "gloo lets several ranks share one GPU when rehearsing the N > 1 path)")
     args = ap.parse_args()
 
+    if args.no_prefilter:
+        os.environ["ECOZ2_VQ_PREFILTER"] = "0"
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -152,6 +158,7 @@ def main():
         kernel_ms.append(sess.last_pass_kernel_ms())
     fence()
     dt = time.perf_counter() - t0
+    prefiltered, fallback_frames = sess.last_pass_info()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -182,18 +189,55 @@ def main():
         # PMC traffic cannot be collected inside this process: it comes from the separate rocprofv3 --pmc passes
         # over this same command, recorded in profiles/traffic.json (FETCH_SIZE doubled per the gfx950 note)
         traffic, traffic_detail = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic_prefilter.json" if prefiltered else "traffic.json")
         if os.path.exists(tpath) and S == FRAMES_PER_GPU:
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_detail = {"fetch_bytes": tj.get("fetch_bytes"), "write_bytes": tj.get("write_bytes"),
                                   "algorithmic_bytes": tj.get("algorithmic_bytes_per_launch"),
-                                  "note": "write side is dominated by the exact accumulate's 79 int64 atomics per frame"}
+                                  "note": tj.get("note")}
             except Exception:
                 traffic = None
         achieved_tf = FLOP_PER_FRAME_PASS * frames_per_launch / (k_ms * 1e-3) / 1e12
         achieved_gbs = BYTES_PER_FRAME_PASS * frames_per_launch / (k_ms * 1e-3) / 1e9
+        if prefiltered:
+            # dominant kernel: the prefiltered sweep.  Its matrix work is 15 f16 MFMA k-steps per (frame, codeword)
+            # (exact integer limb products), priced against the dense f16 MFMA peak; the FP64 chain runs only for the
+            # two certified candidates of a frame.  The algorithmic FP64 flops it replaces are reported beside it.
+            exec_tf = F16_MFMA_FLOP_PER_FRAME_CODEWORD * M * frames_per_launch / (k_ms * 1e-3) / 1e12
+            roofline = {
+                "bound": "mfma",
+                "kernel": "k_pass_pre<37,2,4,3> (exact f16-limb prefilter on v_mfma_f32_32x32x16_f16 + top-3 keys, "
+                          "FP64 evaluation of the certified top two on v_mfma_f64_16x16x4_f64, incremental exact "
+                          "accumulate); uncertified frames: k_pass_mfma<37,2,512,2>",
+                "achieved": exec_tf,
+                "peak": F16_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": exec_tf / F16_PEAK_TFLOPS,
+                "traffic": traffic,
+                "traffic_detail": traffic_detail,
+                "kernel_ms": k_ms,
+                "executed_dtype": "f16 limbs (exact integers) -> f32 accumulators; candidates in f64",
+                "algorithmic_fp64": {"tflops_equivalent": achieved_tf, "fp64_peak": FP64_PEAK_TFLOPS,
+                                     "ratio_to_fp64_peak": achieved_tf / FP64_PEAK_TFLOPS,
+                                     "note": "2*M*(P+1) FP64 flop per frame (SURVEY 8d) / kernel time: what the plain "
+                                             "FP64 sweep would have to sustain for the same time"},
+                "fallback_frames_last_pass": fallback_frames,
+            }
+        else:
+            # the plain sweep is FP64-FMA bound (248 flop/B): useful flops 2*M*(P+1) per frame against the 78.6 TF peak
+            roofline = {
+                "bound": "mfma",
+                "kernel": "k_pass_mfma<37,2,512> (sweep on v_mfma_f64_16x16x4_f64 + argmin + exact accumulate)",
+                "achieved": achieved_tf,
+                "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved_tf / FP64_PEAK_TFLOPS,
+                "traffic": traffic,
+                "traffic_detail": traffic_detail,
+                "kernel_ms": k_ms,
+            }
         out = {
             "metric": "vq_learn_frames_per_sec_M1024_P36",
             "value": world * S * args.steps / dt,
@@ -214,6 +258,8 @@ def main():
                 "codebook_size": M,
                 "prediction_order": P,
                 "parallelism": f"frames sharded over {world} rank(s); int64 all-reduce of cell sums per iteration",
+                "sweep": "prefiltered (exact f16-limb prefilter + FP64 verification; bit-identical to the plain sweep)"
+                         if prefiltered else "plain FP64 MFMA sweep",
                 "ladder_seconds_untimed": round(t_ladder, 3),
                 "final_avg_distortion": st.avg_distortion,
                 "learn_end_to_end": {
@@ -224,25 +270,14 @@ def main():
                 },
                 "quantize_frames_per_sec_device_resident": q_rate,
             },
-            # the sweep is FP64-FMA bound (248 flop/B): useful flops 2*M*(P+1) per frame against the 78.6 TF FP64 peak
-            "roofline": {
-                "bound": "mfma",
-                "kernel": "k_pass_mfma<37,2,256> (sweep on v_mfma_f64_16x16x4_f64 + argmin + exact accumulate)",
-                "achieved": achieved_tf,
-                "peak": FP64_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved_tf / FP64_PEAK_TFLOPS,
-                "traffic": traffic,
-                "traffic_detail": traffic_detail,
-                "kernel_ms": k_ms,
-            },
+            "roofline": roofline,
             "roofline_hbm": {
                 "bound": "hbm",
                 "achieved": achieved_gbs,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "note": "algorithmic 306 B per frame-pass; at M=1024 the FP64 ceiling caps this near 4 % (SURVEY 8d)",
+                "note": "algorithmic 306 B per frame-pass; at M=1024 the sweep, not HBM, bounds the pass (SURVEY 8d)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

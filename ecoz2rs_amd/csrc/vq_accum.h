@@ -37,12 +37,18 @@ __host__ __device__ __forceinline__ long mfma_blk_offset(int NC, long t, int n)
 // images in LDS.  MODE 1: all cells in the LDS table lacc; 5: cells < lds_cells there; 2: global atomics; 3: none.
 // SKIP: frames flagged in skip[] (handled by the fallback launch) contribute an all-zero image (their idx must be 0).
 // NFT: 16-frame tiles per block (4 everywhere but in the one-tile-per-wave fallback sweep).
-template <int NC, int MODE, bool SKIP = false, int NFT = 4>
+// INCR (MODE 2 only): the rows persist from the previous pass over the same frames and codebook size.  When `incr`
+// is set, a frame whose cell did not change (oldidx == idx) adds only its distortion elements (those are rebuilt
+// every pass); a frame that moved is subtracted from its old cell and added to the new one.  64-bit integer sums
+// are exactly invertible, so the rows equal those of a full accumulation bit for bit -- at a fraction of the atomics.
+template <int NC, int MODE, bool SKIP = false, int NFT = 4, bool INCR = false>
 __device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((NC + 3) / 4) + 1) / 2)],
                                                  const double (&best)[4], const int (&idx)[4], int* __restrict__ img,
                                                  i64* __restrict__ lacc, i64* __restrict__ rows, int lds_cells, int sh_r,
-                                                 int sh_d, int sh_d2, long b, long T, int lane, const bool (&skip)[4])
+                                                 int sh_d, int sh_d2, long b, long T, int lane, const bool (&skip)[4],
+                                                 bool incr = false, const int (&oldidx)[4] = {0, 0, 0, 0})
 {
+    static_assert(!INCR || MODE == 2, "incremental accumulation goes through global atomics");
     constexpr int NS = (NC + 3) / 4, REM = NC - 4 * (NS - 1);
     constexpr int RS = (2 * NC + 5 + 7) & ~7;
     constexpr int NE = 2 * NC + 5;
@@ -86,14 +92,21 @@ __device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((N
             const int tq = lane >> 4, te = lane & 15;
 #pragma unroll
             for (int j0 = 0; j0 < 16; j0 += 4) {
-                int v[4], cell[4];
+                int v[4], cell[4], old[4] = {0, 0, 0, 0};
+                bool chg[4] = {true, true, true, true};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     cell[k] = __builtin_amdgcn_readlane(idx[ft], j0 + k);
                     v[k] = (HAS_TAIL || lane < NE) ? img[(j0 + k) * IMG + lane] : 0;
+                    if constexpr (INCR) {
+                        old[k] = __builtin_amdgcn_readlane(oldidx[ft], j0 + k);
+                        chg[k] = old[k] != cell[k];  // wave-uniform
+                    }
                 }
                 const int tv = (HAS_TAIL && te < NE - 64) ? img[(j0 + tq) * IMG + 64 + te] : 0;
                 const int tcell = tq == 0 ? cell[0] : tq == 1 ? cell[1] : tq == 2 ? cell[2] : cell[3];
+                const int told = tq == 0 ? old[0] : tq == 1 ? old[1] : tq == 2 ? old[2] : old[3];
+                const bool tchg = tq == 0 ? chg[0] : tq == 1 ? chg[1] : tq == 2 ? chg[2] : chg[3];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (!HAS_TAIL && lane >= NE) continue;  // short rows: lanes beyond the row sit out
@@ -106,6 +119,10 @@ __device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((N
                             atomicAdd((u64*)&lacc[cell[k] * RS + lane], (u64)(i64)v[k]);
                         else
                             atomicAdd((u64*)&rows[(long)cell[k] * RS + lane], (u64)(i64)v[k]);
+                    } else if constexpr (INCR) {
+                        const bool mov = lane <= 2 * NC;  // limbs and count move with the frame; distortions do not
+                        if (!incr || chg[k] || !mov) atomicAdd((u64*)&rows[(long)cell[k] * RS + lane], (u64)(i64)v[k]);
+                        if (incr && chg[k] && mov) atomicAdd((u64*)&rows[(long)old[k] * RS + lane], (u64)(-(i64)v[k]));
                     } else {
                         atomicAdd((u64*)&rows[(long)cell[k] * RS + lane], (u64)(i64)v[k]);
                     }
@@ -120,6 +137,10 @@ __device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((N
                             atomicAdd((u64*)&lacc[tcell * RS + 64 + te], (u64)(i64)tv);
                         else
                             atomicAdd((u64*)&rows[(long)tcell * RS + 64 + te], (u64)(i64)tv);
+                    } else if constexpr (INCR) {
+                        const bool mov = 64 + te <= 2 * NC;
+                        if (!incr || tchg || !mov) atomicAdd((u64*)&rows[(long)tcell * RS + 64 + te], (u64)(i64)tv);
+                        if (incr && tchg && mov) atomicAdd((u64*)&rows[(long)told * RS + 64 + te], (u64)(-(i64)tv));
                     } else {
                         atomicAdd((u64*)&rows[(long)tcell * RS + 64 + te], (u64)(i64)tv);
                     }
@@ -129,7 +150,21 @@ __device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((N
             for (int jj = 0; jj < nv; ++jj) {
                 const int cell = __builtin_amdgcn_readlane(idx[ft], jj);
                 const int* im = img + jj * IMG;
-                if (cell < lds_cells) {  // wave-uniform
+                if constexpr (INCR) {
+                    const int old = __builtin_amdgcn_readlane(oldidx[ft], jj);
+                    const bool chg = old != cell;
+                    i64* row = rows + (long)cell * RS;
+                    i64* orow = rows + (long)old * RS;
+#pragma unroll
+                    for (int e0 = 0; e0 < NE; e0 += 64) {
+                        const int e = e0 + lane;
+                        if (e < NE) {
+                            const bool mov = e <= 2 * NC;
+                            if (!incr || chg || !mov) atomicAdd((u64*)&row[e], (u64)(i64)im[e]);
+                            if (incr && chg && mov) atomicAdd((u64*)&orow[e], (u64)(-(i64)im[e]));
+                        }
+                    }
+                } else if (cell < lds_cells) {  // wave-uniform
                     i64* row = lacc + cell * RS;
                     if (lane < NE) atomicAdd((u64*)&row[lane], (u64)(i64)im[lane]);
                     if (NE > 64 && lane < NE - 64) atomicAdd((u64*)&row[64 + lane], (u64)(i64)im[64 + lane]);

@@ -204,7 +204,8 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                                                        unsigned short* __restrict__ sym, double* __restrict__ dmin,
                                                        i64* __restrict__ rows, int stagger,
                                                        const int* __restrict__ fb_list = nullptr,
-                                                       const int* __restrict__ fb_count = nullptr)
+                                                       const int* __restrict__ fb_count = nullptr,
+                                                       unsigned short* __restrict__ prev_sym = nullptr, int incr = 0)
 {
     constexpr bool AOS = SRC == 1;
     // frame tiles (of 16) per wave: the fallback list is short, so its waves take one tile each -- four times as
@@ -426,7 +427,15 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
         }
 
         // ---- accumulate: int32 row images [frame][2n+limb | count, d, d2] -> exact 64-bit adds ----
-        if constexpr (MODE != 0)
+        if constexpr (MODE == 2 && SRC == 2) {
+            // fallback of a prefiltered pass: incremental like the pass it completes (vq_accum.h)
+            const long slot = b * FPB + j;
+            const long t = slot < T ? fb_list[slot] : -1;
+            const int oldidx[4] = {(incr && t >= 0) ? (int)prev_sym[t] : 0, 0, 0, 0};
+            accumulate_block<NC, MODE, false, NFT, true>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2, b, T,
+                                                         lane, {false, false, false, false}, incr != 0, oldidx);
+            if (prev_sym && q == 0 && t >= 0) prev_sym[t] = (unsigned short)idx[0];
+        } else if constexpr (MODE != 0)
             accumulate_block<NC, MODE, false, NFT>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2, b, T, lane,
                                                    {false, false, false, false});
     }
@@ -1074,18 +1083,30 @@ int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const
 // full FP64 sweep of the frames a prefiltered pass could not certify (vq_prefilter.hip): fb_list[0 .. *fb_count)
 int launch_pass_fallback(int NC, bool accumulate, const double* blk, const double* cbm, int M, const DevScalars* sc,
                          const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows, const int* fb_list,
-                         const int* fb_count, hipStream_t s)
+                         const int* fb_count, unsigned short* prev_sym, bool incremental, hipStream_t s)
 {
     if (NC != 37) return 1;
     constexpr int IMG = 2 * 37 + 5 + IMG_STRIDE_PAD;
     const int MT = (M + 15) / 16;
     if (accumulate)
         hipLaunchKernelGGL((k_pass_mfma<37, 2, 512, 2>), dim3(256), dim3(512), (size_t)8 * 16 * IMG * 4, s, blk, 0L, 0L, cbm,
-                           MT, M, sc, l1max_bits, sym, dmin, rows, 0, fb_list, fb_count);
+                           MT, M, sc, l1max_bits, sym, dmin, rows, 0, fb_list, fb_count, prev_sym, incremental ? 1 : 0);
     else
         hipLaunchKernelGGL((k_pass_mfma<37, 0, 256, 2>), dim3(512), dim3(256), 0, s, blk, 0L, 0L, cbm, MT, M, sc, l1max_bits,
                            sym, dmin, rows, 0, fb_list, fb_count);
     return 0;
+}
+
+// incremental accumulation: the distortion elements of every row are rebuilt each pass, the cell sums persist
+__global__ void k_zero_dist(i64* __restrict__ rows, int M, int NC, int RS)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4 * M) rows[(long)(i >> 2) * RS + 2 * NC + 1 + (i & 3)] = 0;
+}
+
+void launch_zero_distortion_columns(i64* rows, int M, int NC, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_zero_dist, dim3((4 * M + 255) / 256), dim3(256), 0, s, rows, M, NC, row_stride(NC));
 }
 
 // threads per block of the per-cell kernels: 3 LDS columns of NC doubles per thread must fit 64 KB

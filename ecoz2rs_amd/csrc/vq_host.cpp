@@ -125,6 +125,13 @@ struct e2vq_session {
     void* d_ps = nullptr;
     int* d_fblist = nullptr;
     bool last_prefiltered = false;
+    // incremental accumulation (prefiltered passes): the rank's own rows and every frame's cell persist between
+    // passes of one codebook size; a pass then moves only the frames whose cell changed (vq_accum.h)
+    bool incr_enabled = true, incr_valid = false;
+    int incr_M = 0;
+    unsigned short* d_prev_sym = nullptr;
+    i64* d_rows_local = nullptr;  // world > 1: the un-reduced rows (d_rows holds the all-reduced copy)
+    int rows_local_cap = 0;
     // collective hook
     e2vq_allreduce_fn allreduce = nullptr;
     void* ar_user = nullptr;
@@ -182,6 +189,7 @@ static int ensure_codebook_capacity(e2vq_session* s, int M)
     s->d_S = S;
     s->d_within = within;
     s->d_rows = rows;
+    s->incr_valid = false;
     s->M_cap = cap;
     return 0;
 }
@@ -206,6 +214,7 @@ static int session_init(e2vq_session* s)
     const char* pf = getenv("ECOZ2_VQ_PREFILTER");
     s->pre_enabled = e2vq::prefilter_supports(s->NC, 64) && !(pf && atoi(pf) == 0);
     if (const char* mm = getenv("ECOZ2_VQ_PREFILTER_MIN_M")) s->pre_min_M = std::max(64, atoi(mm));
+    if (const char* inc = getenv("ECOZ2_VQ_INCREMENTAL")) s->incr_enabled = atoi(inc) != 0;
     if (s->pre_enabled) {
         HIPCHK(hipMalloc(&s->d_colmax, (size_t)s->NC * 8));
         HIPCHK(hipMalloc(&s->d_ea, (size_t)s->NC * sizeof(int)));
@@ -251,7 +260,7 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     void* ptrs[] = {s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
-                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg, s->d_ps, s->d_fblist};
+                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg, s->d_ps, s->d_fblist, s->d_prev_sym, s->d_rows_local};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev_stats) (void)hipEventDestroy(s->ev_stats);
@@ -315,17 +324,21 @@ extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames
         if (s->d_fimg) HIPCHK(hipFree(s->d_fimg));
         if (s->d_fg) HIPCHK(hipFree(s->d_fg));
         if (s->d_fblist) HIPCHK(hipFree(s->d_fblist));
+        if (s->d_prev_sym) HIPCHK(hipFree(s->d_prev_sym));
+        s->d_prev_sym = nullptr;
         s->d_fimg = nullptr;
         s->d_fg = nullptr;
         s->d_fblist = nullptr;
         HIPCHK(hipMalloc(&s->d_fimg, e2vq::prefilter_frame_image_bytes(s->nblocks)));
         HIPCHK(hipMalloc(&s->d_fg, (size_t)s->nblocks * 64 * sizeof(float)));
         HIPCHK(hipMalloc(&s->d_fblist, (size_t)s->nblocks * 64 * sizeof(int)));
+        HIPCHK(hipMalloc(&s->d_prev_sym, (size_t)s->nblocks * 64 * sizeof(unsigned short)));
         e2vq::launch_prefilter_frames(s->d_blk, T, s->nblocks, s->NC, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->stream);
         HIPCHK(hipGetLastError());
     }
     s->prepared = false;
     s->stats_valid = false;
+    s->incr_valid = false;
     return 0;
 }
 
@@ -380,8 +393,10 @@ extern "C" int e2vq_prepare(e2vq_session* s)
 
 // ---- codebook ----------------------------------------------------------------------------
 
-static int codebook_prepare(e2vq_session* s)
+// (callers that redefine the codebook's size or contents from outside: set / init / grow)
+static int codebook_prepare(e2vq_session* s, bool redefined = true)
 {
+    if (redefined) s->incr_valid = false;
     if (e2vq::has_cell_update(s->NC))
         e2vq::launch_cell_update(nullptr, s->M, s->NC, s->d_sc, s->d_refl, nullptr, s->d_cbq, s->d_cbm, s->d_l1max,
                                  nullptr, nullptr, s->stream);
@@ -479,9 +494,26 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     if (!s->prepared) return e2vq_set_error("e2vq_prepare has not run");
     if (s->M < 1) return e2vq_set_error("no codebook");
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipMemsetAsync(s->d_rows, 0, (size_t)s->M * s->RS * 8, s->stream));
     const int mode = pass_mode(s);
     s->last_prefiltered = use_prefilter(s, mode);
+    const bool collective = s->allreduce && (s->world > 1 || getenv("ECOZ2_VQ_FORCE_ALLREDUCE"));
+    const bool keep = s->last_prefiltered && mode != 0 && s->incr_enabled;  // rows and cells persist for the next pass
+    i64* rows = s->d_rows;
+    if (keep && collective) {  // the all-reduce overwrites d_rows: accumulate into the rank's own copy
+        if (s->rows_local_cap < s->M_cap) {
+            if (s->d_rows_local) HIPCHK(hipFree(s->d_rows_local));
+            s->d_rows_local = nullptr;
+            HIPCHK(hipMalloc(&s->d_rows_local, (size_t)s->M_cap * s->RS * 8));
+            s->rows_local_cap = s->M_cap;
+            s->incr_valid = false;
+        }
+        rows = s->d_rows_local;
+    }
+    const bool incremental = keep && s->incr_valid && s->incr_M == s->M;
+    if (incremental)
+        e2vq::launch_zero_distortion_columns(rows, s->M, s->NC, s->stream);
+    else if (mode != 0)
+        HIPCHK(hipMemsetAsync(rows, 0, (size_t)s->M * s->RS * 8, s->stream));
     if (s->last_prefiltered) {
         // f16 limb image of the current codebook, prefiltered sweep (exact evaluation of the certified top two),
         // then the full FP64 sweep of whatever it could not certify
@@ -490,23 +522,31 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
         e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, s->d_cimg, s->d_ps,
                                       s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
-                                      (double*)device_dmin, s->d_rows, s->d_fblist, s->stream);
+                                      (double*)device_dmin, rows, s->d_fblist, keep ? s->d_prev_sym : nullptr,
+                                      incremental, s->stream);
         if (s->timing) {
             HIPCHK(hipEventRecord(s->ev1, s->stream));
             s->timed = true;
         }
         e2vq::launch_pass_fallback(s->NC, mode != 0, s->d_blk, s->d_cbm, s->M, s->d_sc, s->d_l1max,
-                                   (unsigned short*)device_sym, (double*)device_dmin, s->d_rows, s->d_fblist,
-                                   e2vq::prefilter_fallback_count(s->d_ps), s->stream);
+                                   (unsigned short*)device_sym, (double*)device_dmin, rows, s->d_fblist,
+                                   e2vq::prefilter_fallback_count(s->d_ps), keep ? s->d_prev_sym : nullptr, incremental,
+                                   s->stream);
     } else {
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
         e2vq::launch_pass(s->NC, mode, s->d_blk, s->T, s->nblocks, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max,
-                          (unsigned short*)device_sym, (double*)device_dmin, s->d_rows, s->stream);
+                          (unsigned short*)device_sym, (double*)device_dmin, rows, s->stream);
         if (s->timing) {
             HIPCHK(hipEventRecord(s->ev1, s->stream));
             s->timed = true;
         }
     }
+    if (mode != 0) {
+        s->incr_valid = keep;
+        s->incr_M = s->M;
+    }
+    if (rows != s->d_rows)
+        HIPCHK(hipMemcpyAsync(s->d_rows, rows, (size_t)s->M * s->RS * 8, hipMemcpyDeviceToDevice, s->stream));
     HIPCHK(hipGetLastError());
     if (reduce(s, s->d_rows, (i64)s->M * s->RS, 0)) return 1;
     s->stats_valid = false;
@@ -614,7 +654,7 @@ extern "C" int e2vq_update(e2vq_session* s)
     }
     e2vq::launch_centroids(s->d_rows, s->d_S, s->M, s->NC, s->d_refl, s->d_refl, s->d_lstats, s->stream);
     HIPCHK(hipGetLastError());
-    return codebook_prepare(s);
+    return codebook_prepare(s, false);
 }
 
 extern "C" int e2vq_row_stride(int prediction_order) { return e2vq::row_stride(prediction_order + 1); }

@@ -274,7 +274,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_pass_pre(const double* __restri
                                                   const double* __restrict__ cbq, int MT, int idxmask,
                                                   const DevScalars* __restrict__ sc, const u64* __restrict__ l1max_bits,
                                                   unsigned short* __restrict__ sym, double* __restrict__ dmin,
-                                                  i64* __restrict__ rows, int* __restrict__ fb_list, int stagger)
+                                                  i64* __restrict__ rows, int* __restrict__ fb_list, int stagger,
+                                                  unsigned short* __restrict__ prev_sym, int incr)
 {
     static_assert(NC == 37, "the K-slot packing of the prefilter is laid out for P = 36");
     constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2, REM = NC - 4 * (NS - 1);
@@ -479,6 +480,16 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_pass_pre(const double* __restri
             for (int ft = 0; ft < 4; ++ft) idx[ft] = skip[ft] ? 0 : idx[ft];
         }
 
+        // cells of the previous pass (incremental accumulation); frames left to the fallback change nothing here
+        int oldidx[4] = {0, 0, 0, 0};
+        if (MODE != 0 && incr) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const long t = b * 64 + 16 * ft + j;
+                oldidx[ft] = (t < T && !skip[ft]) ? prev_sym[t] : 0;
+            }
+        }
+
         // ---- outputs: lane 16q + j owns frame b*64 + lane; uncertified frames go to the fallback list ---------
         {
             const double bs = q == 0 ? best[0] : q == 1 ? best[1] : q == 2 ? best[2] : best[3];
@@ -494,9 +505,15 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_pass_pre(const double* __restri
                 }
             }
         }
-        if constexpr (MODE != 0)
+        if constexpr (MODE != 0) {
             // (no LDS table here: lds_cells = 0; a null table pointer crashes the ROCm 7.2 optimizer, so pass the LDS base)
-            accumulate_block<NC, MODE, true>(Bf, best, idx, img, (i64*)smem, rows, 0, sh_r, sh_d, sh_d2, b, T, lane, skip);
+            accumulate_block<NC, MODE, true, 4, true>(Bf, best, idx, img, (i64*)smem, rows, 0, sh_r, sh_d, sh_d2, b, T, lane,
+                                                      skip, incr != 0, oldidx);
+            // (after the accumulate, which consumed the old cells: the owner lane records the new one)
+            const int is = q == 0 ? idx[0] : q == 1 ? idx[1] : q == 2 ? idx[2] : idx[3];
+            const bool sk = q == 0 ? skip[0] : q == 1 ? skip[1] : q == 2 ? skip[2] : skip[3];
+            if (prev_sym && b * 64 + lane < T && !sk) prev_sym[b * 64 + lane] = (unsigned short)is;
+        }
     }
 }
 
@@ -536,12 +553,14 @@ void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, 
                        (h8*)cimg);
 }
 
-// accumulate = false: assignment only.  Runs after launch_prefilter_codebook of the same pass; afterwards
+// accumulate = false: assignment only.  prev_sym (optional): the cell of every frame is recorded there; with
+// `incremental` the rows must be those of the previous pass over the same frames (distortion elements zeroed) and
+// prev_sym its cells.  Runs after launch_prefilter_codebook of the same pass; afterwards
 // *prefilter_fallback_count(ps) frames wait in fb_list for launch_pass_fallback.
 int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, long nblocks, const void* fimg,
                             const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
-                            long long* rows, int* fb_list, hipStream_t s)
+                            long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, hipStream_t s)
 {
     if (!prefilter_supports(NC, M)) return 1;
     constexpr int IMG = 2 * 37 + 5 + IMG_STRIDE_PAD;
@@ -557,13 +576,13 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                                   E2VQ_LDS_BYTES);
         hipLaunchKernelGGL((k_pass_pre<37, 2, WPB, NSLOT>), dim3(grid), dim3(64 * WPB), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
-                           dmin, rows, fb_list, stagger);
+                           dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0);
     } else {
         (void)hipFuncSetAttribute((const void*)k_pass_pre<37, 0, WPB, NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
         hipLaunchKernelGGL((k_pass_pre<37, 0, WPB, NSLOT>), dim3(grid), dim3(64 * WPB), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
-                           dmin, rows, fb_list, stagger);
+                           dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0);
     }
     return 0;
 }

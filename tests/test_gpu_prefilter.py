@@ -167,3 +167,35 @@ def test_learn_ladder_with_prefilter_matches_oracle(oracle, monkeypatch):
     assert [(l.M, l.passes) for l in levels] == [(l["M"], l["passes"]) for l in levels_o]
     assert cbs == cbs_o
     assert np.array_equal(refl.view(np.uint64), levels_o[-1]["reflections"].view(np.uint64))
+
+
+@pytest.mark.parametrize("collective", [False, True])
+def test_incremental_rows_match_a_full_accumulation_every_pass(oracle, monkeypatch, collective):
+    """Five passes at one codebook size with centroid updates in between: from the second pass on only the frames
+    that changed cell are moved (and the fallback list is incremental too); the rows must equal the oracle's full
+    accumulation every time.  `collective` routes the rows through the all-reduce hook (own copy + reduced copy)."""
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER", "1")
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
+    if collective:
+        monkeypatch.setenv("ECOZ2_VQ_FORCE_ALLREDUCE", "1")
+    frames = _frames(20257, 9000)
+    refl = np.concatenate([_codebook(oracle, frames, 128, seed=8)] * 2, axis=0)  # duplicates: a busy fallback list
+    rc, st = oracle.data_stats(frames)
+    sh_r, _ = oracle.shifts(st.maxabs)
+    calls = []
+    with e.VqSession(P) as s:
+        if collective:
+            s.set_allreduce(lambda buf, count, op, stream: calls.append(count) or 0, 0, 1)
+        s.set_frames(frames)
+        s.prepare()
+        s.set_codebook(refl)
+        for it in range(5):
+            cq = oracle.reflections_to_cq(refl)
+            _sym, _dmin, rows_o = oracle.run_pass(cq, frames, sh_r, oracle.dist_exponent(cq, st.maxabs))
+            s.run_pass()
+            assert s.last_pass_info()[0]
+            assert np.array_equal(s.get_rows(), rows_o), f"pass {it}"
+            refl, _failed = oracle.update(rows_o, P, sh_r, refl)
+            s.update()
+            assert np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64))
+    assert bool(calls) == collective
