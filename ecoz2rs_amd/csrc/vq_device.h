@@ -41,6 +41,9 @@ size_t prefilter_codebook_image_bytes(int M);
 size_t prefilter_scalars_bytes();
 void launch_prefilter_frames(const double* blk, long T, long nblocks64, int NC, unsigned long long* colmax_bits, int* ea,
                              void* fimg, float* fg, hipStream_t s);
+// quantize: scales from the codebook; row-major frames -> blocked FP64 layout + limb image + tolerance terms
+void launch_prefilter_quantize_prep(const double* aos, long T, long nblocks64, int NC, const double* cbq, int M, int* ea,
+                                    double* blk, void* fimg, float* fg, hipStream_t s);
 void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, void* ps, void* cimg, hipStream_t s);
 const int* prefilter_fallback_count(const void* ps);
 int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, long nblocks, const void* fimg,

@@ -125,6 +125,14 @@ struct e2vq_session {
     void* d_ps = nullptr;
     int* d_fblist = nullptr;
     bool last_prefiltered = false;
+    // quantize through the prefiltered sweep: scratch images of the frames handed in and of the codebook
+    int* d_ea_q = nullptr;
+    void* d_qfimg = nullptr;
+    float* d_qfg = nullptr;
+    int* d_qfblist = nullptr;
+    void* d_qcimg = nullptr;
+    i64 qpre_cap = 0;
+    int qcimg_cap = 0;
     // incremental accumulation (prefiltered passes): the rank's own rows and every frame's cell persist between
     // passes of one codebook size; a pass then moves only the frames whose cell changed (vq_accum.h)
     bool incr_enabled = true, incr_valid = false;
@@ -260,7 +268,8 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     void* ptrs[] = {s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
-                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg, s->d_ps, s->d_fblist, s->d_prev_sym, s->d_rows_local};
+                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg, s->d_ps, s->d_fblist, s->d_prev_sym, s->d_rows_local,
+                    s->d_ea_q, s->d_qfimg, s->d_qfg, s->d_qfblist, s->d_qcimg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev_stats) (void)hipEventDestroy(s->ev_stats);
@@ -779,6 +788,40 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
     if (T < 1) return 0;
     HIPCHK(hipSetDevice(s->device));
     const i64 nb = (T + s->FB - 1) / s->FB;
+    if (s->pre_enabled && s->M >= s->pre_min_M && e2vq::prefilter_supports(s->NC, s->M)) {
+        // prefiltered sweep: one re-layout pass builds the blocked FP64 frames and their f16 limb image, then the
+        // assignment-only prefiltered kernel and the FP64 sweep of what it could not certify
+        if (ensure_qblk(s, T)) return 1;
+        if (s->qpre_cap < nb) {
+            for (void* p : {(void*)s->d_qfimg, (void*)s->d_qfg, (void*)s->d_qfblist})
+                if (p) HIPCHK(hipFree(p));
+            s->d_qfimg = nullptr;
+            s->d_qfg = nullptr;
+            s->d_qfblist = nullptr;
+            HIPCHK(hipMalloc(&s->d_qfimg, e2vq::prefilter_frame_image_bytes(nb)));
+            HIPCHK(hipMalloc(&s->d_qfg, (size_t)nb * 64 * sizeof(float)));
+            HIPCHK(hipMalloc(&s->d_qfblist, (size_t)nb * 64 * sizeof(int)));
+            s->qpre_cap = nb;
+        }
+        if (!s->d_ea_q) HIPCHK(hipMalloc(&s->d_ea_q, (size_t)s->NC * sizeof(int)));
+        if (s->qcimg_cap < s->M) {
+            if (s->d_qcimg) HIPCHK(hipFree(s->d_qcimg));
+            s->d_qcimg = nullptr;
+            s->qcimg_cap = std::max(s->M, 2048);
+            HIPCHK(hipMalloc(&s->d_qcimg, e2vq::prefilter_codebook_image_bytes(s->qcimg_cap)));
+        }
+        e2vq::launch_prefilter_quantize_prep((const double*)device_frames, T, nb, s->NC, s->d_cbq, s->M, s->d_ea_q,
+                                             s->d_qblk, s->d_qfimg, s->d_qfg, s->stream);
+        e2vq::launch_prefilter_codebook(s->d_cbq, s->M, s->NC, s->d_ea_q, s->d_ps, s->d_qcimg, s->stream);
+        e2vq::launch_pass_prefiltered(s->NC, false, s->d_qblk, T, nb, s->d_qfimg, s->d_qfg, s->d_qcimg, s->d_ps, s->d_cbq,
+                                      s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym, (double*)device_dmin, nullptr,
+                                      s->d_qfblist, nullptr, false, s->stream);
+        e2vq::launch_pass_fallback(s->NC, false, s->d_qblk, s->d_cbm, s->M, s->d_sc, s->d_l1max,
+                                   (unsigned short*)device_sym, (double*)device_dmin, nullptr, s->d_qfblist,
+                                   e2vq::prefilter_fallback_count(s->d_ps), nullptr, false, s->stream);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (e2vq::uses_mfma(s->NC) && ((uintptr_t)device_frames & 15) == 0) {
         // P = 36: the sweep reads the row-major payload directly (coalesced staging through LDS)
         e2vq::launch_pass(s->NC, 4, (const double*)device_frames, T, nb, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max,

@@ -153,6 +153,103 @@ __global__ __launch_bounds__(64) void k_pre_frames(const double* __restrict__ bl
     }
 }
 
+// ---- quantize: no data statistic is at hand, so the per-coefficient scales come from the codebook ---------
+// a_n = 2^ea[n] with ea[n] = -(ilogb(max_m |c[m][n]|) + 1): every eta = c a is in (-1, 1) with C = 1, and the
+// frame scale A_t absorbs whatever range r / a has.  (Any powers of two keep the limb arithmetic exact and the
+// bound scale-free; the choice only moves how tight the bound is.)
+__global__ void k_pre_ea_from_codebook(const double* __restrict__ cbq, int M, int NC, int NPAD, int* __restrict__ ea)
+{
+    __shared__ u64 smax[E2VQ_MAX_P + 1];
+    for (int i = threadIdx.x; i < NC; i += blockDim.x) smax[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < M * NC; i += blockDim.x) {
+        const int m = i / NC, n = i - m * NC;
+        const u64 bits = (u64)__double_as_longlong(fabs(cbq[(long)m * NPAD + n]));
+        if (bits > smax[n]) atomicMax(&smax[n], bits);
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < NC; n += blockDim.x) {
+        const double mx = __longlong_as_double((i64)smax[n]);
+        ea[n] = mx > 0.0 ? -(ilogb(mx) + 1) : 0;
+    }
+}
+
+// row-major frames [t][NC] -> (a) the blocked FP64 MFMA layout of k_blockify_mfma, (b) the f16 limb image,
+// (c) the tolerance terms, one 64-frame block per workgroup, every global access coalesced through LDS
+template <int NC>
+__global__ __launch_bounds__(256) void k_pre_quant_prep(const double* __restrict__ aos, long T, long nblocks,
+                                                        const int* __restrict__ ea, double* __restrict__ blk,
+                                                        h8* __restrict__ fimg, float* __restrict__ fg)
+{
+    constexpr int NS = (NC + 3) / 4;
+    __shared__ double stage[64 * NC];
+    __shared__ short X[3][64][40];
+    __shared__ int eAs[64];
+    __shared__ int eas[NC];
+    for (int n = threadIdx.x; n < NC; n += 256) eas[n] = ea[n];
+    for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        __syncthreads();
+        const long base = b * 64 * NC, total = T * NC;
+        for (int i = threadIdx.x; i < 64 * NC; i += 256) stage[i] = base + i < total ? aos[base + i] : 0.0;
+        __syncthreads();
+        // (a) blocked FP64 layout: element o of the block holds r[t][n] as k_blockify_mfma lays it out
+        for (int o = threadIdx.x; o < 64 * NC; o += 256) {
+            const int u = o / (NC * 32), x = o - u * (NC * 32);
+            int n, h, j;
+            if (x < (NS - 1) * 128) {
+                const int y = x & 127, l = y >> 1;
+                h = y & 1;
+                j = l & 15;
+                n = 4 * (x >> 7) + (l >> 4);
+            } else {
+                const int y = x - (NS - 1) * 128, z = y >> 1;
+                h = y & 1;
+                j = z & 15;
+                n = 4 * (NS - 1) + (z >> 4);
+            }
+            blk[base + o] = stage[(u * 32 + h * 16 + j) * NC + n];
+        }
+        // frame scales and tolerance terms: one thread per frame (row stride NC is odd: conflict-free)
+        if (threadIdx.x < 64) {
+            const double* row = stage + threadIdx.x * NC;
+            int eA = -100000;
+            for (int n = 0; n < NC; ++n)
+                if (row[n] != 0.0) {
+                    const int e = ilogb(row[n]) - eas[n] + 1;
+                    eA = e > eA ? e : eA;
+                }
+            if (eA == -100000) eA = 0;
+            eAs[threadIdx.x] = eA;
+            double g = 0.0;
+            for (int n = 0; n < NC; ++n) g += fabs(ldexp(row[n], -eas[n] - eA));
+            const long t = b * 64 + threadIdx.x;
+            if (t < T) fg[t] = (float)g * 1.000001f;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * 40; i += 256) {
+            const int f = i / 40, n = i - f * 40;
+            int l1 = 0, l2 = 0, l3 = 0;
+            if (n < NC) pre_split(ldexp(stage[f * NC + n], -eas[n] - eAs[f]), l1, l2, l3);
+            X[0][f][n] = (short)l1;
+            X[1][f][n] = (short)l2;
+            X[2][f][n] = (short)l3;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * PRE_PAIRS * 64; i += 256) {
+            const int cb = i / (PRE_PAIRS * 64), r = i - cb * (PRE_PAIRS * 64), p = r >> 6, l = r & 63;
+            const int hh = l >> 5, f = 32 * cb + (l & 31);
+            h8 out;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int fl, n;
+                pre_slot(p, hh, e, fl, n);
+                out[e] = n >= 0 ? (_Float16)(int)X[fl][f][n] : (_Float16)0;
+            }
+            fimg[((b * 2 + cb) * PRE_PAIRS + p) * 64 + l] = out;
+        }
+    }
+}
+
 // per-pass scalars, zeroed by one memset before the codebook image is built
 struct PreScalars {
     int eC_biased;  // codebook scale C = 2^eC > max |c[m][n]| a_n, stored as eC + PRE_EBIAS (0 = empty)
@@ -538,6 +635,15 @@ void launch_prefilter_frames(const double* blk, long T, long nblocks64, int NC, 
     hipLaunchKernelGGL(k_pre_exponents, dim3(1), dim3(256), 0, s, (const u64*)colmax_bits, NC, ea);
     hipLaunchKernelGGL(k_pre_frames, dim3(pre_grid(nblocks64 * 2, 1, 16384)), dim3(64), 0, s, blk, T, nblocks64 * 2, NC,
                        (const int*)ea, (h8*)fimg, fg);
+}
+
+void launch_prefilter_quantize_prep(const double* aos, long T, long nblocks64, int NC, const double* cbq, int M, int* ea,
+                                    double* blk, void* fimg, float* fg, hipStream_t s)
+{
+    const int NPAD = (NC + 7) & ~7;
+    hipLaunchKernelGGL(k_pre_ea_from_codebook, dim3(1), dim3(1024), 0, s, cbq, M, NC, NPAD, ea);
+    hipLaunchKernelGGL((k_pre_quant_prep<37>), dim3(pre_grid(nblocks64, 1, 4096)), dim3(256), 0, s, aos, T, nblocks64,
+                       (const int*)ea, blk, (h8*)fimg, fg);
 }
 
 const int* prefilter_fallback_count(const void* ps) { return &((const PreScalars*)ps)->fb_count; }

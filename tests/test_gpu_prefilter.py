@@ -199,3 +199,23 @@ def test_incremental_rows_match_a_full_accumulation_every_pass(oracle, monkeypat
             s.update()
             assert np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64))
     assert bool(calls) == collective
+
+
+@pytest.mark.parametrize("T,M", [(1, 64), (63, 256), (7777, 256), (20000, 1024), (5000, 2048)])
+def test_quantize_through_the_prefilter_bit_exact(oracle, monkeypatch, T, M):
+    """vq quantize: the limb image is built from the row-major payload with codebook-derived scales."""
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER", "1")
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
+    frames = _frames(20258, max(T, 3000))
+    refl = _codebook(oracle, frames, M, seed=9)
+    frames = frames[:T].copy()
+    if T > 100:
+        frames[::9] *= 1e-7
+        frames[4::17] = 0.0
+        frames[2::23] *= -3.0
+    sym_o, dmin_o = oracle.quantize(oracle.reflections_to_cq(refl), frames)
+    with e.VqSession(P) as s:
+        s.set_codebook(refl)
+        sym, dmin = s.quantize(frames)
+    assert np.array_equal(sym, sym_o)
+    assert np.array_equal(dmin.view(np.uint64), dmin_o.view(np.uint64))

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle parity fuzz (bit-exact): random T, M, P, codebooks; one pass + update + quantize each.
-usage: tools/fuzz_parity.py [n_cases] [seed]"""
+usage: tools/fuzz_parity.py [n_cases] [seed] [pre]
+`pre`: aim at the prefiltered sweep -- P = 36, M a multiple of 32 in 64..2048 (prefilter forced from M = 64), frames
+rescaled / zeroed / sign-flipped at random, duplicated and twinned codewords, three passes with updates in between
+(the second and third accumulate incrementally)."""
 import os, sys, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,6 +16,8 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     oracle = oracle_lib.load()
     os.environ["ECOZ2_VQ_QUIET"] = "1"
+    if len(sys.argv) > 3 and sys.argv[3] == "pre":
+        return fuzz_prefilter(n, rng, oracle)
     bad = 0
     t0 = time.time()
     for case in range(n):
@@ -52,6 +57,62 @@ def main():
             print(f"{case + 1} cases, {bad} mismatches, {time.time() - t0:.0f}s", flush=True)
     print(f"fuzz done: {n} cases, {bad} mismatches")
     sys.exit(1 if bad else 0)
+
+def fuzz_prefilter(n, rng, oracle):
+    os.environ["ECOZ2_VQ_PREFILTER"] = "1"
+    os.environ["ECOZ2_VQ_PREFILTER_MIN_M"] = "64"
+    P, bad, fallback, frames_total, t0 = 36, 0, 0, 0, time.time()
+    for case in range(n):
+        T = int(rng.choice([rng.integers(1, 300), rng.integers(300, 8000), rng.integers(8000, 30000)]))
+        M = 32 * int(rng.choice([rng.integers(2, 9), rng.integers(9, 33), rng.integers(33, 65)]))
+        frames = e.synth.synth_frames(int(rng.integers(1, 1 << 30)), int(rng.integers(1, 12)), P, int(rng.integers(0, 1000)), T)
+        kind = int(rng.integers(0, 6))
+        if kind == 1:  # rows rescaled over many decades
+            frames = frames * 10.0 ** rng.integers(-12, 12, size=T)[:, None]
+        elif kind == 2:  # some zero rows, some sign-flipped rows, one dead coefficient
+            frames = frames.copy()
+            frames[rng.random(T) < 0.05] = 0.0
+            frames[rng.random(T) < 0.05] *= -1.0
+            frames[:, int(rng.integers(1, P + 1))] = 0.0
+            if not frames.any():
+                frames[0, 0] = 1.0
+        elif kind == 3:  # whole set scaled
+            frames = frames * 10.0 ** int(rng.integers(-30, 30))
+        nsrc = M if kind != 4 else max(2, M // int(rng.integers(2, 9)))  # kind 4: duplicated codewords
+        src = e.synth.synth_frames(int(rng.integers(1, 1 << 30)), 5, P, 0, nsrc)
+        refl = np.zeros((M, P + 1))
+        for i in range(M):
+            refl[i, 1:] = oracle.lpca_r(src[i % nsrc], P)[2][1:] * (rng.uniform(0.9, 1.0) if kind != 4 else 1.0)
+        if kind == 5:  # twins of the LBG split
+            refl = oracle.grow(refl[: M // 2])
+        rc, st = oracle.data_stats(frames)
+        sh_r, sh_q = oracle.shifts(st.maxabs)
+        ok, what = True, ""
+        with e.VqSession(P) as s:
+            s.set_frames(frames); s.prepare(); s.set_codebook(refl)
+            for it in range(3):
+                cq = oracle.reflections_to_cq(refl)
+                Ed = oracle.dist_exponent(cq, st.maxabs)
+                _sym, _dmin, rows_o = oracle.run_pass(cq, frames, sh_r, Ed)
+                ls_o = oracle.rows_stats(rows_o, P, T, sh_r, Ed, oracle.unfix(st.q_hi, st.q_lo, sh_q))
+                refl, _ = oracle.update(rows_o, P, sh_r, refl)
+                s.run_pass(); used, nfb = s.last_pass_info(); rows = s.get_rows(); ls = s.pass_stats(); s.update()
+                fallback += nfb; frames_total += T
+                good = (used and np.array_equal(rows, rows_o) and ls.DD == ls_o.DD and ls.sigma == ls_o.sigma
+                        and ls.inertia == ls_o.inertia
+                        and np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64)))
+                if not good:
+                    ok, what = False, f"pass {it} (prefiltered={used})"
+                    break
+        if not ok:
+            bad += 1
+            print(f"MISMATCH case {case}: kind={kind} T={T} M={M}: {what}", flush=True)
+        if case % 25 == 24:
+            print(f"{case + 1} cases, {bad} mismatches, {fallback}/{frames_total} frame-passes via the FP64 fallback, "
+                  f"{time.time() - t0:.0f}s", flush=True)
+    print(f"prefilter fuzz done: {n} cases x 3 passes, {bad} mismatches, {fallback}/{frames_total} frame-passes via the fallback")
+    sys.exit(1 if bad else 0)
+
 
 if __name__ == "__main__":
     main()
