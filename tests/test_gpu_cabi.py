@@ -184,7 +184,7 @@ s = e.VqSession(36, device=0)
 parallel.bind_torch_stream(s, 0)
 s.set_allreduce(parallel.make_allreduce(0), rank, world)
 s.set_frames(frames); s.prepare(); s.init_codebook()
-levels = s.learn(0.05, 64)
+levels = s.learn(0.05, 512)
 np.save(sys.argv[2] + f"/cb_{rank}.npy", s.get_codebook())
 np.save(sys.argv[2] + f"/passes_{rank}.npy", np.array([l.passes for l in levels]))
 s.close(); dist.destroy_process_group()
@@ -209,7 +209,7 @@ def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
         s.set_frames(frames)
         s.prepare()
         s.init_codebook()
-        levels = s.learn(0.05, 64)
+        levels = s.learn(0.05, 512)
         ref = s.get_codebook()
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / f"cb_{r}.npy").view(np.uint64), ref.view(np.uint64))
@@ -235,7 +235,7 @@ s = e.VqSession(36, device=0)
 parallel.bind_torch_stream(s, 0)
 s.set_allreduce(counting, 0, 1)
 s.set_frames(frames); s.prepare(); s.init_codebook()
-s.learn(0.05, 32)
+s.learn(0.05, 256)
 np.save(sys.argv[2] + "/cb_nccl.npy", s.get_codebook())
 np.save(sys.argv[2] + "/calls.npy", np.array(calls))
 s.close(); dist.barrier(); dist.destroy_process_group()
@@ -255,7 +255,7 @@ def test_rccl_hook_single_rank_group(tmp_path):
         s.set_frames(frames)
         s.prepare()
         s.init_codebook()
-        s.learn(0.05, 32)
+        s.learn(0.05, 256)
         ref = s.get_codebook()
     assert np.array_equal(np.load(tmp_path / "cb_nccl.npy").view(np.uint64), ref.view(np.uint64))
     calls = np.load(tmp_path / "calls.npy")
