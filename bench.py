@@ -203,27 +203,39 @@ def main():
         achieved_gbs = BYTES_PER_FRAME_PASS * frames_per_launch / (k_ms * 1e-3) / 1e9
         if prefiltered:
             # dominant kernel: the prefiltered sweep.  Its matrix work is 15 f16 MFMA k-steps per (frame, codeword)
-            # (exact integer limb products), priced against the dense f16 MFMA peak; the FP64 chain runs only for the
-            # two certified candidates of a frame.  The algorithmic FP64 flops it replaces are reported beside it.
+            # (exact integer limb products); the FP64 chain runs only for the two certified candidates of a frame.
             exec_tf = F16_MFMA_FLOP_PER_FRAME_CODEWORD * M * frames_per_launch / (k_ms * 1e-3) / 1e12
+            kernel_name = ("k_pass_pre<37,2,4,3> (exact f16-limb prefilter on v_mfma_f32_32x32x16_f16 + top-3 keys, "
+                           "FP64 evaluation of the certified top two on v_mfma_f64_16x16x4_f64, incremental exact "
+                           "accumulate); uncertified frames: k_pass_mfma<37,2,512,2>")
+            # by the contract: ALGORITHMIC flops of the path (2*M*(P+1) FP64 flop per frame-pass) per kernel
+            # time against the FP64 peak.  The ratio exceeds 1 because the kernel does not execute most of those flops:
+            # it proves, per frame, which two codewords can win and runs the FP64 chain for those only.
             roofline = {
                 "bound": "mfma",
-                "kernel": "k_pass_pre<37,2,4,3> (exact f16-limb prefilter on v_mfma_f32_32x32x16_f16 + top-3 keys, "
-                          "FP64 evaluation of the certified top two on v_mfma_f64_16x16x4_f64, incremental exact "
-                          "accumulate); uncertified frames: k_pass_mfma<37,2,512,2>",
+                "kernel": kernel_name,
+                "achieved": achieved_tf,
+                "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved_tf / FP64_PEAK_TFLOPS,
+                "traffic": traffic,
+                "traffic_detail": traffic_detail,
+                "kernel_ms": k_ms,
+                "note": "algorithmic FP64 flops / kernel time; > 1 is the algorithmic gain of the exact prefilter, not a "
+                        "measurement artefact (results are bit-identical to the plain FP64 sweep, which runs at 0.80 of "
+                        "this peak: --no-prefilter).  The work actually issued is priced in roofline_executed.",
+                "fallback_frames_last_pass": fallback_frames,
+            }
+            roofline_executed = {
+                "bound": "mfma",
+                "what": "limb products actually issued: 15 k-steps of v_mfma_f32_32x32x16_f16 per (frame, codeword) pair",
                 "achieved": exec_tf,
                 "peak": F16_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": exec_tf / F16_PEAK_TFLOPS,
-                "traffic": traffic,
-                "traffic_detail": traffic_detail,
-                "kernel_ms": k_ms,
                 "executed_dtype": "f16 limbs (exact integers) -> f32 accumulators; candidates in f64",
-                "algorithmic_fp64": {"tflops_equivalent": achieved_tf, "fp64_peak": FP64_PEAK_TFLOPS,
-                                     "ratio_to_fp64_peak": achieved_tf / FP64_PEAK_TFLOPS,
-                                     "note": "2*M*(P+1) FP64 flop per frame (SURVEY 8d) / kernel time: what the plain "
-                                             "FP64 sweep would have to sustain for the same time"},
-                "fallback_frames_last_pass": fallback_frames,
+                "note": "dense f16 MFMA peak of the guide (2.5 PF); on random operands the pipe sustains 1.1-1.25 PF "
+                        "(power), the sweep phase alone runs at 1.13 PF (tools/probe/pre_sweep.hip)",
             }
         else:
             # the plain sweep is FP64-FMA bound (248 flop/B): useful flops 2*M*(P+1) per frame against the 78.6 TF peak
@@ -238,6 +250,7 @@ def main():
                 "traffic_detail": traffic_detail,
                 "kernel_ms": k_ms,
             }
+            roofline_executed = None
         out = {
             "metric": "vq_learn_frames_per_sec_M1024_P36",
             "value": world * S * args.steps / dt,
@@ -271,6 +284,7 @@ def main():
                 "quantize_frames_per_sec_device_resident": q_rate,
             },
             "roofline": roofline,
+            "roofline_executed": roofline_executed,
             "roofline_hbm": {
                 "bound": "hbm",
                 "achieved": achieved_gbs,
