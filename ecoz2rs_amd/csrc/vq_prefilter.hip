@@ -403,8 +403,14 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_pass_pre(const double* __restri
     // Two workgroups share a CU (the second half of the grid lands on the CUs of the first).  Started together they
     // stay in lockstep -- both sweeping, then both in the memory-bound verify/accumulate phase with the matrix pipe
     // idle.  Delaying the second half by about half a block period makes the phases alternate.
-    if (stagger && blockIdx.x >= gridDim.x / 2 && nblocks > (long)WPB * gridDim.x)
-        for (int i = 0; i < stagger * MT / 8; ++i) __builtin_amdgcn_s_sleep(127);  // ~8k cycles each; a tile pair ~2k
+    if (stagger && nblocks > (long)WPB * gridDim.x) {
+        // (which workgroups share a CU is the dispatcher's business: stagger >> 8 selects the guess, for A/B runs)
+        const int how = stagger >> 8, amount = stagger & 255;
+        const bool late = how == 0 ? blockIdx.x >= gridDim.x / 2 : how == 1 ? (blockIdx.x & 1) : how == 2 ? ((blockIdx.x >> 3) & 1)
+                                                                                               : ((blockIdx.x >> 4) & 1);
+        if (late)
+            for (int i = 0; i < amount * MT / 8; ++i) __builtin_amdgcn_s_sleep(127);  // ~8k cycles each; a tile pair ~2k
+    }
 
     for (long sb = blockIdx.x; sb * WPB < nblocks; sb += gridDim.x) {
         const long b = sb * WPB + wib;

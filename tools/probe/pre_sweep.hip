@@ -144,15 +144,19 @@ __global__ __launch_bounds__(TPB) void k_pre_sweep(const h8* __restrict__ fimg, 
     }
 
     for (int t = 0; t < MT; ++t) {
+#ifndef NO_REFILL
         gload(t + 2 < MT ? t + 2 : MT - 1);
+#endif
         const h8* cur = lds + (t & 3) * TILE_E;
         h8 A[NSTEP];
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) A[s] = cur[s * 64 + lane];
         JOB(acc0, B[0], acc1, (t - 1) & 0xffff, 1)
         JOB(acc1, B[1], acc0, t, 0)
+#ifndef NO_REFILL
         lstore((t + 2) & 3);
         __syncthreads();
+#endif
     }
     {
 #pragma unroll
