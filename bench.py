@@ -205,7 +205,7 @@ def main():
             # dominant kernel: the prefiltered sweep.  Its matrix work is 15 f16 MFMA k-steps per (frame, codeword)
             # (exact integer limb products); the FP64 chain runs only for the two certified candidates of a frame.
             exec_tf = F16_MFMA_FLOP_PER_FRAME_CODEWORD * M * frames_per_launch / (k_ms * 1e-3) / 1e12
-            kernel_name = ("k_pass_pre<37,2,4,3> (exact f16-limb prefilter on v_mfma_f32_32x32x16_f16 + top-3 keys, "
+            kernel_name = ("k_pass_pre<37,2,512> (exact f16-limb prefilter on v_mfma_f32_32x32x16_f16 + top-3 keys, "
                            "FP64 evaluation of the certified top two on v_mfma_f64_16x16x4_f64, incremental exact "
                            "accumulate); uncertified frames: k_pass_mfma<37,2,512,2>")
             # by the contract: ALGORITHMIC flops of the path (2*M*(P+1) FP64 flop per frame-pass) per kernel

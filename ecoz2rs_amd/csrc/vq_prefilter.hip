@@ -360,12 +360,12 @@ __device__ __forceinline__ double pre_exact(const double (&Bft)[2 * ((((NC + 3) 
     return __shfl(v, 16 * (j & 3) + j, 64);  // the lane with q = j & 3 holds the diagonal element of frame j
 }
 
-// WPB waves per workgroup share the codeword tiles through an NSLOT-deep LDS ring.  WPB = 4, NSLOT = 3 lets two
-// workgroups live on a CU (2 x (48 KB ring + 21 KB row images)): they drift apart, so one sweeps (matrix pipe) while
-// the other verifies and accumulates (memory pipe) -- eight lock-stepped waves would all leave the matrix pipe idle
-// at the same time.
-template <int NC, int MODE, int WPB, int NSLOT>
-__global__ __launch_bounds__(64 * WPB, 2) void k_pass_pre(const double* __restrict__ blk, long T, long nblocks,
+// One wave = 64 frames, independent of every other wave (no LDS sharing, no barriers): the codeword tile images come
+// straight from L2 (512 KB at M = 1024; 16 B per lane and k-step) -- measured as fast as a workgroup-shared LDS ring
+// (tools/probe/pre_sweep.hip -DDIRECT_L2), and it lets the two waves of a SIMD drift apart so that one sweeps (matrix
+// pipe) while the other is in its latency-bound evaluate / accumulate phase.
+template <int NC, int MODE, int TPBM>
+__global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__ blk, long T, long nblocks,
                                                   const h8* __restrict__ fimg, const float* __restrict__ fg,
                                                   const h8* __restrict__ cimg, PreScalars* __restrict__ ps,
                                                   const double* __restrict__ cbq, int MT, int idxmask,
@@ -379,12 +379,11 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_pass_pre(const double* __restri
     constexpr bool TAILV = REM == 1;
     constexpr int NE = 2 * NC + 5, IMG = NE + IMG_STRIDE_PAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TPB = 64 * WPB;
-    static_assert(NSLOT >= 3 && PRE_TILE_E % TPB == 0, "ring depth / copy split");
-    h8* lds = (h8*)smem;                                     // [NSLOT][PRE_TILE_E]
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int q = lane >> 4, j = lane & 15;
-    int* img = (int*)(smem + (size_t)NSLOT * PRE_TILE_E * 16) + wib * (16 * IMG);
+    const long wave = (long)blockIdx.x * (TPBM >> 6) + wib;
+    const long nwaves = (long)gridDim.x * (TPBM >> 6);
+    int* img = (int*)smem + wib * (16 * IMG);
 
     int sh_r = 0, sh_d = 0, sh_d2 = 0;
     if constexpr (MODE != 0) {
@@ -400,51 +399,21 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_pass_pre(const double* __restri
     const float ymax1 = __int_as_float(ps->ymax_bits);
     const float relk = 2.0f / (float)(1u << (22 - __builtin_popcount(~idxmask)));  // 2 rho, rho = 2^-(22-idxbits)
 
-    // Two workgroups share a CU (the second half of the grid lands on the CUs of the first).  Started together they
-    // stay in lockstep -- both sweeping, then both in the memory-bound verify/accumulate phase with the matrix pipe
-    // idle.  Delaying the second half by about half a block period makes the phases alternate.
-    if (stagger && nblocks > (long)WPB * gridDim.x) {
-        // (which workgroups share a CU is the dispatcher's business: stagger >> 8 selects the guess, for A/B runs)
-        const int how = stagger >> 8, amount = stagger & 255;
-        const bool late = how == 0 ? blockIdx.x >= gridDim.x / 2 : how == 1 ? (blockIdx.x & 1) : how == 2 ? ((blockIdx.x >> 3) & 1)
-                                                                                               : ((blockIdx.x >> 4) & 1);
-        if (late)
-            for (int i = 0; i < amount * MT / 8; ++i) __builtin_amdgcn_s_sleep(127);  // ~8k cycles each; a tile pair ~2k
-    }
+    // Waves w and w + 4 of an 8-wave workgroup share a SIMD.  Started together they would reach their evaluate /
+    // accumulate phases together; half a block period of delay for waves 4..7 makes the phases alternate.
+    if (stagger && TPBM == 512 && nblocks >= 2 * nwaves && wib >= 4)
+        for (int i = 0; i < stagger * MT / 8; ++i) __builtin_amdgcn_s_sleep(127);  // ~8k cycles each; a tile ~2k
 
-    for (long sb = blockIdx.x; sb * WPB < nblocks; sb += gridDim.x) {
-        const long b = sb * WPB + wib;
-        const bool active = b < nblocks;
-
+    for (long b = wave; b < nblocks; b += nwaves) {
         // ---- f16 limb images of the wave's 64 frames: B operands, resident for the sweep ----------
         h8 B[2][PRE_PAIRS];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int p = 0; p < PRE_PAIRS; ++p) {
-                const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                B[cb][p] = active ? fimg[((b * 2 + cb) * PRE_PAIRS + p) * 64 + lane] : z;
-            }
+            for (int p = 0; p < PRE_PAIRS; ++p) B[cb][p] = fimg[((b * 2 + cb) * PRE_PAIRS + p) * 64 + lane];
         float k1[2], k2[2], k3[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) k1[cb] = k2[cb] = k3[cb] = __int_as_float(0x7f7fffff);
-
-        // ---- sweep: codeword tiles stream through a 4-slot LDS ring, one workgroup barrier per tile ----
-        constexpr int PER_T = PRE_TILE_E / TPB;
-        h8 pre[PER_T];
-        auto gload = [&](int t) {
-#pragma unroll
-            for (int i = 0; i < PER_T; ++i) pre[i] = cimg[(long)t * PRE_TILE_E + i * TPB + threadIdx.x];
-        };
-        auto lstore = [&](int slot) {
-#pragma unroll
-            for (int i = 0; i < PER_T; ++i) lds[slot * PRE_TILE_E + i * TPB + threadIdx.x] = pre[i];
-        };
-        gload(0);
-        lstore(0);
-        gload(MT > 1 ? 1 : 0);
-        lstore(1);
-        __syncthreads();
 
         f16v acc0[3], acc1[3];
 #pragma unroll
@@ -481,20 +450,15 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_pass_pre(const double* __restri
         }                                                                                                         \
     }
         for (int t = 0; t < MT; ++t) {
-            gload(t + 2 < MT ? t + 2 : MT - 1);
-            const h8* cur = lds + (t % NSLOT) * PRE_TILE_E;
             h8 A[PRE_NSTEP];
 #pragma unroll
-            for (int s = 0; s < PRE_NSTEP; ++s) A[s] = cur[s * 64 + lane];
+            for (int s = 0; s < PRE_NSTEP; ++s) A[s] = cimg[(long)t * PRE_TILE_E + s * 64 + lane];
             E2VQ_PRE_JOB(acc0, B[0], acc1, (t - 1) & 0xffff, 1)  // (t = 0: the "previous" accumulators hold 3e38)
             E2VQ_PRE_JOB(acc1, B[1], acc0, t, 0)
-            lstore((t + 2) % NSLOT);
-            __syncthreads();
         }
         E2VQ_PRE_EPILOGUE(acc1, MT - 1, 1)
 #undef E2VQ_PRE_JOB
 #undef E2VQ_PRE_EPILOGUE
-        if (!active) continue;
 
         // ---- per frame: merge the two lane halves (rows 4h..4h+3 of every 8), certify the top two -------------
         int c1[2], c2[2];
@@ -676,23 +640,23 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
 {
     if (!prefilter_supports(NC, M)) return 1;
     constexpr int IMG = 2 * 37 + 5 + IMG_STRIDE_PAD;
-    constexpr int WPB = 4, NSLOT = 3;
-    const size_t lds = (size_t)NSLOT * PRE_TILE_E * 16 + (size_t)WPB * 16 * IMG * 4;
+    constexpr int TPBM = 512;  // 8 waves = 2 per SIMD, one persistent workgroup per CU
+    const size_t lds = (size_t)(TPBM / 64) * 16 * IMG * 4;
     int bits = 0;
     while ((1 << bits) < M) ++bits;
     const int idxmask = ~((1 << bits) - 1);
-    const int grid = pre_grid(nblocks, WPB, 512);  // two persistent 4-wave workgroups per CU
+    const int grid = pre_grid(nblocks, TPBM / 64, 256);
     static const int stagger = getenv("ECOZ2_VQ_PRE_STAGGER") ? atoi(getenv("ECOZ2_VQ_PRE_STAGGER")) : 1;
     if (accumulate) {
-        (void)hipFuncSetAttribute((const void*)k_pass_pre<37, 2, WPB, NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)k_pass_pre<37, 2, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
-        hipLaunchKernelGGL((k_pass_pre<37, 2, WPB, NSLOT>), dim3(grid), dim3(64 * WPB), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
+        hipLaunchKernelGGL((k_pass_pre<37, 2, TPBM>), dim3(grid), dim3(TPBM), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
                            dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0);
     } else {
-        (void)hipFuncSetAttribute((const void*)k_pass_pre<37, 0, WPB, NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)k_pass_pre<37, 0, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
-        hipLaunchKernelGGL((k_pass_pre<37, 0, WPB, NSLOT>), dim3(grid), dim3(64 * WPB), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
+        hipLaunchKernelGGL((k_pass_pre<37, 0, TPBM>), dim3(grid), dim3(TPBM), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
                            dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0);
     }

@@ -149,8 +149,14 @@ __global__ __launch_bounds__(TPB) void k_pre_sweep(const h8* __restrict__ fimg, 
 #endif
         const h8* cur = lds + (t & 3) * TILE_E;
         h8 A[NSTEP];
+#ifdef DIRECT_L2
+        (void)cur;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) A[s] = cimg[(long)t * TILE_E + s * 64 + lane];
+#else
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) A[s] = cur[s * 64 + lane];
+#endif
         JOB(acc0, B[0], acc1, (t - 1) & 0xffff, 1)
         JOB(acc1, B[1], acc0, t, 0)
 #ifndef NO_REFILL
