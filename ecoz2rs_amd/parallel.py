@@ -40,9 +40,14 @@ def reduce_int64_(t, op, group=None):
 def make_allreduce(device_index, group=None):
     """Hook for VqSession.set_allreduce: reduces `count` int64 at device address `ptr` in place."""
     backend = dist.get_backend(group)
+    views = {}  # (ptr, count) -> tensor view: the session reduces the same few buffers every iteration
 
     def hook(ptr, count, op, _stream):
-        t = torch.as_tensor(_DeviceBuffer(ptr, count), device=f"cuda:{device_index}")
+        t = views.get((ptr, count))
+        if t is None:
+            if len(views) > 64:
+                views.clear()
+            t = views[(ptr, count)] = torch.as_tensor(_DeviceBuffer(ptr, count), device=f"cuda:{device_index}")
         if backend == "nccl":
             reduce_int64_(t, op, group)  # RCCL, ordered after the session's work on the current stream
         else:
