@@ -60,6 +60,27 @@ __device__ __forceinline__ int mini(int a, int b)
 }
 
 __device__ __forceinline__ float med3f(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+// epilogue ablations (EPI != 0 gives wrong results; they price the instructions beside the MFMA stream)
+#ifndef EPI
+#define EPI 0
+#endif
+#if EPI == 4
+#define EPI_V(PREV) const float v = r == 0 ? PREV[0][r] + PREV[1][r] + PREV[2][r] : PREV[r % 3][r]; (void)sidx;
+#else
+#define EPI_V(PREV) const float v = __builtin_fmaf(PREV[0][r], 262144.f, __builtin_fmaf(PREV[1][r], 512.f, PREV[2][r])); \
+                    const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);
+#endif
+#if EPI == 0   // product: three v_med3_f32
+#define EPI_UPDATE(PCB) k3[PCB] = med3f(k2[PCB], k3[PCB], key); k2[PCB] = med3f(k1[PCB], k2[PCB], key); k1[PCB] = med3f(k1[PCB], key, ninf);
+#elif EPI == 1 // min only
+#define EPI_UPDATE(PCB) k1[PCB] = __builtin_fminf(k1[PCB], key);
+#elif EPI == 3 // VOP2 min/max insertion network (5 ops)
+#define EPI_UPDATE(PCB) { const float u_ = __builtin_fmaxf(k1[PCB], key); k1[PCB] = __builtin_fminf(k1[PCB], key); const float w_ = __builtin_fmaxf(k2[PCB], u_); k2[PCB] = __builtin_fminf(k2[PCB], u_); k3[PCB] = __builtin_fminf(k3[PCB], w_); }
+#elif EPI == 4 // (with EPI_SKIP) nearly nothing: one min per register
+#define EPI_UPDATE(PCB) k1[PCB] = __builtin_fminf(k1[PCB], v);
+#elif EPI == 5 // top-2 only (2 med3)
+#define EPI_UPDATE(PCB) k2[PCB] = med3f(k1[PCB], k2[PCB], key); k1[PCB] = med3f(k1[PCB], key, ninf);
+#endif
 
 // keys are compared as floats (v_min/v_med3_f32): positive keys order like their bit patterns
 __global__ __launch_bounds__(TPB) void k_pre_sweep(const h8* __restrict__ fimg, long nblk32, const h8* __restrict__ cimg,
@@ -130,11 +151,8 @@ __global__ __launch_bounds__(TPB) void k_pre_sweep(const h8* __restrict__ fimg, 
         _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                              \
         {                                                                                                           \
             const int sidx = __builtin_amdgcn_readfirstlane((PTILE) * 32 + 8 * (r >> 2) + (r & 3));                 \
-            const float v = __builtin_fmaf(PREV[0][r], 262144.f, __builtin_fmaf(PREV[1][r], 512.f, PREV[2][r]));   \
-            const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);                                   \
-            k3[PCB] = med3f(k2[PCB], k3[PCB], key);                                                                 \
-            k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                                 \
-            k1[PCB] = med3f(k1[PCB], key, ninf);                                                                    \
+            EPI_V(PREV)                                                                                             \
+            EPI_UPDATE(PCB)                                                                                         \
         }                                                                                                           \
         _Pragma("unroll") for (int s = 0; s < NSTEP; ++s)                                                           \
         {                                                                                                           \
@@ -149,7 +167,14 @@ __global__ __launch_bounds__(TPB) void k_pre_sweep(const h8* __restrict__ fimg, 
 #endif
         const h8* cur = lds + (t & 3) * TILE_E;
         h8 A[NSTEP];
-#ifdef DIRECT_L2
+#ifdef A_RESIDENT  // ablation: no operand traffic at all (wrong results), the bare MFMA + epilogue loop
+        (void)cur;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            A[s] = B[0][s % 7];
+            asm volatile("" : "+v"(A[s]));
+        }
+#elif defined(DIRECT_L2)
         (void)cur;
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) A[s] = cimg[(long)t * TILE_E + s * 64 + lane];
