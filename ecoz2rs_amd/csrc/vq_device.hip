@@ -212,6 +212,9 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
     // many waves, each a quarter of the latency of a full 64-frame sweep
     constexpr int NFT = SRC == 2 ? 1 : 4;
     constexpr int FPB = 16 * NFT;
+    // ... and the waves of a workgroup split the codebook of ONE tile between them (the list is latency-bound: a
+    // single wave walking all M / 16 codeword tiles takes ~50 us at M = 1024), then combine through LDS
+    constexpr int SPLIT = SRC == 2 ? TPBM / 64 : 1;
     if constexpr (SRC == 2) {
         T = *fb_count;
         nblocks = (T + FPB - 1) / FPB;
@@ -230,8 +233,8 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, j = lane & 15;
     const int wib = threadIdx.x >> 6;
-    const long wave = (long)blockIdx.x * (TPBM >> 6) + wib;
-    const long nwaves = (long)gridDim.x * (TPBM >> 6);
+    const long wave = SPLIT > 1 ? (long)blockIdx.x : (long)blockIdx.x * (TPBM >> 6) + wib;
+    const long nwaves = SPLIT > 1 ? (long)gridDim.x : (long)gridDim.x * (TPBM >> 6);
 
     int sh_r = 0, sh_d = 0, sh_d2 = 0;
     if constexpr (MODE != 0) {
@@ -385,17 +388,20 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             }
         };
         {
+            // this wave's share of the codeword tiles (all of them unless the workgroup splits the codebook)
+            const int ct0 = SPLIT > 1 ? (int)((long)wib * MT / SPLIT) : 0;
+            const int ct1 = SPLIT > 1 ? (int)((long)(wib + 1) * MT / SPLIT) : MT;
             double2 A0[NP], A1[NP];
             d4 T0 = {0.0, 0.0, 0.0, 0.0}, T1 = {0.0, 0.0, 0.0, 0.0};
-            load_tile(0, A0, T0);
-            int ct = 0;
-            for (; ct + 1 < MT; ct += 2) {
+            int ct = ct0;
+            if (ct < ct1) load_tile(ct, A0, T0);
+            for (; ct + 1 < ct1; ct += 2) {
                 load_tile(ct + 1, A1, T1);
                 do_tile(ct, A0, T0);
-                load_tile(ct + 2 < MT ? ct + 2 : ct + 1, A0, T0);
+                load_tile(ct + 2 < ct1 ? ct + 2 : ct + 1, A0, T0);
                 do_tile(ct + 1, A1, T1);
             }
-            if (ct < MT) do_tile(ct, A0, T0);
+            if (ct < ct1) do_tile(ct, A0, T0);
         }
 
         // ---- combine the four lanes (q = 0..3) that hold one frame: min value, lowest index ---
@@ -410,6 +416,26 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                 const bool take = ob < best[ft] || (ob == best[ft] && oi < idx[ft]);
                 best[ft] = take ? ob : best[ft];
                 idx[ft] = take ? oi : idx[ft];
+            }
+        }
+
+        if constexpr (SPLIT > 1) {
+            // codebook split: wave 0 collects the partial (min, index) pairs of its partners (double-buffered by
+            // iteration parity, so one barrier per block suffices), the others go on to the next block
+            const long it = (b - wave) / nwaves;
+            double* xb = (double*)(smem + (size_t)SPLIT * 16 * IMG * 4) + (it & 1) * (SPLIT * 64);
+            int* xi = (int*)(smem + (size_t)SPLIT * 16 * IMG * 4 + (size_t)2 * SPLIT * 64 * 8) + (it & 1) * (SPLIT * 64);
+            xb[wib * 64 + lane] = best[0];
+            xi[wib * 64 + lane] = idx[0];
+            __syncthreads();
+            if (wib != 0) continue;
+#pragma unroll
+            for (int w = 1; w < SPLIT; ++w) {
+                const double ob = xb[w * 64 + lane];
+                const int oi = xi[w * 64 + lane];
+                const bool take = ob < best[0] || (ob == best[0] && oi < idx[0]);
+                best[0] = take ? ob : best[0];
+                idx[0] = take ? oi : idx[0];
             }
         }
 
@@ -1088,12 +1114,14 @@ int launch_pass_fallback(int NC, bool accumulate, const double* blk, const doubl
     if (NC != 37) return 1;
     constexpr int IMG = 2 * 37 + 5 + IMG_STRIDE_PAD;
     const int MT = (M + 15) / 16;
+    // one 4-wave workgroup per 16 listed frames at a time; LDS: the waves' row images + the (min, index) exchange
+    const size_t lds = (size_t)4 * 16 * IMG * 4 + (size_t)2 * 4 * 64 * (8 + 4);
     if (accumulate)
-        hipLaunchKernelGGL((k_pass_mfma<37, 2, 512, 2>), dim3(256), dim3(512), (size_t)8 * 16 * IMG * 4, s, blk, 0L, 0L, cbm,
-                           MT, M, sc, l1max_bits, sym, dmin, rows, 0, fb_list, fb_count, prev_sym, incremental ? 1 : 0);
+        hipLaunchKernelGGL((k_pass_mfma<37, 2, 256, 2>), dim3(1024), dim3(256), lds, s, blk, 0L, 0L, cbm, MT, M, sc,
+                           l1max_bits, sym, dmin, rows, 0, fb_list, fb_count, prev_sym, incremental ? 1 : 0);
     else
-        hipLaunchKernelGGL((k_pass_mfma<37, 0, 256, 2>), dim3(512), dim3(256), 0, s, blk, 0L, 0L, cbm, MT, M, sc, l1max_bits,
-                           sym, dmin, rows, 0, fb_list, fb_count);
+        hipLaunchKernelGGL((k_pass_mfma<37, 0, 256, 2>), dim3(1024), dim3(256), lds, s, blk, 0L, 0L, cbm, MT, M, sc,
+                           l1max_bits, sym, dmin, rows, 0, fb_list, fb_count);
     return 0;
 }
 
