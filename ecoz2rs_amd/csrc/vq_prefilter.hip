@@ -1,11 +1,12 @@
-// vq_prefilter.hip -- the prefiltered sweep: same results as the FP64 sweep (bit for bit), ~1/3 of its time.
+// vq_prefilter.hip -- the prefiltered sweep: same results as the FP64 sweep (bit for bit), about half its time.
 //
 // Idea.  argmin_m d(r, c_m) needs the FP64 chain only for the codewords that can win.  A cheap approximation
 // d~ with a PROVEN error bound eps finds them: every codeword whose d~ exceeds the smallest d~ by more than
 // 2 eps is out.  The approximation runs on the f16 matrix pipe and is made of exact integer arithmetic, so the
 // bound needs no assumption about the hardware's summation order:
 //
-//   * per coefficient n a power of two a_n >= max_t |r_t[n]| (data statistic), per frame a power of two A_t,
+//   * per coefficient n a power of two a_n (vq learn: > max_t |r_t[n]|, one scan per upload; vq quantize: from the
+//     codebook, so that no pass over the data is needed), per frame a power of two A_t,
 //     per codebook a power of two C:   xi = r / (a A_t),  eta = c a / C,  both in (-1, 1),  d = A_t C sum xi eta
 //   * xi -> three integer limbs  X1 = rint(xi 2^9) (|X1| <= 512), X2, X3 (|.| <= 256):
 //         xi = X1 2^-9 + X2 2^-18 + X3 2^-27 + rho,  |rho| <= 2^-28;   eta likewise (Y1, Y2, Y3, sigma)
