@@ -56,6 +56,11 @@ class _DeviceBuffer:
         assert self.hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), self.ptr, C.c_size_t(self.nbytes), 2) == 0  # D2H
         return out
 
+    def from_host(self, array, offset=0):
+        a = np.ascontiguousarray(array)
+        dst = C.c_void_p(self.ptr.value + offset)
+        assert self.hip.hipMemcpy(dst, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0  # H2D
+
     def free(self):
         self.hip.hipFree(self.ptr)
 
@@ -219,3 +224,25 @@ def test_quantize_through_the_prefilter_bit_exact(oracle, monkeypatch, T, M):
         sym, dmin = s.quantize(frames)
     assert np.array_equal(sym, sym_o)
     assert np.array_equal(dmin.view(np.uint64), dmin_o.view(np.uint64))
+
+
+@pytest.mark.parametrize("prefilter", [True, False])
+@pytest.mark.parametrize("offset", [0, 8])
+def test_quantize_device_payload_alignment(oracle, monkeypatch, prefilter, offset):
+    """Device-resident quantize of a payload that is 16-byte aligned (read in place) or only 8-byte aligned
+    (re-laid into a blocked copy first), with and without the prefiltered sweep."""
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER", "1" if prefilter else "0")
+    T, M = 5003, 256
+    frames = _frames(20259, T)
+    refl = _codebook(oracle, frames, M, seed=10)
+    sym_o, dmin_o = oracle.quantize(oracle.reflections_to_cq(refl), frames)
+    payload, sym, dmin = _DeviceBuffer(frames.nbytes + 16), _DeviceBuffer(2 * T), _DeviceBuffer(8 * T)
+    payload.from_host(frames, offset)
+    with e.VqSession(P) as s:
+        s.set_codebook(refl)
+        s.quantize_device(payload.ptr.value + offset, T, sym.ptr.value, dmin.ptr.value)
+        s.synchronize()
+    assert np.array_equal(sym.to_host(np.uint16), sym_o)
+    assert np.array_equal(dmin.to_host(np.float64).view(np.uint64), dmin_o.view(np.uint64))
+    for b in (payload, sym, dmin):
+        b.free()
