@@ -338,12 +338,26 @@ extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames
         s->d_fimg = nullptr;
         s->d_fg = nullptr;
         s->d_fblist = nullptr;
-        HIPCHK(hipMalloc(&s->d_fimg, e2vq::prefilter_frame_image_bytes(s->nblocks)));
-        HIPCHK(hipMalloc(&s->d_fg, (size_t)s->nblocks * 64 * sizeof(float)));
-        HIPCHK(hipMalloc(&s->d_fblist, (size_t)s->nblocks * 64 * sizeof(int)));
-        HIPCHK(hipMalloc(&s->d_prev_sym, (size_t)s->nblocks * 64 * sizeof(unsigned short)));
-        e2vq::launch_prefilter_frames(s->d_blk, T, s->nblocks, s->NC, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->stream);
-        HIPCHK(hipGetLastError());
+        // 234 B per frame beside the 296 B of the blocked frames.  If the device cannot hold them, the session
+        // simply keeps to the plain FP64 sweep (same results): use_prefilter() looks at d_fimg.
+        const bool fits = hipMalloc(&s->d_fimg, e2vq::prefilter_frame_image_bytes(s->nblocks)) == hipSuccess &&
+                          hipMalloc(&s->d_fg, (size_t)s->nblocks * 64 * sizeof(float)) == hipSuccess &&
+                          hipMalloc(&s->d_fblist, (size_t)s->nblocks * 64 * sizeof(int)) == hipSuccess &&
+                          hipMalloc(&s->d_prev_sym, (size_t)s->nblocks * 64 * sizeof(unsigned short)) == hipSuccess;
+        if (fits) {
+            e2vq::launch_prefilter_frames(s->d_blk, T, s->nblocks, s->NC, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg,
+                                          s->stream);
+            HIPCHK(hipGetLastError());
+        } else {
+            (void)hipGetLastError();  // clear the out-of-memory status
+            for (void** p : {(void**)&s->d_fimg, (void**)&s->d_fg, (void**)&s->d_fblist, (void**)&s->d_prev_sym}) {
+                if (*p) (void)hipFree(*p);
+                *p = nullptr;
+            }
+            if (!getenv("ECOZ2_VQ_QUIET"))
+                fprintf(stderr, "ecoz2vq: no room for the prefilter images of %lld frames; using the plain FP64 sweep\n",
+                        (long long)T);
+        }
     }
     s->prepared = false;
     s->stats_valid = false;

@@ -483,6 +483,16 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             c2[cb] = __float_as_int(u2) & ~idxmask;
         }
 
+        // cells of the previous pass (incremental accumulation): loaded here, with the frames, not after the evaluation
+        int oldidx[4] = {0, 0, 0, 0};
+        if (MODE != 0 && incr) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const long t = b * 64 + 16 * ft + j;
+                oldidx[ft] = t < T ? prev_sym[t] : 0;
+            }
+        }
+
         // ---- FP64 frames (MFMA operand layout of k_pass_mfma), exact evaluation of the two candidates -----------
         double Bf[4][2 * NP];
         const double* fb = blk + b * (long)(NC * 64);
@@ -548,15 +558,9 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             for (int ft = 0; ft < 4; ++ft) idx[ft] = skip[ft] ? 0 : idx[ft];
         }
 
-        // cells of the previous pass (incremental accumulation); frames left to the fallback change nothing here
-        int oldidx[4] = {0, 0, 0, 0};
-        if (MODE != 0 && incr) {
+        // (frames left to the fallback change nothing here: their old cell is taken as their new one, 0)
 #pragma unroll
-            for (int ft = 0; ft < 4; ++ft) {
-                const long t = b * 64 + 16 * ft + j;
-                oldidx[ft] = (t < T && !skip[ft]) ? prev_sym[t] : 0;
-            }
-        }
+        for (int ft = 0; ft < 4; ++ft) oldidx[ft] = skip[ft] ? 0 : oldidx[ft];
 
         // ---- outputs: lane 16q + j owns frame b*64 + lane; uncertified frames go to the fallback list ---------
         {
