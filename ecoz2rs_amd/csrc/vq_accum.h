@@ -58,9 +58,11 @@ __device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((N
 #pragma unroll
     for (int ft = 0; ft < NFT; ++ft) {
         int* my = img + j * IMG;
+        // incremental pass: the limbs are needed only if a frame of this tile changed cell (wave-uniform test)
+        const bool limbs = !INCR || !incr || __ballot(oldidx[ft] != idx[ft]) != 0;
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
-            if (st < NS - 1 || q < REM) {  // with TAILV only q = 0 writes r[NC-1] (all q lanes hold it)
+            if (limbs && (st < NS - 1 || q < REM)) {  // with TAILV only q = 0 writes r[NC-1] (all q lanes hold it)
                 int hi, lo;
                 fix2(Bf[ft][st], sh_r, hi, lo);
                 if (SKIP && skip[ft]) hi = lo = 0;
