@@ -37,10 +37,10 @@ def counters(path, W, K):
 kt = newest(f"{SRC}/prof_pf_kt/*/*_kernel_trace.csv")
 sel = pre_rows(kt)[9:29]
 d = [ms(r) for r in sel]
-fb = [r for r in csv.DictReader(open(kt)) if "k_pass_mfma<37, 2, 512, 2>" in r["Kernel_Name"]][9:29]
+fb = [r for r in csv.DictReader(open(kt)) if "k_pass_mfma<37, 2, 256, 2>" in r["Kernel_Name"]][9:29]
 out = {"kernel": "e2vq::k_pass_pre<37, 2, 512>", "dispatches": len(d), "avg_ms": sum(d) / len(d), "min_ms": min(d),
        "max_ms": max(d), "vgpr": sel[0].get("VGPR_Count"), "accum_vgpr": sel[0].get("Accum_VGPR_Count"),
-       "lds_bytes": sel[0].get("LDS_Block_Size"), "fallback_kernel": "e2vq::k_pass_mfma<37, 2, 512, 2>",
+       "lds_bytes": sel[0].get("LDS_Block_Size"), "fallback_kernel": "e2vq::k_pass_mfma<37, 2, 256, 2>",
        "fallback_kernel_avg_ms": sum(ms(r) for r in fb) / len(fb),
        "source": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --steps 20; "
                  "the timed steps are k_pass_pre dispatches 9..28"}
