@@ -136,6 +136,7 @@ struct e2vq_session {
     // incremental accumulation (prefiltered passes): the rank's own rows and every frame's cell persist between
     // passes of one codebook size; a pass then moves only the frames whose cell changed (vq_accum.h)
     bool incr_enabled = true, incr_valid = false;
+    bool plain_first = true;  // first (full) pass of the smallest prefiltered levels on the plain hybrid kernel
     int incr_M = 0;
     unsigned short* d_prev_sym = nullptr;
     i64* d_rows_local = nullptr;  // world > 1: the un-reduced rows (d_rows holds the all-reduced copy)
@@ -223,6 +224,7 @@ static int session_init(e2vq_session* s)
     s->pre_enabled = e2vq::prefilter_supports(s->NC, 64) && !(pf && atoi(pf) == 0);
     if (const char* mm = getenv("ECOZ2_VQ_PREFILTER_MIN_M")) s->pre_min_M = std::max(64, atoi(mm));
     if (const char* inc = getenv("ECOZ2_VQ_INCREMENTAL")) s->incr_enabled = atoi(inc) != 0;
+    if (const char* pf1 = getenv("ECOZ2_VQ_PLAIN_FIRST")) s->plain_first = atoi(pf1) != 0;
     if (s->pre_enabled) {
         HIPCHK(hipMalloc(&s->d_colmax, (size_t)s->NC * 8));
         HIPCHK(hipMalloc(&s->d_ea, (size_t)s->NC * sizeof(int)));
@@ -537,7 +539,24 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         e2vq::launch_zero_distortion_columns(rows, s->M, s->NC, s->stream);
     else if (mode != 0)
         HIPCHK(hipMemsetAsync(rows, 0, (size_t)s->M * s->RS * 8, s->stream));
-    if (s->last_prefiltered) {
+    // The first pass of a level accumulates in full.  For the smallest prefiltered sizes that is cheaper on the plain
+    // FP64 sweep with its workgroup-local LDS table (hybrid accumulate: 0.92 vs 1.5 ms at M = 256, where 2^21 frames
+    // hammer 256 rows with global atomics); it records the cells for the incremental passes that follow.
+    const bool plain_first = s->plain_first && keep && !incremental && mode == 5 && s->M <= 384;
+    if (plain_first) {
+        unsigned short* sym_out = device_sym ? (unsigned short*)device_sym : s->d_prev_sym;
+        if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
+        e2vq::launch_pass(s->NC, mode, s->d_blk, s->T, s->nblocks, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max, sym_out,
+                          (double*)device_dmin, rows, s->stream);
+        if (s->timing) {
+            HIPCHK(hipEventRecord(s->ev1, s->stream));
+            s->timed = true;
+        }
+        if (sym_out != s->d_prev_sym)
+            HIPCHK(hipMemcpyAsync(s->d_prev_sym, sym_out, (size_t)s->T * sizeof(unsigned short), hipMemcpyDeviceToDevice,
+                                  s->stream));
+        s->last_prefiltered = false;
+    } else if (s->last_prefiltered) {
         // f16 limb image of the current codebook, prefiltered sweep (exact evaluation of the certified top two),
         // then the full FP64 sweep of whatever it could not certify
         if (ensure_codebook_image(s)) return 1;

@@ -82,6 +82,7 @@ int ecoz2_vq_classify(const char *const *cb_filenames, int num_codebooks,
  *   ECOZ2_VQ_GPUS               vq learn only: shard over this many in-process ranks / GPUs (default 1)
  *   ECOZ2_VQ_PREFILTER          0 = every pass on the FP64 sweep (default 1: prefiltered sweep for P = 36, M >= 256)
  *   ECOZ2_VQ_PREFILTER_MIN_M    smallest codebook the prefiltered sweep serves (default 256, at least 64)
+ *   ECOZ2_VQ_INCREMENTAL        0 = accumulate in full every pass; ECOZ2_VQ_PLAIN_FIRST 0 = no plain first pass
  *   ECOZ2_VQ_OUT_ROOT           prefix for data/... outputs (default ".")               */
 
 /* ========================================================================================

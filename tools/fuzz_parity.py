@@ -61,6 +61,7 @@ def main():
 def fuzz_prefilter(n, rng, oracle):
     os.environ["ECOZ2_VQ_PREFILTER"] = "1"
     os.environ["ECOZ2_VQ_PREFILTER_MIN_M"] = "64"
+    os.environ["ECOZ2_VQ_PLAIN_FIRST"] = "0"
     P, bad, fallback, frames_total, t0 = 36, 0, 0, 0, time.time()
     for case in range(n):
         T = int(rng.choice([rng.integers(1, 300), rng.integers(300, 8000), rng.integers(8000, 30000)]))
