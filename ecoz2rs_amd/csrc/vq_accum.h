@@ -32,6 +32,34 @@ __host__ __device__ __forceinline__ long mfma_blk_offset(int NC, long t, int n)
     return b * (long)NC * 64 + (long)u * NC * 32 + x;
 }
 
+// The 64 frames of block b from the blocked layout into the FP64 MFMA B operands: Bf[ft][st], lane (q, j), holds
+// r[frame 16 ft + j][4 st + q]; with NC = 4k+1 every q lane holds r[NC-1] in the last slot (it is applied on the VALU).
+template <int NC>
+__device__ __forceinline__ void load_block_frames(const double* __restrict__ blk, long b, int lane,
+                                                  double (&Bf)[4][2 * ((((NC + 3) / 4) + 1) / 2)])
+{
+    constexpr int NS = (NC + 3) / 4, REM = NC - 4 * (NS - 1);
+    const int q = lane >> 4, j = lane & 15;
+    const double* fb = blk + b * (long)(NC * 64);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const double* base = fb + u * (NC * 32);
+#pragma unroll
+        for (int st = 0; st < NS - 1; ++st) {
+            const double2 v = *(const double2*)(base + (st * 64 + lane) * 2);
+            Bf[2 * u][st] = v.x;
+            Bf[2 * u + 1][st] = v.y;
+        }
+        double2 v = make_double2(0.0, 0.0);
+        if (REM == 1)  // every lane of frame j keeps r[NC-1] (the four q lanes read the same 16 B)
+            v = *(const double2*)(base + (NS - 1) * 128 + j * 2);
+        else if (q < REM)
+            v = *(const double2*)(base + (NS - 1) * 128 + (q * 16 + j) * 2);
+        Bf[2 * u][NS - 1] = v.x;
+        Bf[2 * u + 1][NS - 1] = v.y;
+    }
+}
+
 // Bf[ft][st]: lane (q, j) holds r[frame 16 ft + j][4 st + q] (with NC = 4k+1 every q lane holds r[NC-1] in the
 // last slot); best / idx: min distortion and cell of frame 16 ft + j, in all four q lanes.  img: this wave's 16 row
 // images in LDS.  MODE 1: all cells in the LDS table lacc; 5: cells < lds_cells there; 2: global atomics; 3: none.

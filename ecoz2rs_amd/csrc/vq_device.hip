@@ -318,23 +318,8 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                     Bf[ft][st] = (t >= 0 && n >= 0) ? blk[mfma_blk_offset(NC, t, n)] : 0.0;
                 }
             }
-        } else
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const double* base = fb + u * (NC * 32);
-#pragma unroll
-            for (int st = 0; st < NS - 1; ++st) {
-                const double2 v = *(const double2*)(base + (st * 64 + lane) * 2);
-                Bf[2 * u][st] = v.x;
-                Bf[2 * u + 1][st] = v.y;
-            }
-            double2 v = make_double2(0.0, 0.0);
-            if (TAILV)  // every lane of frame j keeps r[NC-1] (the four q lanes read the same 16 B)
-                v = *(const double2*)(base + (NS - 1) * 128 + j * 2);
-            else if (q < REM)
-                v = *(const double2*)(base + (NS - 1) * 128 + (q * 16 + j) * 2);
-            Bf[2 * u][NS - 1] = v.x;
-            Bf[2 * u + 1][NS - 1] = v.y;
+        } else {
+            load_block_frames<NC>(blk, b, lane, Bf);
         }
 
         // ---- sweep: 16 codewords x 16 frames per MFMA, k ascending = canonical chain -------

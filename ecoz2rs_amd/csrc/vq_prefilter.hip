@@ -376,8 +376,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
                                                   unsigned short* __restrict__ prev_sym, int incr)
 {
     static_assert(NC == 37, "the K-slot packing of the prefilter is laid out for P = 36");
-    constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2, REM = NC - 4 * (NS - 1);
-    constexpr bool TAILV = REM == 1;
+    constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2;
     constexpr int NE = 2 * NC + 5, IMG = NE + IMG_STRIDE_PAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -495,24 +494,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 
         // ---- FP64 frames (MFMA operand layout of k_pass_mfma), exact evaluation of the two candidates -----------
         double Bf[4][2 * NP];
-        const double* fb = blk + b * (long)(NC * 64);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const double* base = fb + u * (NC * 32);
-#pragma unroll
-            for (int st = 0; st < NS - 1; ++st) {
-                const double2 v = *(const double2*)(base + (st * 64 + lane) * 2);
-                Bf[2 * u][st] = v.x;
-                Bf[2 * u + 1][st] = v.y;
-            }
-            double2 v = make_double2(0.0, 0.0);
-            if (TAILV)
-                v = *(const double2*)(base + (NS - 1) * 128 + j * 2);
-            else if (q < REM)
-                v = *(const double2*)(base + (NS - 1) * 128 + (q * 16 + j) * 2);
-            Bf[2 * u][NS - 1] = v.x;
-            Bf[2 * u + 1][NS - 1] = v.y;
-        }
+        load_block_frames<NC>(blk, b, lane, Bf);
         double best[4];
         int idx[4];
         bool skip[4];
