@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -89,7 +90,8 @@ struct e2vq_session {
     u64* d_l1max_spec = nullptr;
     bool spec_valid = false;
     hipEvent_t ev_stats = nullptr;
-    struct HostStats { i64 l[64 * 8]; u64 l1bits; }* h_stats = nullptr;  // pinned
+    struct HostStats { i64 l[64 * 8]; u64 l1bits; volatile u64 seq; }* h_stats = nullptr;  // pinned, host-mapped
+    u64 stats_seq = 0;
     double* h_within = nullptr;                                      // pinned, M_cap doubles
     // statistics
     DevScalars* d_sc = nullptr;
@@ -159,7 +161,7 @@ static int ensure_codebook_capacity(e2vq_session* s, int M)
     HIPCHK(hipMalloc(&cbq, (size_t)cap * s->NPAD * 8 + 512));
     HIPCHK(hipMalloc(&refl_spec, (size_t)cap * s->NC * 8));
     HIPCHK(hipMalloc(&cbq_spec, (size_t)cap * s->NPAD * 8 + 512));
-    HIPCHK(hipHostMalloc(&hw, (size_t)cap * 8));
+    HIPCHK(hipHostMalloc(&hw, (size_t)cap * 8, hipHostMallocMapped | hipHostMallocCoherent));
     if (e2vq::uses_mfma(s->NC)) {
         HIPCHK(hipMalloc(&cbm, (size_t)e2vq::cbm_doubles(s->NC, cap) * 8));
         HIPCHK(hipMalloc(&cbm_spec, (size_t)e2vq::cbm_doubles(s->NC, cap) * 8));
@@ -218,7 +220,8 @@ static int session_init(e2vq_session* s)
     HIPCHK(hipEventCreate(&s->ev1));
     HIPCHK(hipEventCreateWithFlags(&s->ev_stats, hipEventDisableTiming));
     HIPCHK(hipMalloc(&s->d_l1max_spec, 8));
-    HIPCHK(hipHostMalloc(&s->h_stats, sizeof(*s->h_stats)));
+    HIPCHK(hipHostMalloc(&s->h_stats, sizeof(*s->h_stats), hipHostMallocMapped | hipHostMallocCoherent));
+    s->h_stats->seq = 0;
     // ECOZ2_VQ_PREFILTER=0 keeps every pass on the FP64 sweep; ECOZ2_VQ_PREFILTER_MIN_M moves the switch-over size
     const char* pf = getenv("ECOZ2_VQ_PREFILTER");
     s->pre_enabled = e2vq::prefilter_supports(s->NC, 64) && !(pf && atoi(pf) == 0);
@@ -640,9 +643,15 @@ extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
                                  s->d_cbm_spec, s->d_l1max_spec, s->d_within, s->d_lstats, s->stream);
     else
         e2vq::launch_rows_stats(s->d_rows, s->M, s->NC, s->d_sc, s->d_S, s->d_within, s->d_lstats, s->stream);
-    HIPCHK(hipMemcpyAsync(s->h_stats->l, s->d_lstats, sizeof s->h_stats->l, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipMemcpyAsync(&s->h_stats->l1bits, s->d_l1max, 8, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipMemcpyAsync(s->h_within, s->d_within, (size_t)s->M * 8, hipMemcpyDeviceToHost, s->stream));
+    // publish: one small kernel writes the statistics into host-mapped memory and then a sequence number
+    {
+        void *dl = nullptr, *dw = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&dl, s->h_stats, 0));
+        HIPCHK(hipHostGetDevicePointer(&dw, s->h_within, 0));
+        auto* dstats = (e2vq_session::HostStats*)dl;
+        e2vq::launch_publish_stats(s->d_lstats, s->d_l1max, s->d_within, s->M, dstats->l, &dstats->l1bits, (double*)dw,
+                                   (u64*)&dstats->seq, ++s->stats_seq, s->stream);
+    }
     HIPCHK(hipEventRecord(s->ev_stats, s->stream));
     if (!fused) {  // speculative centroid update: keeps the GPU busy while the host decides
         e2vq::launch_centroids(s->d_rows, s->d_S, s->M, s->NC, s->d_refl, s->d_refl_spec, s->d_lstats, s->stream);
@@ -651,7 +660,19 @@ extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
     }
     HIPCHK(hipGetLastError());
     s->spec_valid = true;
-    HIPCHK(hipEventSynchronize(s->ev_stats));
+    // spin on the sequence number (microseconds); the event is the safety net should the kernel never get there
+    for (unsigned long spins = 0; s->h_stats->seq != s->stats_seq; ++spins) {
+        if ((spins & 0xfff) == 0xfff) {
+            const hipError_t q = hipEventQuery(s->ev_stats);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return e2vq_set_error("statistics kernel failed: %s", hipGetErrorString(q));
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    if (s->h_stats->seq != s->stats_seq) HIPCHK(hipStreamSynchronize(s->stream));
+    std::atomic_thread_fence(std::memory_order_acquire);
     i64 l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int slot = 0; slot < 64; ++slot)
         for (int k = 0; k < 8; ++k) l[k] += s->h_stats->l[slot * 8 + k];
