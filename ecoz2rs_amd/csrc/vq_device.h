@@ -60,8 +60,9 @@ void launch_rows_stats(const long long* rows, int M, int NC, const DevScalars* s
 void launch_centroids(const long long* rows, const double* S, int M, int NC, const double* refl_in, double* refl_out,
                       long long* lstats, hipStream_t s);
 void launch_combine_i64(long long* dst, const long long* stage, int nsrc, long count, int op, hipStream_t s);
-// copies the level statistics to host-mapped memory and then stores `seq` at *h_seq (all pointers device-visible)
-void launch_publish_stats(const long long* lstats, const unsigned long long* l1max_bits, const double* within, int M,
+// copies the level statistics to host-mapped memory, zeroes the slots for the next pass, then stores `seq` at *h_seq
+// (all pointers device-visible)
+void launch_publish_stats(long long* lstats, const unsigned long long* l1max_bits, const double* within, int M,
                           long long* h_l, unsigned long long* h_l1, double* h_within, unsigned long long* h_seq,
                           unsigned long long seq, hipStream_t s);
 bool has_cell_update(int NC);

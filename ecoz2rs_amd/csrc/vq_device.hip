@@ -1124,11 +1124,14 @@ void launch_zero_distortion_columns(i64* rows, int M, int NC, hipStream_t s)
 
 // Level statistics -> host-mapped (fine-grained) pinned memory, then a sequence number: the host spins on the number
 // instead of waiting for three small D2H copies and an event (tens of microseconds per pass, 45 passes per ladder).
-__global__ void k_publish_stats(const i64* __restrict__ lstats, const u64* __restrict__ l1max_bits,
+__global__ void k_publish_stats(i64* __restrict__ lstats, const u64* __restrict__ l1max_bits,
                                 const double* __restrict__ within, int M, i64* __restrict__ h_l, u64* __restrict__ h_l1,
                                 double* __restrict__ h_within, volatile u64* __restrict__ h_seq, u64 seq)
 {
-    for (int i = threadIdx.x; i < 64 * 8; i += blockDim.x) h_l[i] = lstats[i];
+    for (int i = threadIdx.x; i < 64 * 8; i += blockDim.x) {
+        h_l[i] = lstats[i];
+        lstats[i] = 0;  // ready for the next pass (saves a memset per pass)
+    }
     for (int i = threadIdx.x; i < M; i += blockDim.x) h_within[i] = within[i];
     if (threadIdx.x == 0) *h_l1 = *l1max_bits;
     __threadfence_system();
@@ -1139,7 +1142,7 @@ __global__ void k_publish_stats(const i64* __restrict__ lstats, const u64* __res
     }
 }
 
-void launch_publish_stats(const i64* lstats, const u64* l1max_bits, const double* within, int M, i64* h_l, u64* h_l1,
+void launch_publish_stats(i64* lstats, const u64* l1max_bits, const double* within, int M, i64* h_l, u64* h_l1,
                           double* h_within, u64* h_seq, u64 seq, hipStream_t s)
 {
     hipLaunchKernelGGL(k_publish_stats, dim3(1), dim3(256), 0, s, lstats, l1max_bits, within, M, h_l, h_l1, h_within,

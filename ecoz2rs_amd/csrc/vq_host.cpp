@@ -103,6 +103,7 @@ struct e2vq_session {
     double* d_S = nullptr;    // [M][NC]
     double* d_within = nullptr;
     i64* d_lstats = nullptr;  // [64 slots][8]: dist, dist2 limbs, empty, failed (slots are summed on the host)
+    bool lstats_dirty = false;  // a centroid kernel added to the slots after they were published
     bool stats_valid = false;
     e2vq_level_stats last{};
     double DDprv = DBL_MAX / 1e5;  // "e+303" in notes.md:128
@@ -215,6 +216,7 @@ static int session_init(e2vq_session* s)
     HIPCHK(hipMalloc(&s->d_flags, 2 * sizeof(int)));
     HIPCHK(hipMalloc(&s->d_stats, (size_t)(2 * s->NC + 3) * 8));
     HIPCHK(hipMalloc(&s->d_lstats, 64 * 8 * 8));
+    HIPCHK(hipMemset(s->d_lstats, 0, 64 * 8 * 8));
     HIPCHK(hipMemset(s->d_sc, 0, sizeof(DevScalars)));
     HIPCHK(hipEventCreate(&s->ev0));
     HIPCHK(hipEventCreate(&s->ev1));
@@ -636,7 +638,10 @@ extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
         if (out) *out = s->last;
         return 0;
     }
-    HIPCHK(hipMemsetAsync(s->d_lstats, 0, 64 * 8 * 8, s->stream));
+    // (d_lstats is zero here -- zeroed at session start and by every publish kernel -- unless a separate centroid
+    // kernel counted failed cells into it afterwards)
+    if (s->lstats_dirty) HIPCHK(hipMemsetAsync(s->d_lstats, 0, 64 * 8 * 8, s->stream));
+    s->lstats_dirty = false;
     const bool fused = e2vq::has_cell_update(s->NC);
     if (fused)  // statistics + speculative update into the shadow codebook in ONE wave-per-cell kernel
         e2vq::launch_cell_update(s->d_rows, s->M, s->NC, s->d_sc, s->d_refl, s->d_refl_spec, s->d_cbq_spec,
@@ -655,6 +660,7 @@ extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
     HIPCHK(hipEventRecord(s->ev_stats, s->stream));
     if (!fused) {  // speculative centroid update: keeps the GPU busy while the host decides
         e2vq::launch_centroids(s->d_rows, s->d_S, s->M, s->NC, s->d_refl, s->d_refl_spec, s->d_lstats, s->stream);
+        s->lstats_dirty = true;
         e2vq::launch_codebook_prepare(s->d_refl_spec, s->M, s->NC, s->d_cbq_spec, s->d_l1max_spec, s->d_cbm_spec,
                                       s->stream);
     }
@@ -716,6 +722,7 @@ extern "C" int e2vq_update(e2vq_session* s)
         return 0;
     }
     e2vq::launch_centroids(s->d_rows, s->d_S, s->M, s->NC, s->d_refl, s->d_refl, s->d_lstats, s->stream);
+    s->lstats_dirty = true;
     HIPCHK(hipGetLastError());
     return codebook_prepare(s, false);
 }
