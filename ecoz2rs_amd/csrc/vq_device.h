@@ -49,7 +49,8 @@ const int* prefilter_fallback_count(const void* ps);
 int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, long nblocks, const void* fimg,
                             const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
-                            long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, hipStream_t s);
+                            long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
+                            hipStream_t s);
 int launch_pass_fallback(int NC, bool accumulate, const double* blk, const double* cbm, int M, const DevScalars* sc,
                          const unsigned long long* l1max_bits, unsigned short* sym, double* dmin, long long* rows,
                          const int* fb_list, const int* fb_count, unsigned short* prev_sym, bool incremental,

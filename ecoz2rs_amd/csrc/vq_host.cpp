@@ -570,7 +570,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, s->d_cimg, s->d_ps,
                                       s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                                       (double*)device_dmin, rows, s->d_fblist, keep ? s->d_prev_sym : nullptr,
-                                      incremental, s->stream);
+                                      incremental, /*hybrid_table=*/mode == 5 && !incremental, s->stream);
         if (s->timing) {
             HIPCHK(hipEventRecord(s->ev1, s->stream));
             s->timed = true;
@@ -876,7 +876,7 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
         e2vq::launch_prefilter_codebook(s->d_cbq, s->M, s->NC, s->d_ea_q, s->d_ps, s->d_qcimg, s->stream);
         e2vq::launch_pass_prefiltered(s->NC, false, s->d_qblk, T, nb, s->d_qfimg, s->d_qfg, s->d_qcimg, s->d_ps, s->d_cbq,
                                       s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym, (double*)device_dmin, nullptr,
-                                      s->d_qfblist, nullptr, false, s->stream);
+                                      s->d_qfblist, nullptr, false, false, s->stream);
         e2vq::launch_pass_fallback(s->NC, false, s->d_qblk, s->d_cbm, s->M, s->d_sc, s->d_l1max,
                                    (unsigned short*)device_sym, (double*)device_dmin, nullptr, s->d_qfblist,
                                    e2vq::prefilter_fallback_count(s->d_ps), nullptr, false, s->stream);

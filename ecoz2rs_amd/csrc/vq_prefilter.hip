@@ -383,7 +383,17 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
     const int q = lane >> 4, j = lane & 15;
     const long wave = (long)blockIdx.x * (TPBM >> 6) + wib;
     const long nwaves = (long)gridDim.x * (TPBM >> 6);
-    int* img = (int*)smem + wib * (16 * IMG);
+    // MODE 5 (full accumulation at 128 < M <= 672): the first HYB_CELLS cells go to an LDS table of the workgroup,
+    // flushed once at the end; the others, and every cell in MODE 2, take global atomics
+    constexpr int RS = (2 * NC + 5 + 7) & ~7;
+    constexpr int HYB_CELLS = mfma_hyb_cells(NC);
+    const int lds_cells = MODE == 5 ? HYB_CELLS : 0;
+    i64* lacc = (i64*)smem;
+    int* img = (int*)(smem + (size_t)lds_cells * RS * 8) + wib * (16 * IMG);
+    if constexpr (MODE == 5) {
+        for (int i = threadIdx.x; i < lds_cells * RS; i += TPBM) lacc[i] = 0;
+        __syncthreads();
+    }
 
     int sh_r = 0, sh_d = 0, sh_d2 = 0;
     if constexpr (MODE != 0) {
@@ -560,13 +570,20 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             }
         }
         if constexpr (MODE != 0) {
-            // (no LDS table here: lds_cells = 0; a null table pointer crashes the ROCm 7.2 optimizer, so pass the LDS base)
-            accumulate_block<NC, MODE, true, 4, true>(Bf, best, idx, img, (i64*)smem, rows, 0, sh_r, sh_d, sh_d2, b, T, lane,
-                                                      skip, incr != 0, oldidx);
+            // (MODE 2 has no LDS table, lds_cells = 0; a null table pointer crashes the ROCm 7.2 optimizer: the LDS base)
+            accumulate_block<NC, MODE, true, 4, MODE == 2>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2, b, T,
+                                                           lane, skip, incr != 0, oldidx);
             // (after the accumulate, which consumed the old cells: the owner lane records the new one)
             const int is = q == 0 ? idx[0] : q == 1 ? idx[1] : q == 2 ? idx[2] : idx[3];
             const bool sk = q == 0 ? skip[0] : q == 1 ? skip[1] : q == 2 ? skip[2] : skip[3];
             if (prev_sym && b * 64 + lane < T && !sk) prev_sym[b * 64 + lane] = (unsigned short)is;
+        }
+    }
+    if constexpr (MODE == 5) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < lds_cells * RS; i += TPBM) {
+            const i64 v = lacc[i];
+            if (v != 0) atomicAdd((u64*)&rows[i], (u64)v);
         }
     }
 }
@@ -616,6 +633,7 @@ void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, 
                        (h8*)cimg);
 }
 
+// hybrid_table (full accumulation only): cells < mfma_hybrid_cells(NC) accumulate in the workgroup's LDS table.
 // accumulate = false: assignment only.  prev_sym (optional): the cell of every frame is recorded there; with
 // `incremental` the rows must be those of the previous pass over the same frames (distortion elements zeroed) and
 // prev_sym its cells.  Runs after launch_prefilter_codebook of the same pass; afterwards
@@ -623,9 +641,10 @@ void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, 
 int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, long nblocks, const void* fimg,
                             const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
-                            long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, hipStream_t s)
+                            long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
+                            hipStream_t s)
 {
-    if (!prefilter_supports(NC, M)) return 1;
+    if (!prefilter_supports(NC, M) || (hybrid_table && incremental)) return 1;
     constexpr int IMG = 2 * 37 + 5 + IMG_STRIDE_PAD;
     constexpr int TPBM = 512;  // 8 waves = 2 per SIMD, one persistent workgroup per CU
     const size_t lds = (size_t)(TPBM / 64) * 16 * IMG * 4;
@@ -634,7 +653,14 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
     const int idxmask = ~((1 << bits) - 1);
     const int grid = pre_grid(nblocks, TPBM / 64, 256);
     static const int stagger = getenv("ECOZ2_VQ_PRE_STAGGER") ? atoi(getenv("ECOZ2_VQ_PRE_STAGGER")) : 1;
-    if (accumulate) {
+    if (accumulate && hybrid_table) {  // full accumulation with the workgroup's LDS table for the first cells
+        const size_t lds5 = (size_t)mfma_hyb_cells(37) * (((2 * 37 + 5 + 7) & ~7) * 8) + lds;
+        (void)hipFuncSetAttribute((const void*)k_pass_pre<37, 5, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  E2VQ_LDS_BYTES);
+        hipLaunchKernelGGL((k_pass_pre<37, 5, TPBM>), dim3(grid), dim3(TPBM), lds5, s, blk, T, nblocks, (const h8*)fimg, fg,
+                           (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
+                           dmin, rows, fb_list, stagger, prev_sym, 0);
+    } else if (accumulate) {
         (void)hipFuncSetAttribute((const void*)k_pass_pre<37, 2, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
         hipLaunchKernelGGL((k_pass_pre<37, 2, TPBM>), dim3(grid), dim3(TPBM), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
