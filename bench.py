@@ -134,11 +134,8 @@ def main():
     sym = torch.empty(S, dtype=torch.int16, device=f"cuda:{local}")
     dmin = torch.empty(S, dtype=torch.float64, device=f"cuda:{local}")
 
-    def step():
-        sess.run_pass(sym, dmin)
-        st = sess.pass_stats()
-        sess.update()
-        return st
+    def step():  # sweep + accumulate (+ all-reduce) -> level statistics -> centroid update
+        return sess.iterate(sym, dmin)
 
     for _ in range(args.warmup):
         step()

@@ -727,6 +727,13 @@ extern "C" int e2vq_update(e2vq_session* s)
     return codebook_prepare(s, false);
 }
 
+extern "C" int e2vq_iterate(e2vq_session* s, void* device_sym, void* device_dmin, e2vq_level_stats* out)
+{
+    if (e2vq_pass(s, device_sym, device_dmin)) return 1;
+    if (e2vq_pass_stats(s, out)) return 1;
+    return e2vq_update(s);
+}
+
 extern "C" int e2vq_row_stride(int prediction_order) { return e2vq::row_stride(prediction_order + 1); }
 
 extern "C" int e2vq_get_rows(e2vq_session* s, int64_t* rows)

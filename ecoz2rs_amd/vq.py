@@ -186,6 +186,12 @@ class VqSession:
     def update(self):
         check(lib.e2vq_update(self._h))
 
+    def iterate(self, device_sym=None, device_dmin=None):
+        """One whole LBG iteration (pass + statistics + centroid update) in one library call."""
+        st = LevelStatsC()
+        check(lib.e2vq_iterate(self._h, _ptr(device_sym), _ptr(device_dmin), C.byref(st)))
+        return LevelStats.from_c(st)
+
     def enable_timing(self, on=True):
         check(lib.e2vq_enable_timing(self._h, int(on)))
 

@@ -139,6 +139,8 @@ int e2vq_last_pass_kernel_ms(e2vq_session *s, float *ms);
  * *fallback_frames = frames it handed to the full FP64 sweep (synchronises the stream) */
 int e2vq_last_pass_info(e2vq_session *s, int *prefiltered, int64_t *fallback_frames);
 int e2vq_update(e2vq_session *s);
+/* one whole LBG iteration in a single call: e2vq_pass + e2vq_pass_stats + e2vq_update */
+int e2vq_iterate(e2vq_session *s, void *device_sym, void *device_dmin, e2vq_level_stats *out);
 /* the reduced accumulator rows of the last pass (M x row_stride int64) copied to the host */
 int e2vq_row_stride(int prediction_order);
 int e2vq_get_rows(e2vq_session *s, int64_t *rows);

@@ -227,3 +227,24 @@ def test_incremental_switch_gives_the_same_ladder(oracle, monkeypatch):
             out.append((cbs, s.get_codebook().copy()))
     assert out[0][0] == out[1][0]
     assert np.array_equal(out[0][1].view(np.uint64), out[1][1].view(np.uint64))
+
+
+def test_iterate_is_pass_stats_update(oracle, monkeypatch):
+    """e2vq_iterate = e2vq_pass + e2vq_pass_stats + e2vq_update in one call (what bench.py times)."""
+    frames = _frames(20263, 7000)
+    refl = _codebook(oracle, frames, 64, seed=11)
+    rc, st = oracle.data_stats(frames)
+    sh_r, sh_q = oracle.shifts(st.maxabs)
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.set_codebook(refl)
+        for _ in range(3):
+            cq = oracle.reflections_to_cq(refl)
+            Ed = oracle.dist_exponent(cq, st.maxabs)
+            _sym, _dmin, rows_o = oracle.run_pass(cq, frames, sh_r, Ed)
+            ls_o = oracle.rows_stats(rows_o, P, frames.shape[0], sh_r, Ed, oracle.unfix(st.q_hi, st.q_lo, sh_q))
+            refl, _failed = oracle.update(rows_o, P, sh_r, refl)
+            ls = s.iterate()
+            assert (ls.DD, ls.avg_distortion, ls.sigma, ls.inertia) == (ls_o.DD, ls_o.avg, ls_o.sigma, ls_o.inertia)
+            assert np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64))
