@@ -270,11 +270,23 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
         }
     }
 
+    // MODE 1 (small codebooks, HBM-bound): the frames of the wave's next block are requested before the accumulate
+    // phase of the current one, which hides their HBM latency
+    constexpr bool PREFETCH = MODE == 1 && SRC == 0;
+    double Bn[PREFETCH ? 4 : 1][2 * NP];
+    if constexpr (PREFETCH) {
+        if (wave < nblocks) load_block_frames<NC>(blk, wave, lane, Bn);
+    }
     for (long b = wave; b < nblocks; b += nwaves) {
         // ---- frames -> B operands (resident for the whole sweep) ---------------------------
         double Bf[4][2 * NP];
         const double* fb = blk + b * (long)(NC * 64);
-        if constexpr (AOS) {
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+                for (int st = 0; st < 2 * NP; ++st) Bf[ft][st] = Bn[ft][st];
+        } else if constexpr (AOS) {
             static_assert(MODE == 0, "the AoS path serves the assignment-only kernel");
             double* stage = (double*)smem + wib * (NC * 64);  // this wave's 64 rows
             const long remaining = (T - b * 64) * NC;         // doubles left in the payload from this block on
@@ -422,6 +434,10 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                 best[0] = take ? ob : best[0];
                 idx[0] = take ? oi : idx[0];
             }
+        }
+
+        if constexpr (PREFETCH) {
+            if (b + nwaves < nblocks) load_block_frames<NC>(blk, b + nwaves, lane, Bn);
         }
 
         // ---- outputs: lane 16q + j owns frame b*64 + lane ---------------------------------------
