@@ -595,7 +595,8 @@ static inline int pre_grid(long items, int per_block, int cap)
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-bool prefilter_supports(int NC, int M) { return NC == 37 && M >= 64 && M % 32 == 0 && M <= 32768; }
+// (the codeword index shares the f32 key with the value: beyond 4096 codewords too few mantissa bits would be left)
+bool prefilter_supports(int NC, int M) { return NC == 37 && M >= 64 && M % 32 == 0 && M <= 4096; }
 size_t prefilter_frame_image_bytes(long nblocks64) { return (size_t)nblocks64 * 2 * PRE_PAIRS * 64 * 16; }
 size_t prefilter_codebook_image_bytes(int M) { return (size_t)((M + 31) / 32) * PRE_TILE_E * 16; }
 size_t prefilter_scalars_bytes() { return sizeof(PreScalars); }
