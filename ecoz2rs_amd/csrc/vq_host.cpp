@@ -123,9 +123,14 @@ struct e2vq_session {
     int* d_ea = nullptr;
     void* d_fimg = nullptr;
     float* d_fg = nullptr;
-    void* d_cimg = nullptr;
+    // two codebook limb images + per-pass scalars: slot img_cur serves the current codebook, the other one is built
+    // for the speculative (shadow) codebook right after the statistics are published, while the host reads them
+    void* d_cimg2[2] = {nullptr, nullptr};
+    void* d_ps2[2] = {nullptr, nullptr};
+    bool img_valid[2] = {false, false};
+    int img_cur = 0, img_last = 0;  // img_last: the slot whose scalars hold the last pass's fallback count
     int cimg_cap = 0;
-    void* d_ps = nullptr;
+    void* d_ps = nullptr;  // quantize
     int* d_fblist = nullptr;
     bool last_prefiltered = false;
     // quantize through the prefiltered sweep: scratch images of the frames handed in and of the codebook
@@ -234,6 +239,8 @@ static int session_init(e2vq_session* s)
         HIPCHK(hipMalloc(&s->d_colmax, (size_t)s->NC * 8));
         HIPCHK(hipMalloc(&s->d_ea, (size_t)s->NC * sizeof(int)));
         HIPCHK(hipMalloc(&s->d_ps, e2vq::prefilter_scalars_bytes()));
+        HIPCHK(hipMalloc(&s->d_ps2[0], e2vq::prefilter_scalars_bytes()));
+        HIPCHK(hipMalloc(&s->d_ps2[1], e2vq::prefilter_scalars_bytes()));
     }
     return 0;
 }
@@ -275,7 +282,7 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     void* ptrs[] = {s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
-                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg, s->d_ps, s->d_fblist, s->d_prev_sym, s->d_rows_local,
+                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg2[0], s->d_cimg2[1], s->d_ps2[0], s->d_ps2[1], s->d_ps, s->d_fblist, s->d_prev_sym, s->d_rows_local,
                     s->d_ea_q, s->d_qfimg, s->d_qfg, s->d_qfblist, s->d_qcimg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -427,6 +434,7 @@ extern "C" int e2vq_prepare(e2vq_session* s)
 static int codebook_prepare(e2vq_session* s, bool redefined = true)
 {
     if (redefined) s->incr_valid = false;
+    s->img_valid[0] = s->img_valid[1] = false;  // the codebook in d_cbq is a new one
     if (e2vq::has_cell_update(s->NC))
         e2vq::launch_cell_update(nullptr, s->M, s->NC, s->d_sc, s->d_refl, nullptr, s->d_cbq, s->d_cbm, s->d_l1max,
                                  nullptr, nullptr, s->stream);
@@ -512,10 +520,14 @@ static bool use_prefilter(const e2vq_session* s, int mode)
 static int ensure_codebook_image(e2vq_session* s)
 {
     if (s->M <= s->cimg_cap) return 0;
-    if (s->d_cimg) HIPCHK(hipFree(s->d_cimg));
-    s->d_cimg = nullptr;
+    for (int k = 0; k < 2; ++k) {
+        if (s->d_cimg2[k]) HIPCHK(hipFree(s->d_cimg2[k]));
+        s->d_cimg2[k] = nullptr;
+        s->img_valid[k] = false;
+    }
     s->cimg_cap = std::max(s->M, 2048);
-    HIPCHK(hipMalloc(&s->d_cimg, e2vq::prefilter_codebook_image_bytes(s->cimg_cap)));
+    for (int k = 0; k < 2; ++k)
+        HIPCHK(hipMalloc(&s->d_cimg2[k], e2vq::prefilter_codebook_image_bytes(s->cimg_cap)));
     return 0;
 }
 
@@ -565,9 +577,17 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         // f16 limb image of the current codebook, prefiltered sweep (exact evaluation of the certified top two),
         // then the full FP64 sweep of whatever it could not certify
         if (ensure_codebook_image(s)) return 1;
-        e2vq::launch_prefilter_codebook(s->d_cbq, s->M, s->NC, s->d_ea, s->d_ps, s->d_cimg, s->stream);
+        const int k = s->img_cur;
+        if (s->img_valid[k])  // built ahead by e2vq_pass_stats for the codebook committed since: only the count restarts
+            HIPCHK(hipMemsetAsync((void*)e2vq::prefilter_fallback_count(s->d_ps2[k]), 0, sizeof(int), s->stream));
+        else
+            e2vq::launch_prefilter_codebook(s->d_cbq, s->M, s->NC, s->d_ea, s->d_ps2[k], s->d_cimg2[k], s->stream);
+        s->img_valid[k] = true;
+        s->img_last = k;
+        void* const d_cimg = s->d_cimg2[k];
+        void* const d_ps = s->d_ps2[k];
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
-        e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, s->d_cimg, s->d_ps,
+        e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, d_cimg, d_ps,
                                       s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                                       (double*)device_dmin, rows, s->d_fblist, keep ? s->d_prev_sym : nullptr,
                                       incremental, /*hybrid_table=*/mode == 5 && !incremental, s->stream);
@@ -577,7 +597,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         }
         e2vq::launch_pass_fallback(s->NC, mode != 0, s->d_blk, s->d_cbm, s->M, s->d_sc, s->d_l1max,
                                    (unsigned short*)device_sym, (double*)device_dmin, rows, s->d_fblist,
-                                   e2vq::prefilter_fallback_count(s->d_ps), keep ? s->d_prev_sym : nullptr, incremental,
+                                   e2vq::prefilter_fallback_count(d_ps), keep ? s->d_prev_sym : nullptr, incremental,
                                    s->stream);
     } else {
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
@@ -598,6 +618,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     if (reduce(s, s->d_rows, (i64)s->M * s->RS, 0)) return 1;
     s->stats_valid = false;
     s->spec_valid = false;
+    s->img_valid[1 - s->img_cur] = false;
     return 0;
 }
 
@@ -608,7 +629,8 @@ extern "C" int e2vq_last_pass_info(e2vq_session* s, int* prefiltered, int64_t* f
     if (fallback_frames) {
         int n = 0;
         if (s->last_prefiltered) {
-            HIPCHK(hipMemcpyAsync(&n, e2vq::prefilter_fallback_count(s->d_ps), sizeof(int), hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipMemcpyAsync(&n, e2vq::prefilter_fallback_count(s->d_ps2[s->img_last]), sizeof(int),
+                                  hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipStreamSynchronize(s->stream));
         }
         *fallback_frames = n;
@@ -664,6 +686,13 @@ extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
         e2vq::launch_codebook_prepare(s->d_refl_spec, s->M, s->NC, s->d_cbq_spec, s->d_l1max_spec, s->d_cbm_spec,
                                       s->stream);
     }
+    // the next pass will most likely run on the shadow codebook: its limb image is built now -- after the statistics
+    // went out, i.e. during the host's round trip -- if that pass is going to be a prefiltered one
+    if (fused && s->d_cimg2[1 - s->img_cur] && use_prefilter(s, pass_mode(s)) && s->M <= s->cimg_cap) {
+        const int k = 1 - s->img_cur;
+        e2vq::launch_prefilter_codebook(s->d_cbq_spec, s->M, s->NC, s->d_ea, s->d_ps2[k], s->d_cimg2[k], s->stream);
+        s->img_valid[k] = true;
+    }
     HIPCHK(hipGetLastError());
     s->spec_valid = true;
     // spin on the sequence number (microseconds); the event is the safety net should the kernel never get there
@@ -717,6 +746,8 @@ extern "C" int e2vq_update(e2vq_session* s)
         std::swap(s->d_cbq, s->d_cbq_spec);
         std::swap(s->d_cbm, s->d_cbm_spec);
         std::swap(s->d_l1max, s->d_l1max_spec);
+        s->img_valid[s->img_cur] = false;  // (that codebook is the shadow now)
+        s->img_cur = 1 - s->img_cur;
         s->spec_valid = false;
         s->stats_valid = false;
         return 0;
