@@ -116,6 +116,9 @@ struct e2vq_session {
     // HIP events around the sweep kernel (bench.py's roofline figures)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false, timed = false;
+    double timing_sum_ms = 0.0;  // kernel time of the timed passes already folded in (e2vq_timing_total)
+    long timing_count = 0;
+    bool timing_pending = false;  // ev0/ev1 hold a pass that is not in the sum yet
     // prefiltered sweep (P = 36, M >= pre_min_M): f16 limb images of the frames / the codebook, fallback list
     bool pre_enabled = false;
     int pre_min_M = 256;
@@ -510,6 +513,18 @@ static int pass_mode(const e2vq_session* s)
     return 2;  // generic kernel: global atomics
 }
 
+// adds the pass bracketed by ev0/ev1 to the running total; only called when those events have completed
+static int fold_pending_timing(e2vq_session* s)
+{
+    if (!s->timing_pending) return 0;
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    s->timing_sum_ms += ms;
+    s->timing_count += 1;
+    s->timing_pending = false;
+    return 0;
+}
+
 // the prefiltered sweep serves the accumulate-by-global-atomics and assignment-only passes of large codebooks
 static bool use_prefilter(const e2vq_session* s, int mode)
 {
@@ -536,6 +551,10 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     if (!s->prepared) return e2vq_set_error("e2vq_prepare has not run");
     if (s->M < 1) return e2vq_set_error("no codebook");
     HIPCHK(hipSetDevice(s->device));
+    if (s->timing && s->timing_pending) {  // the previous timed pass has long finished (its statistics were read)
+        HIPCHK(hipEventSynchronize(s->ev1));
+        if (fold_pending_timing(s)) return 1;
+    }
     const int mode = pass_mode(s);
     s->last_prefiltered = use_prefilter(s, mode);
     const bool collective = s->allreduce && (s->world > 1 || getenv("ECOZ2_VQ_FORCE_ALLREDUCE"));
@@ -568,6 +587,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         if (s->timing) {
             HIPCHK(hipEventRecord(s->ev1, s->stream));
             s->timed = true;
+            s->timing_pending = true;
         }
         if (sym_out != s->d_prev_sym)
             HIPCHK(hipMemcpyAsync(s->d_prev_sym, sym_out, (size_t)s->T * sizeof(unsigned short), hipMemcpyDeviceToDevice,
@@ -594,6 +614,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         if (s->timing) {
             HIPCHK(hipEventRecord(s->ev1, s->stream));
             s->timed = true;
+            s->timing_pending = true;
         }
         e2vq::launch_pass_fallback(s->NC, mode != 0, s->d_blk, s->d_cbm, s->M, s->d_sc, s->d_l1max,
                                    (unsigned short*)device_sym, (double*)device_dmin, rows, s->d_fblist,
@@ -606,6 +627,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         if (s->timing) {
             HIPCHK(hipEventRecord(s->ev1, s->stream));
             s->timed = true;
+            s->timing_pending = true;
         }
     }
     if (mode != 0) {
@@ -642,6 +664,21 @@ extern "C" int e2vq_enable_timing(e2vq_session* s, int on)
 {
     s->timing = on != 0;
     s->timed = false;
+    s->timing_pending = false;
+    s->timing_sum_ms = 0.0;
+    s->timing_count = 0;
+    return 0;
+}
+
+extern "C" int e2vq_timing_total(e2vq_session* s, double* total_ms, int64_t* passes)
+{
+    HIPCHK(hipSetDevice(s->device));
+    if (s->timing_pending) {
+        HIPCHK(hipEventSynchronize(s->ev1));
+        if (fold_pending_timing(s)) return 1;
+    }
+    if (total_ms) *total_ms = s->timing_sum_ms;
+    if (passes) *passes = s->timing_count;
     return 0;
 }
 

@@ -200,6 +200,12 @@ class VqSession:
         check(lib.e2vq_last_pass_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def timing_total(self):
+        """(sum of the event-measured sweep-kernel times in ms, number of passes) since enable_timing(True)."""
+        ms, n = C.c_double(), C.c_int64()
+        check(lib.e2vq_timing_total(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def last_pass_info(self):
         """(prefiltered sweep used?, frames it left to the full FP64 sweep) of the last run_pass."""
         used, n = C.c_int(), C.c_int64()

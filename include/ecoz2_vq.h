@@ -135,6 +135,9 @@ int e2vq_pass_stats(e2vq_session *s, e2vq_level_stats *out);
 /* HIP events around the sweep kernel of e2vq_pass, on the session's stream */
 int e2vq_enable_timing(e2vq_session *s, int on);
 int e2vq_last_pass_kernel_ms(e2vq_session *s, float *ms);
+/* sum of those event-measured kernel times over all passes since e2vq_enable_timing(1), and their number: lets a
+ * caller time K iterations without a host synchronisation per iteration */
+int e2vq_timing_total(e2vq_session *s, double *total_ms, int64_t *passes);
 /* which sweep served the last e2vq_pass: *prefiltered = 1 when the f16-prefiltered sweep ran (P = 36, large M),
  * *fallback_frames = frames it handed to the full FP64 sweep (synchronises the stream) */
 int e2vq_last_pass_info(e2vq_session *s, int *prefiltered, int64_t *fallback_frames);
