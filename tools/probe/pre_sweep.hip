@@ -219,6 +219,55 @@ __global__ __launch_bounds__(TPB) void k_pre_sweep(const h8* __restrict__ fimg, 
     }
 }
 
+// Variant for occupancy: one 32-frame column block per wave (28 VGPRs of limbs), single-buffered accumulators, A
+// operands loaded just in time from L2: ~110 VGPRs, 4 waves per SIMD; the epilogue of a job is not overlapped inside
+// the wave but by the other waves.  Costs twice the L2 traffic of the 64-frame-per-wave kernel.
+__global__ __launch_bounds__(256, 4) void k_pre_sweep_occ(const h8* __restrict__ fimg, long nblk32,
+                                                          const h8* __restrict__ cimg, int MT, int idxmask,
+                                                          int4* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    int maskv = idxmask;
+    asm volatile("" : "+v"(maskv));
+    float ninf = -__builtin_inff();
+    asm volatile("" : "+v"(ninf));
+    for (long blk = wave; blk < nblk32; blk += nwaves) {
+        h8 B[7];
+#pragma unroll
+        for (int p = 0; p < 7; ++p) B[p] = fimg[(blk * 7 + p) * 64 + lane];
+        float k1 = __int_as_float(0x7f7fffff), k2 = k1, k3 = k1;
+        for (int t = 0; t < MT; ++t) {
+            f16v acc[3];
+            const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                const h8 a = cimg[(long)t * 1024 + s * 64 + lane];
+                const int lv = step_level(s), pr = step_pair(s);
+                const bool first = s == 0 || s == 3 || s == 8;
+                acc[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B[pr], first ? zero : acc[lv], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int sidx = __builtin_amdgcn_readfirstlane(t * 32 + 8 * (r >> 2) + (r & 3));
+                const float v = __builtin_fmaf(acc[0][r], 262144.f, __builtin_fmaf(acc[1][r], 512.f, acc[2][r]));
+                const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);
+                k3 = med3f(k2, k3, key);
+                k2 = med3f(k1, k2, key);
+                k1 = med3f(k1, key, ninf);
+            }
+        }
+        const int hb = (lane >> 5) << 2;
+        const float a1 = __int_as_float(__float_as_int(k1) | hb), a2 = __int_as_float(__float_as_int(k2) | hb),
+                    a3 = __int_as_float(__float_as_int(k3) | hb);
+        const float b1 = __shfl_xor(a1, 32, 64), b2 = __shfl_xor(a2, 32, 64), b3 = __shfl_xor(a3, 32, 64);
+        const float t3 = med3f(a2, a3, b1), t2 = med3f(a1, a2, b1), t1 = med3f(a1, b1, ninf);
+        const float u3 = med3f(t2, t3, b2), u2 = med3f(t1, t2, b2);
+        const float w3 = med3f(u2, u3, b3);
+        if (lane < 32) out[blk * 32 + lane] = make_int4(__float_as_int(t1), __float_as_int(u2), __float_as_int(w3), 0);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 static inline unsigned long long sm64(unsigned long long& s)
 {
@@ -313,7 +362,11 @@ int main(int argc, char** argv)
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
         const int R = rep == 0 ? 1 : 10;
+#ifdef OCC
+        for (int i = 0; i < R; ++i) k_pre_sweep_occ<<<OCC, 256>>>(d_f, nblk32, d_c, MT, idxmask, d_o);
+#else
         for (int i = 0; i < R; ++i) k_pre_sweep<<<grid, TPB, lds>>>(d_f, nblk32, d_c, MT, idxmask, d_o);
+#endif
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
