@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- VQ-learn frames/s at M=1024, P=36 on N MI355X (BASELINE.json metric).
 
-A "step" is one full LBG iteration at M=1024 over the resident shard of every rank:
+A "step" is one LBG pass of the REAL M=1024 level over the resident shard of every rank:
   sweep+accumulate kernel (K1+K2)  ->  int64 all-reduce of the cell sums (RCCL, N>1)
   ->  level statistics (the host reads DD for the convergence test)  ->  centroid update (K3/K4).
+The timed region repeats the level exactly as the ladder runs it: restore the converged M=512 codebook and its
+DD, split to M=1024, then passes until (DDprv-DD)/DD < eps ends the level (3 passes on this data: one full
+accumulation + two incremental ones), through the library's own e2vq_learn.  K steps = K such passes (whole
+levels; a remainder of K is run as the leading passes of one more level).
 Frames are synthetic (seeded, counter based: rank r holds frames [r*S, (r+1)*S) of one stream) and
 resident in HBM before the timed region.  Weak scaling: S = 2^21 frames per GPU (config 4's shard).
 
@@ -31,6 +35,34 @@ F16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense BF16/F16 MFMA peak ~2.5 
 F16_MFMA_FLOP_PER_FRAME_CODEWORD = 2 * 16 * 15  # 15 k-steps of v_mfma_f32_32x32x16_f16 per (frame, codeword) pair
 BYTES_PER_FRAME_PASS = 306  # 296 B frame + 2 B symbol + 8 B min distortion
 FLOP_PER_FRAME_PASS = 2 * M * (P + 1)
+
+
+def kernel_sources_sha16():
+    """sha256 (first 16 hex digits) over the device/host sources of the library: ties a PMC traffic figure to a build"""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ecoz2rs_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_quota_cores():
+    """CPU share of this container (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unreadable"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
 
 
 def cpu_baseline(e, np):
@@ -70,6 +102,13 @@ def cpu_baseline(e, np):
         "value": n * reps / secs,
         "unit": "frames/s",
         "cores": threads,
+        "per_thread": n * reps / secs / max(1, threads),
+        "gflops": n * reps / secs * FLOP_PER_FRAME_PASS / 1e9,
+        "visible_cores": ncpu,
+        "cpu_quota_cores": cpu_quota_cores(),
+        "caveat": "stand-in for the unbuildable reference C library (kind: port); assignment pass only (the accumulate "
+                  "adds 37 of 37 888 operations per frame); thread count picked by calibration because the box's CPU "
+                  "quota can be below its visible cores; a GPU/CPU ratio is not a measure of kernel quality",
         "kind": "port",
         "sample": f"{reps} assignment passes over {n} synthetic frames at M={M}, P={P} "
                   f"({secs:.1f} s; oracle source built with the reference's flags -O3 -ffast-math -fopenmp, {variant})",
@@ -130,16 +169,31 @@ def main():
     levels = sess.learn(0.05, M // 2)  # real LBG ladder 2..512 (untimed) -> realistic codebook state
     torch.cuda.synchronize()
     t_ladder = time.time() - t_ladder
-    sess.grow()  # M = 1024
+    cb512 = sess.get_codebook()          # the converged M = 512 codebook ...
+    dd512 = levels[-1].DD                # ... and the DD the stopping rule carries into the M = 1024 level
     sym = torch.empty(S, dtype=torch.int16, device=f"cuda:{local}")
     dmin = torch.empty(S, dtype=torch.float64, device=f"cuda:{local}")
+    EPS = 0.05
 
-    def step():  # sweep + accumulate (+ all-reduce) -> level statistics -> centroid update
-        return sess.iterate(sym, dmin)
+    def restore():
+        sess.set_codebook(cb512)
+        sess.set_prev_distortion(dd512)
 
-    for _ in range(args.warmup):
-        step()
-    sess.enable_timing(True)  # HIP events around the sweep kernel of every pass, summed inside the library
+    def whole_level():
+        """the M = 1024 level through the library's LBG driver (e2vq_learn): split + passes until convergence"""
+        restore()
+        return sess.learn(EPS, M)[0]
+
+    def leading_passes(n):
+        """the first n passes of the level, step by step (same calls, same order as e2vq_learn's loop)"""
+        restore()
+        sess.grow()
+        for i in range(n):
+            sess.run_pass()
+            st_ = sess.pass_stats()
+            if i + 1 < n:
+                sess.update()
+        return st_
 
     def fence():
         torch.cuda.synchronize()
@@ -147,19 +201,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # warm-up: whole levels (at least one: it also tells how many passes the level takes on this data)
+    lv = whole_level()
+    L = lv.passes
+    done = L
+    while done < args.warmup:
+        whole_level()
+        done += L
+    sess.enable_timing(True)  # HIP events around the sweep kernel of every pass, summed inside the library
     fence()
+    launches_before = sess.sweep_launch_counts()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = step()
+    steps_left = args.steps
+    while steps_left >= L:
+        st = whole_level()
+        assert st.passes == L
+        steps_left -= L
+    if steps_left:
+        st = leading_passes(steps_left)
     fence()
     dt = time.perf_counter() - t0
     kernel_ms_total, kernel_passes = sess.timing_total()
-    assert kernel_passes == args.steps
+    assert kernel_passes == args.steps, (kernel_passes, args.steps)
     prefiltered, fallback_frames = sess.last_pass_info()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- steady state (informational): back-to-back iterations on the converged M = 1024 codebook, where the
+    # incremental accumulate has almost nothing left to move -- round 1's headline regime, kept as an extra key
+    whole_level()
+    for _ in range(3):
+        sess.iterate(sym, dmin)
+    sess.enable_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        sess.iterate(sym, dmin)
+    fence()
+    steady_ms = (time.perf_counter() - t0) / 10 * 1e3
+    steady_kernel_ms = sess.timing_total()[0] / 10
 
     # ---- secondary figures (SURVEY 8d ii / iii), outside the timed region, informational --------------------
     sess.enable_timing(False)
@@ -183,71 +265,74 @@ def main():
     if rank == 0:
         k_ms = kernel_ms_total / kernel_passes
         frames_per_launch = S
-        # PMC traffic cannot be collected inside this process: it comes from the separate rocprofv3 --pmc passes
-        # over this same command, recorded in profiles/traffic.json (FETCH_SIZE doubled per the gfx950 note)
+        # PMC traffic cannot be collected inside this process: it comes from separate rocprofv3 --pmc passes over this
+        # same command (tools/summarize_profiles.py -> profiles/r02_traffic.json).  The file records the hash of the
+        # kernel sources it was measured on; a figure measured on other sources is reported as stale (null).
         traffic, traffic_detail = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_prefilter.json" if prefiltered else "traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json" if prefiltered else "r02_traffic_noprefilter.json")
         if os.path.exists(tpath) and S == FRAMES_PER_GPU:
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get("hbm_bytes_per_launch")
+                fresh = tj.get("kernel_sources_sha16") == kernel_sources_sha16()
+                traffic = tj.get("hbm_bytes_per_launch") if fresh else None
                 traffic_detail = {"fetch_bytes": tj.get("fetch_bytes"), "write_bytes": tj.get("write_bytes"),
                                   "algorithmic_bytes": tj.get("algorithmic_bytes_per_launch"),
-                                  "note": tj.get("note")}
+                                  "measured_on_sources": tj.get("kernel_sources_sha16"),
+                                  "stale": not fresh, "note": tj.get("note")}
             except Exception:
                 traffic = None
-        achieved_tf = FLOP_PER_FRAME_PASS * frames_per_launch / (k_ms * 1e-3) / 1e12
+        alg_tf = FLOP_PER_FRAME_PASS * frames_per_launch / (k_ms * 1e-3) / 1e12
         achieved_gbs = BYTES_PER_FRAME_PASS * frames_per_launch / (k_ms * 1e-3) / 1e9
+        roofline_algorithmic = None
         if prefiltered:
-            # dominant kernel: the prefiltered sweep.  Its matrix work is 15 f16 MFMA k-steps per (frame, codeword)
-            # (exact integer limb products); the FP64 chain runs only for the two certified candidates of a frame.
+            # dominant kernel: the prefiltered sweep.  The work it EXECUTES is 15 f16 MFMA k-steps per (frame, codeword)
+            # pair (exact integer limb products) -- priced against the dense f16 MFMA peak of the guide; the FP64 chain
+            # runs only for the two certified candidates of a frame.
             exec_tf = F16_MFMA_FLOP_PER_FRAME_CODEWORD * M * frames_per_launch / (k_ms * 1e-3) / 1e12
-            kernel_name = ("k_pass_pre<37,2,512> (exact f16-limb prefilter on v_mfma_f32_32x32x16_f16 + top-3 keys, "
-                           "FP64 evaluation of the certified top two on v_mfma_f64_16x16x4_f64, incremental exact "
-                           "accumulate); uncertified frames: k_pass_mfma<37,2,512,2>")
-            # by the contract: ALGORITHMIC flops of the path (2*M*(P+1) FP64 flop per frame-pass) per kernel
-            # time against the FP64 peak.  The ratio exceeds 1 because the kernel does not execute most of those flops:
-            # it proves, per frame, which two codewords can win and runs the FP64 chain for those only.
             roofline = {
                 "bound": "mfma",
-                "kernel": kernel_name,
-                "achieved": achieved_tf,
-                "peak": FP64_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved_tf / FP64_PEAK_TFLOPS,
-                "traffic": traffic,
-                "traffic_detail": traffic_detail,
-                "kernel_ms": k_ms,
-                "note": "algorithmic FP64 flops / kernel time; > 1 is the algorithmic gain of the exact prefilter, not a "
-                        "measurement artefact (results are bit-identical to the plain FP64 sweep, which runs at 0.80 of "
-                        "this peak: --no-prefilter).  The work actually issued is priced in roofline_executed.",
-                "fallback_frames_last_pass": fallback_frames,
-            }
-            roofline_executed = {
-                "bound": "mfma",
-                "what": "limb products actually issued: 15 k-steps of v_mfma_f32_32x32x16_f16 per (frame, codeword) pair",
+                "kernel": "k_pass_pre<37,2,512> (exact f16-limb prefilter on v_mfma_f32_32x32x16_f16 + top-3 keys, FP64 "
+                          "evaluation of the certified top two on v_mfma_f64_16x16x4_f64, exact accumulate: full on the "
+                          "first pass of the level, incremental after); uncertified frames: k_pass_mfma<37,2,512,2>",
                 "achieved": exec_tf,
                 "peak": F16_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": exec_tf / F16_PEAK_TFLOPS,
+                "traffic": traffic,
+                "traffic_detail": traffic_detail,
+                "kernel_ms": k_ms,
+                "launches": kernel_passes,
+                "trace_dispatches": {"kernel": "k_pass_pre", "first": launches_before[0], "count": kernel_passes},
+                "work_per_launch": f"{F16_MFMA_FLOP_PER_FRAME_CODEWORD} f16 MFMA flop x {M} codewords x {S} frames "
+                                   "(limb products actually issued)",
                 "executed_dtype": "f16 limbs (exact integers) -> f32 accumulators; candidates in f64",
-                "note": "dense f16 MFMA peak of the guide (2.5 PF); on random operands the pipe sustains 1.1-1.25 PF "
-                        "(power), the sweep phase alone runs at 1.13 PF (tools/probe/pre_sweep.hip)",
+                "fallback_frames_last_pass": fallback_frames,
+                "note": "dense f16 MFMA peak of the guide (2.5 PF); on random operands the pipe sustains 1.1-1.4 PF "
+                        "(power-limited clock, tools/probe/pre_sweep.hip)",
+            }
+            roofline_algorithmic = {
+                "what": "the path's algorithmic FP64 flops (SURVEY 8d: 2*M*(P+1) per frame-pass) / kernel time, against "
+                        "the FP64 peak: a speed-up figure, NOT a roofline fraction (the kernel does not execute these "
+                        "flops; the plain FP64 sweep, --no-prefilter, runs at 0.80 of this peak)",
+                "fp64_equivalent_tflops": alg_tf,
+                "fp64_peak_tflops": FP64_PEAK_TFLOPS,
+                "ratio": alg_tf / FP64_PEAK_TFLOPS,
             }
         else:
             # the plain sweep is FP64-FMA bound (248 flop/B): useful flops 2*M*(P+1) per frame against the 78.6 TF peak
             roofline = {
                 "bound": "mfma",
                 "kernel": "k_pass_mfma<37,2,512> (sweep on v_mfma_f64_16x16x4_f64 + argmin + exact accumulate)",
-                "achieved": achieved_tf,
+                "achieved": alg_tf,
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved_tf / FP64_PEAK_TFLOPS,
+                "frac": alg_tf / FP64_PEAK_TFLOPS,
                 "traffic": traffic,
                 "traffic_detail": traffic_detail,
                 "kernel_ms": k_ms,
+                "launches": kernel_passes,
+                "trace_dispatches": {"kernel": "k_pass_mfma", "first": launches_before[1], "count": kernel_passes},
             }
-            roofline_executed = None
         out = {
             "metric": "vq_learn_frames_per_sec_M1024_P36",
             "value": world * S * args.steps / dt,
@@ -262,16 +347,26 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"vq learn LBG iteration at M={M}, P={P}: {S} frames per GPU "
-                            f"(config 4 shard: 16M frames over 8 GPUs), eps=0.05 ladder 2..{M // 2} run untimed first",
+                "workload": f"vq learn, the real M={M} level at P={P}: {S} frames per GPU (config 4 shard: 16M frames "
+                            f"over 8 GPUs); per repetition the converged M={M // 2} codebook is restored, split, and "
+                            f"passes run until (DDprv-DD)/DD < {EPS} ({L} passes: 1 full + {L - 1} incremental "
+                            f"accumulations); a step = one such pass; eps={EPS} ladder 2..{M // 2} run untimed first",
                 "frames_per_gpu": S,
                 "codebook_size": M,
                 "prediction_order": P,
+                "passes_per_level": L,
                 "parallelism": f"frames sharded over {world} rank(s); int64 all-reduce of cell sums per iteration",
                 "sweep": "prefiltered (exact f16-limb prefilter + FP64 verification; bit-identical to the plain sweep)"
                          if prefiltered else "plain FP64 MFMA sweep",
                 "ladder_seconds_untimed": round(t_ladder, 3),
                 "final_avg_distortion": st.avg_distortion,
+                "steady_state": {
+                    "what": "back-to-back iterations on the converged codebook (incremental accumulate nearly idle): "
+                            "round 1's headline regime, informational",
+                    "ms_per_step": steady_ms,
+                    "kernel_ms": steady_kernel_ms,
+                    "frames_per_sec": world * S / (steady_ms * 1e-3),
+                },
                 "learn_end_to_end": {
                     "what": f"whole LBG ladder M=2..{M}, eps=0.05, resident frames, all ranks",
                     "seconds": round(e2e_s, 4),
@@ -281,7 +376,7 @@ def main():
                 "quantize_frames_per_sec_device_resident": q_rate,
             },
             "roofline": roofline,
-            "roofline_executed": roofline_executed,
+            "roofline_algorithmic": roofline_algorithmic,
             "roofline_hbm": {
                 "bound": "hbm",
                 "achieved": achieved_gbs,

@@ -76,6 +76,9 @@ _sig("e2vq_last_pass_kernel_ms", C.c_int, C.c_void_p, C.POINTER(C.c_float))
 _sig("e2vq_timing_total", C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64))
 _sig("e2vq_iterate", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LevelStatsC))
 _sig("e2vq_last_pass_info", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64))
+_sig("e2vq_set_prev_distortion", C.c_int, C.c_void_p, C.c_double)
+_sig("e2vq_get_prev_distortion", C.c_int, C.c_void_p, C.POINTER(C.c_double))
+_sig("e2vq_sweep_launch_counts", C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
 _sig("e2vq_row_stride", C.c_int, C.c_int)
 _sig("e2vq_get_rows", C.c_int, C.c_void_p, C.c_void_p)
 _sig("e2vq_learn", C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, LEARN_CALLBACK,

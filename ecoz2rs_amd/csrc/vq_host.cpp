@@ -136,6 +136,7 @@ struct e2vq_session {
     void* d_ps = nullptr;  // quantize
     int* d_fblist = nullptr;
     bool last_prefiltered = false;
+    i64 n_pre_launches = 0, n_plain_launches = 0;  // sweep launches of this session's training passes, by kernel family
     // quantize through the prefiltered sweep: scratch images of the frames handed in and of the codebook
     int* d_ea_q = nullptr;
     void* d_qfimg = nullptr;
@@ -335,12 +336,24 @@ static int reduce(e2vq_session* s, void* buf, i64 count, int op)
 extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames, int64_t T)
 {
     if (T < 1) return e2vq_set_error("empty training set");
+    // frame indices travel as 32-bit ints in the fallback lists / block tables of the kernels
+    if (T > (int64_t)INT32_MAX - 64) return e2vq_set_error("%lld frames exceed the per-session limit of 2^31 - 65", (long long)T);
     HIPCHK(hipSetDevice(s->device));
+    // whatever happens below, the previous training set is gone: nothing may sweep a stale or null buffer
+    s->prepared = false;
+    s->stats_valid = false;
+    s->spec_valid = false;
+    s->incr_valid = false;
+    s->maxabs_scanned = false;
+    s->T = 0;
+    s->nblocks = 0;
+    HIPCHK(hipStreamSynchronize(s->stream));  // no kernel of this session still reads the old blocks
     if (s->d_blk) HIPCHK(hipFree(s->d_blk));
     s->d_blk = nullptr;
+    const i64 nblocks = (T + s->FB - 1) / s->FB;
+    HIPCHK(hipMalloc(&s->d_blk, (size_t)nblocks * s->NC * s->FB * 8));
     s->T = T;
-    s->nblocks = (T + s->FB - 1) / s->FB;
-    HIPCHK(hipMalloc(&s->d_blk, (size_t)s->nblocks * s->NC * s->FB * 8));
+    s->nblocks = nblocks;
     HIPCHK(hipMemsetAsync(s->d_maxabs, 0, 8, s->stream));
     HIPCHK(hipMemsetAsync(s->d_flags, 0, 2 * sizeof(int), s->stream));
     s->maxabs_scanned = e2vq::launch_blockify((const double*)device_frames, T, s->NC, s->FB, s->d_blk, s->nblocks,
@@ -376,9 +389,9 @@ extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames
                         (long long)T);
         }
     }
-    s->prepared = false;
-    s->stats_valid = false;
-    s->incr_valid = false;
+    // The re-layout kernels read `device_frames` on the session's stream: the caller must have finished writing it
+    // (or have written it on this stream).  They are complete when this returns, so the buffer may be reused or freed.
+    HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
 }
 
@@ -482,6 +495,7 @@ extern "C" int e2vq_init_codebook(e2vq_session* s)
     HIPCHK(hipStreamSynchronize(s->stream));
     if (st != 0) return e2vq_set_error("Levinson recursion failed on the global centroid (status %d)", st);
     s->M = 1;
+    s->DDprv = DBL_MAX / 1e5;  // a fresh ladder: "e+303" in notes.md:128
     return codebook_prepare(s);
 }
 
@@ -582,6 +596,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     if (plain_first) {
         unsigned short* sym_out = device_sym ? (unsigned short*)device_sym : s->d_prev_sym;
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
+        s->n_plain_launches++;
         e2vq::launch_pass(s->NC, mode, s->d_blk, s->T, s->nblocks, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max, sym_out,
                           (double*)device_dmin, rows, s->stream);
         if (s->timing) {
@@ -607,6 +622,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         void* const d_cimg = s->d_cimg2[k];
         void* const d_ps = s->d_ps2[k];
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
+        s->n_pre_launches++;
         e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, d_cimg, d_ps,
                                       s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                                       (double*)device_dmin, rows, s->d_fblist, keep ? s->d_prev_sym : nullptr,
@@ -622,6 +638,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
                                    s->stream);
     } else {
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
+        s->n_plain_launches++;
         e2vq::launch_pass(s->NC, mode, s->d_blk, s->T, s->nblocks, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max,
                           (unsigned short*)device_sym, (double*)device_dmin, rows, s->stream);
         if (s->timing) {
@@ -657,6 +674,15 @@ extern "C" int e2vq_last_pass_info(e2vq_session* s, int* prefiltered, int64_t* f
         }
         *fallback_frames = n;
     }
+    return 0;
+}
+
+// training-pass sweep launches so far, by kernel family: lets a profile of a whole run (rocprofv3 --kernel-trace)
+// be cut to the dispatches of a timed region
+extern "C" int e2vq_sweep_launch_counts(e2vq_session* s, int64_t* prefiltered, int64_t* plain)
+{
+    if (prefiltered) *prefiltered = s->n_pre_launches;
+    if (plain) *plain = s->n_plain_launches;
     return 0;
 }
 
@@ -767,6 +793,16 @@ extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
     s->last.sigma = sqrt(v);
     s->last.inertia = s->h_sc.Q - w;
     s->last.empty_cells = l[4];
+    s->last.failed_cells = l[5];  // fused kernel: counted before the publish
+    if (!fused) {
+        // thread-per-cell path (P > 63): k_centroids counted the failed recursions after the slots were published
+        i64 slots[64 * 8];
+        HIPCHK(hipMemcpyAsync(slots, s->d_lstats, sizeof slots, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        i64 f = 0;
+        for (int slot = 0; slot < 64; ++slot) f += slots[slot * 8 + 5];
+        s->last.failed_cells = f;
+    }
     s->stats_valid = true;
     if (out) *out = s->last;
     return 0;
@@ -800,6 +836,21 @@ extern "C" int e2vq_iterate(e2vq_session* s, void* device_sym, void* device_dmin
     if (e2vq_pass(s, device_sym, device_dmin)) return 1;
     if (e2vq_pass_stats(s, out)) return 1;
     return e2vq_update(s);
+}
+
+// DDprv of the convergence rule (notes.md:128-153: it carries over between codebook sizes).  A caller that restores
+// an earlier codebook with e2vq_set_codebook restores the matching DD with this, so that e2vq_learn repeats the
+// level exactly as the uninterrupted ladder ran it (bench.py times the real M = 1024 level this way).
+extern "C" int e2vq_set_prev_distortion(e2vq_session* s, double DDprv)
+{
+    s->DDprv = DDprv;
+    return 0;
+}
+
+extern "C" int e2vq_get_prev_distortion(e2vq_session* s, double* DDprv)
+{
+    *DDprv = s->DDprv;
+    return 0;
 }
 
 extern "C" int e2vq_row_stride(int prediction_order) { return e2vq::row_stride(prediction_order + 1); }
@@ -922,6 +973,7 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
 {
     if (s->M < 1) return e2vq_set_error("no codebook");
     if (T < 1) return 0;
+    if (T > (int64_t)INT32_MAX - 64) return e2vq_set_error("%lld frames per quantize call exceed 2^31 - 65 (split the call)", (long long)T);
     HIPCHK(hipSetDevice(s->device));
     const i64 nb = (T + s->FB - 1) / s->FB;
     if (s->pre_enabled && s->M >= s->pre_min_M && e2vq::prefilter_supports(s->NC, s->M)) {
@@ -1043,9 +1095,12 @@ struct LocalGroup {
         }
         return !failed;
     }
+    // first failing rank's message (g_err is thread-local: the workers' text would be lost with their threads)
+    std::string first_error;
     void fail()
     {
         std::lock_guard<std::mutex> lk(mu);
+        if (!failed) first_error = g_err;
         failed = true;
         cv.notify_all();
     }
@@ -1084,7 +1139,7 @@ int local_allreduce(void* user, void* buf, int64_t count, int op, void* stream_)
         }
         g->buf0 = (i64*)buf;
     }
-    if (!g->barrier()) return 1;  // A0: staging area and buf0 published
+    if (!g->barrier()) return e2vq_set_error("in-process group: another rank failed");  // A0: staging area and buf0 published
     if (r > 0) {
         GRPCHK(hipSetDevice(lr->device));
         GRPCHK(hipMemcpyPeerAsync(g->stage + (size_t)(r - 1) * count, g->dev0, buf, lr->device, bytes, stream));
@@ -1156,15 +1211,15 @@ static int load_predictors(const char* const* files, int n, int P_expected, std:
     return 0;
 }
 
-// one rank of a learn: session on `device`, frames [lo, hi) of the training set
+// one rank of a learn: session on `device`, frames [lo, hi) of the training set.
+// Every failing path of a group rank marks the group failed, so the other ranks leave their barriers.
 static int learn_rank(int device, int P, double eps, const char* class_name, const double* base_refl, int base_M,
                       const double* frames, i64 lo, i64 hi, LocalRank* lr, int world, void* target,
                       ecoz2_vq_learn_callback_t cb)
 {
     e2vq_session* s = nullptr;
-    if (e2vq_session_create(device, P, &s)) return 1;
-    int rc = 0;
-    if (lr) rc = e2vq_set_allreduce(s, local_allreduce, lr, lr->rank, world);
+    int rc = e2vq_session_create(device, P, &s);
+    if (!rc && lr) rc = e2vq_set_allreduce(s, local_allreduce, lr, lr->rank, world);
     if (!rc) rc = e2vq_set_frames_host(s, frames + (size_t)lo * (P + 1), hi - lo);
     if (!rc) rc = e2vq_prepare(s);
     if (!rc) rc = base_refl ? e2vq_set_codebook(s, base_refl, base_M) : e2vq_init_codebook(s);
@@ -1172,7 +1227,7 @@ static int learn_rank(int device, int P, double eps, const char* class_name, con
         rc = e2vq_learn(s, eps, env_int("ECOZ2_VQ_MAX_CODEBOOK_SIZE", 2048), class_name,
                         env_str("ECOZ2_VQ_OUT_ROOT", "."), target, cb, nullptr, 0, nullptr);
     if (rc && lr) lr->g->fail();
-    e2vq_session_destroy(s);
+    if (s) e2vq_session_destroy(s);
     return rc;
 }
 
@@ -1199,17 +1254,39 @@ static int learn_common(int P, double eps, const char* class_name, const double*
     g.dev0 = dev0 % ndev;
     g.ev_up.assign((size_t)world, nullptr);
     g.ev_back.assign((size_t)world, nullptr);
+    struct GroupCleanup {  // events and the staging area are released on every return path
+        LocalGroup& g;
+        ~GroupCleanup()
+        {
+            for (hipEvent_t ev : g.ev_up)
+                if (ev) (void)hipEventDestroy(ev);
+            for (hipEvent_t ev : g.ev_back)
+                if (ev) (void)hipEventDestroy(ev);
+            if (g.ev_done) (void)hipEventDestroy(g.ev_done);
+            if (g.stage) {
+                (void)hipSetDevice(g.dev0);
+                (void)hipFree(g.stage);
+            }
+        }
+    } cleanup{g};
     std::vector<LocalRank> ranks((size_t)world);
     for (int r = 0; r < world; ++r) {
         ranks[r] = LocalRank{&g, r, (dev0 + r) % ndev};
         HIPCHK(hipSetDevice(ranks[r].device));
         HIPCHK(hipEventCreateWithFlags(&g.ev_up[r], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&g.ev_back[r], hipEventDisableTiming));
-        if (ranks[r].device != g.dev0) {  // peer access both ways (ignored if already enabled / same device)
-            (void)hipDeviceEnablePeerAccess(g.dev0, 0);
-            (void)hipSetDevice(g.dev0);
-            (void)hipDeviceEnablePeerAccess(ranks[r].device, 0);
-            (void)hipGetLastError();
+        if (ranks[r].device != g.dev0) {  // peer access both ways; "already enabled" is the only tolerated failure
+            for (int dir = 0; dir < 2; ++dir) {
+                const int from = dir ? g.dev0 : ranks[r].device, to = dir ? ranks[r].device : g.dev0;
+                int can = 0;
+                HIPCHK(hipDeviceCanAccessPeer(&can, from, to));
+                if (!can) return e2vq_set_error("device %d cannot access device %d (no peer path): ECOZ2_VQ_GPUS needs P2P", from, to);
+                HIPCHK(hipSetDevice(from));
+                const hipError_t pe = hipDeviceEnablePeerAccess(to, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                    return e2vq_set_error("hipDeviceEnablePeerAccess(%d -> %d) failed: %s", from, to, hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
         }
     }
     HIPCHK(hipSetDevice(g.dev0));
@@ -1236,17 +1313,12 @@ static int learn_common(int P, double eps, const char* class_name, const double*
                             target, cb);
     }
     for (auto& t : th) t.join();
-    for (int r = 0; r < world; ++r) {
-        (void)hipEventDestroy(g.ev_up[r]);
-        (void)hipEventDestroy(g.ev_back[r]);
-    }
-    (void)hipEventDestroy(g.ev_done);
-    if (g.stage) {
-        (void)hipSetDevice(g.dev0);
-        (void)hipFree(g.stage);
-    }
     for (int rc : rcs)
-        if (rc) return rc;
+        if (rc) {
+            // the message of the rank that failed FIRST (the others only report the broken barrier)
+            if (!g.first_error.empty()) snprintf(g_err, sizeof g_err, "%s", g.first_error.c_str());
+            return rc;
+        }
     return 0;
 }
 

@@ -223,6 +223,9 @@ extern "C" int e2vq_prd_read(const char* path, double* frames, int64_t capacity_
 
 extern "C" int e2vq_prd_write(const char* path, const char* class_name, int P, const double* frames, int64_t T)
 {
+    // the header carries the vector count as u32 (src/sequence/mod.rs:60 for .seq; .prd by analogy)
+    if (T < 0 || T > (int64_t)UINT32_MAX) return e2vq_set_error("%s: %lld vectors do not fit the u32 header field", path, (long long)T);
+    if (P < 1) return e2vq_set_error("%s: prediction order %d", path, P);
     if (e2vq_io::mkdirs_for(path) != 0) return e2vq_set_error("%s: cannot create directories", path);
     FILE* f = fopen(path, "wb");
     if (!f) return e2vq_set_error("%s: %s", path, strerror(errno));
@@ -283,6 +286,8 @@ extern "C" int e2vq_cbook_write(const char* path, const char* class_name, int P,
 
 extern "C" int e2vq_seq_write(const char* path, const char* class_name, int M, const uint16_t* sym, int64_t T)
 {
+    if (T < 0 || T > (int64_t)UINT32_MAX) return e2vq_set_error("%s: %lld symbols do not fit the u32 header field", path, (long long)T);
+    if (M < 1 || M > 65536) return e2vq_set_error("%s: codebook size %d does not fit u16 symbols", path, M);
     if (e2vq_io::mkdirs_for(path) != 0) return e2vq_set_error("%s: cannot create directories", path);
     FILE* f = fopen(path, "wb");
     if (!f) return e2vq_set_error("%s: %s", path, strerror(errno));

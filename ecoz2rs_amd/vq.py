@@ -143,6 +143,9 @@ class VqSession:
         """frames: (T, P+1) float64 numpy array, or a CUDA/HIP torch tensor of that shape."""
         if hasattr(frames, "data_ptr"):
             assert frames.is_contiguous() and frames.shape[1] == self.P + 1
+            import torch
+
+            torch.cuda.current_stream(frames.device).synchronize()  # the producer of `frames` has finished
             check(lib.e2vq_set_frames_device(self._h, frames.data_ptr(), frames.shape[0]))
         else:
             a = np.ascontiguousarray(frames, dtype=np.float64)
@@ -211,6 +214,21 @@ class VqSession:
         used, n = C.c_int(), C.c_int64()
         check(lib.e2vq_last_pass_info(self._h, C.byref(used), C.byref(n)))
         return bool(used.value), n.value
+
+    def set_prev_distortion(self, dd):
+        """DDprv of the stopping rule (carries over between codebook sizes); see e2vq_set_prev_distortion."""
+        check(lib.e2vq_set_prev_distortion(self._h, float(dd)))
+
+    def prev_distortion(self):
+        dd = C.c_double()
+        check(lib.e2vq_get_prev_distortion(self._h, C.byref(dd)))
+        return dd.value
+
+    def sweep_launch_counts(self):
+        """(prefiltered, plain) sweep launches of training passes so far"""
+        a, b = C.c_int64(), C.c_int64()
+        check(lib.e2vq_sweep_launch_counts(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def get_rows(self):
         rs = lib.e2vq_row_stride(self.P)

@@ -116,7 +116,9 @@ void e2vq_session_destroy(e2vq_session *s);
 int e2vq_set_stream(e2vq_session *s, void *hip_stream);
 int e2vq_set_allreduce(e2vq_session *s, e2vq_allreduce_fn fn, void *user, int rank, int world);
 
-/* training set: T x (P+1) doubles, row-major (the .prd payload). Copies / re-lays it out in HBM. */
+/* training set: T x (P+1) doubles, row-major (the .prd payload), T <= 2^31 - 65. Copies / re-lays it out in HBM.
+ * e2vq_set_frames_device reads `device_frames` on the session's stream: the caller must have finished writing the
+ * buffer (or have written it on that stream); the read is complete when the call returns. */
 int e2vq_set_frames_host(e2vq_session *s, const double *frames, int64_t T);
 int e2vq_set_frames_device(e2vq_session *s, const void *device_frames, int64_t T);
 /* data statistics (max |x|, global sums, sum of squares) incl. the cross-rank reduction */
@@ -141,6 +143,9 @@ int e2vq_timing_total(e2vq_session *s, double *total_ms, int64_t *passes);
 /* which sweep served the last e2vq_pass: *prefiltered = 1 when the f16-prefiltered sweep ran (P = 36, large M),
  * *fallback_frames = frames it handed to the full FP64 sweep (synchronises the stream) */
 int e2vq_last_pass_info(e2vq_session *s, int *prefiltered, int64_t *fallback_frames);
+/* number of training-pass sweep launches so far, by kernel family (k_pass_pre / k_pass_mfma+generic): lets a
+ * kernel trace of a whole run be cut to the dispatches of a timed region */
+int e2vq_sweep_launch_counts(e2vq_session *s, int64_t *prefiltered, int64_t *plain);
 int e2vq_update(e2vq_session *s);
 /* one whole LBG iteration in a single call: e2vq_pass + e2vq_pass_stats + e2vq_update */
 int e2vq_iterate(e2vq_session *s, void *device_sym, void *device_dmin, e2vq_level_stats *out);
@@ -153,7 +158,14 @@ int e2vq_learn(e2vq_session *s, double epsilon, int max_M, const char *class_nam
                const char *out_root, void *target, ecoz2_vq_learn_callback_t callback,
                e2vq_level_stats *levels, int max_levels, int *num_levels);
 
-/* nearest-codeword assignment of arbitrary frames against the session's codebook */
+/* DDprv of the stopping rule (DDprv - DD)/DD < eps; it carries over between codebook sizes (notes.md:128-153).
+ * After restoring an earlier codebook with e2vq_set_codebook, restore its level's DD here and e2vq_learn repeats the
+ * next level exactly as the uninterrupted ladder ran it. */
+int e2vq_set_prev_distortion(e2vq_session *s, double DDprv);
+int e2vq_get_prev_distortion(e2vq_session *s, double *DDprv);
+
+/* nearest-codeword assignment of arbitrary frames against the session's codebook.  Frames must be finite
+ * (the file entry points check this and fail); T <= 2^31 - 65 per call. */
 int e2vq_quantize_host(e2vq_session *s, const double *frames, int64_t T, uint16_t *sym,
                        double *dmin);
 int e2vq_quantize_device(e2vq_session *s, const void *device_frames, int64_t T, void *device_sym,

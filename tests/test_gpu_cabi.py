@@ -18,7 +18,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 P = 36
 
 
-def test_ecoz2_vq_learn_and_quantize_reproduce_golden_files(tmp_path, monkeypatch):
+def test_ecoz2_vq_learn_and_quantize_reproduce_golden_files(tmp_path, monkeypatch, oracle):
     """config 1 through ecoz2_vq_learn / ecoz2_vq_quantize: emitted .cbook / .seq are byte-identical to the fixtures."""
     meta = json.load(open(os.path.join(GOLD, "config1.json")))
     frames = e.synth.synth_frames(meta["seed"], meta["classes"], P, 0, meta["T"])
@@ -51,6 +51,26 @@ def test_ecoz2_vq_learn_and_quantize_reproduce_golden_files(tmp_path, monkeypatc
     e.vq_learn(str(tmp_path / "data" / "codebooks" / "_" / "eps_0.05_M_0004.cbook"), None, 1e9, "_", files,
                callback=lambda *a: seen2.append(a))
     assert [s[0] for s in seen2] == [8, 16]
+    # ... and the resumed codebooks / callback scalars are the oracle's for the same base (F1b,
+    # src/ecoz2_lib/mod.rs:107-115): bytes of eps_1e+09_M_0008/0016.cbook against oracle.learn(base=M4)
+    _c, _p, base = e.formats.read_cbook(os.path.join(GOLD, "config1_eps_0.05_M_0004.cbook"))
+    rc, levels_b, cbs_b = oracle.learn(frames, 1e9, meta["max_M"], base=base)
+    assert rc == 0 and [lv["M"] for lv in levels_b] == [8, 16] and seen2 == cbs_b
+    for lv in levels_b:
+        got = open(tmp_path / "data" / "codebooks" / "_" / f"eps_1e+09_M_{lv['M']:04d}.cbook", "rb").read()
+        want = tmp_path / "want.cbook"
+        e.formats.write_cbook(str(want), "_", lv["reflections"])
+        assert got == open(want, "rb").read()
+    # a resume with the real epsilon (several passes per level) as well
+    seen3 = []
+    e.vq_learn(str(tmp_path / "data" / "codebooks" / "_" / "eps_0.05_M_0002.cbook"), None, 0.01, "_", files,
+               callback=lambda *a: seen3.append(a))
+    _c, _p, base2 = e.formats.read_cbook(os.path.join(GOLD, "config1_eps_0.05_M_0002.cbook"))
+    rc, levels_c, cbs_c = oracle.learn(frames, 0.01, meta["max_M"], base=base2)
+    assert rc == 0 and seen3 == cbs_c and [lv["M"] for lv in levels_c] == [4, 8, 16]
+    for lv in levels_c:
+        _c, _p, refl = e.formats.read_cbook(str(tmp_path / "data" / "codebooks" / "_" / f"eps_0.01_M_{lv['M']:04d}.cbook"))
+        assert np.array_equal(refl.view(np.uint64), lv["reflections"].view(np.uint64))
 
 
 @pytest.mark.parametrize("T", [1, 15, 16, 17, 63, 64, 65, 129, 4097])
@@ -162,6 +182,67 @@ def test_config3_sized_quantize_properties(oracle):
     assert np.allclose(d, dmin[idx], rtol=1e-12, atol=1e-12)
 
 
+def test_config4_sized_learn_properties(oracle):
+    """configs[3]'s data size on ONE GPU: 2^24 frames, whole LBG ladder 2..1024 with the real convergence rule, then one
+    more pass at M = 1024 whose outputs are checked through size-independent properties and sampled oracle runs:
+      * every frame counted once; per-cell counts == histogram of the emitted symbols; DD == sum of (dmin - 1);
+      * a contiguous 400k-frame slice: symbols and min distortions bit-equal to the oracle;
+      * all member frames of 24 sampled cells (~400k frames picked by the GPU's own symbols): the oracle assigns them to
+        the same cells and its exact integer cell sums equal the GPU's rows of those cells word for word -- the
+        accumulate of the full 16M-frame pass, checked exactly where it was sampled;
+      * shard invariance: the first and second half of the set swept as separate quantize calls (different block /
+        chunk boundaries) give the same symbols."""
+    import torch
+
+    T, M = 1 << 24, 1024
+    frames = e.synth.synth_frames(20244, 20, P, 0, T)
+    os.environ["ECOZ2_VQ_QUIET"] = "1"
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        levels = s.learn(0.05, M)
+        assert [l.M for l in levels] == [2 << i for i in range(10)] and all(l.passes >= 2 for l in levels)
+        assert all(a.avg_distortion > b.avg_distortion for a, b in zip(levels, levels[1:]))
+        refl = s.get_codebook()
+        sym_d = torch.empty(T, dtype=torch.int16, device="cuda")
+        dmin_d = torch.empty(T, dtype=torch.float64, device="cuda")
+        s.run_pass(sym_d, dmin_d)
+        st = s.pass_stats()
+        rows = s.get_rows()
+        prefiltered, fallback = s.last_pass_info()
+        sym = sym_d.cpu().numpy().view(np.uint16)
+        dmin = dmin_d.cpu().numpy()
+        del sym_d, dmin_d
+        half = T // 2 + 12345
+        sym_a = s.quantize(frames[:half], want_dmin=False)
+        sym_b = s.quantize(frames[half:], want_dmin=False)
+    assert prefiltered and 0 <= fallback < T // 20
+    assert np.array_equal(sym[:half], sym_a) and np.array_equal(sym[half:], sym_b)
+    counts = rows[:, 2 * (P + 1)]
+    assert int(counts.sum()) == T and np.array_equal(counts, np.bincount(sym, minlength=M))
+    assert st.empty_cells == int((counts == 0).sum())
+    import math
+    dd = math.fsum((dmin - 1.0).tolist())
+    assert abs(st.DD - dd) <= 1e-9 * abs(dd) and st.avg_distortion == st.DD / T
+    # sampled oracle checks
+    cq = oracle.reflections_to_cq(refl)
+    sl = slice(9_000_000, 9_400_000)
+    sym_o, dmin_o = oracle.quantize(cq, frames[sl])
+    assert np.array_equal(sym[sl], sym_o) and np.array_equal(dmin[sl].view(np.uint64), dmin_o.view(np.uint64))
+    maxabs = float(np.abs(frames).max())
+    sh_r, _ = oracle.shifts(maxabs)
+    Ed = oracle.dist_exponent(cq, maxabs)
+    order = np.argsort(counts)
+    cells = np.concatenate([order[-8:], order[M // 2 - 8:M // 2 + 8]])  # the 8 fullest cells and 16 median ones
+    cells = cells[counts[cells] > 0]
+    idx = np.flatnonzero(np.isin(sym, cells))
+    assert len(idx) >= 200_000
+    sym_m, dmin_m, rows_m = oracle.run_pass(cq, frames[idx], sh_r, Ed)
+    assert np.array_equal(sym_m, sym[idx]) and np.array_equal(dmin_m.view(np.uint64), dmin[idx].view(np.uint64))
+    assert np.array_equal(rows_m[cells], rows[cells])
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -176,44 +257,52 @@ import ecoz2rs_amd as e
 from ecoz2rs_amd import parallel
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-T = 50001
+T, MAXM, SEED = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 lo, hi = parallel.shard_range(T, rank, world)
-frames = e.synth.synth_frames(55, 5, 36, lo, hi - lo)
+frames = e.synth.synth_frames(SEED, 5, 36, lo, hi - lo)
 os.environ["ECOZ2_VQ_QUIET"] = "1"
 s = e.VqSession(36, device=0)
 parallel.bind_torch_stream(s, 0)
 s.set_allreduce(parallel.make_allreduce(0), rank, world)
 s.set_frames(frames); s.prepare(); s.init_codebook()
-levels = s.learn(0.05, 512)
+levels = s.learn(0.05, MAXM)
 np.save(sys.argv[2] + f"/cb_{rank}.npy", s.get_codebook())
 np.save(sys.argv[2] + f"/passes_{rank}.npy", np.array([l.passes for l in levels]))
 s.close(); dist.destroy_process_group()
 """
 
 
-def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
-    """Sharded learn (2 processes, gloo exchange of the int64 cell sums) gives the single-rank codebook bit-for-bit."""
+@pytest.mark.parametrize("T,max_m,seed,world", [(50001, 512, 55, 2), (100003, 1024, 57, 2), (100003, 1024, 57, 3)])
+def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path, oracle, T, max_m, seed, world):
+    """Sharded learn (N processes, gloo exchange of the int64 cell sums) gives the single-rank codebook bit-for-bit --
+    up to config 4's codebook size M = 1024 (prefiltered sweep + incremental accumulate under a real exchange) --
+    and both equal the oracle's ladder."""
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT)
     port = _free_port()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=env))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path), str(T), str(max_m), str(seed)],
+                                      env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
-    frames = e.synth.synth_frames(55, 5, P, 0, 50001)
+    frames = e.synth.synth_frames(seed, 5, P, 0, T)
     os.environ["ECOZ2_VQ_QUIET"] = "1"
     with e.VqSession(P) as s:
         s.set_frames(frames)
         s.prepare()
         s.init_codebook()
-        levels = s.learn(0.05, 512)
+        levels = s.learn(0.05, max_m)
         ref = s.get_codebook()
-    for r in range(2):
+    for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"cb_{r}.npy").view(np.uint64), ref.view(np.uint64))
         assert list(np.load(tmp_path / f"passes_{r}.npy")) == [l.passes for l in levels]
+    rc, levels_o, _cbs = oracle.learn(frames, 0.05, max_m)
+    assert rc == 0 and [l.passes for l in levels] == [lv["passes"] for lv in levels_o]
+    assert np.array_equal(ref.view(np.uint64), levels_o[-1]["reflections"].view(np.uint64))
+    assert [l.DD for l in levels] == [lv["DD"] for lv in levels_o]
 
 
 _NCCL_SCRIPT = r"""

@@ -94,3 +94,39 @@ def test_learn_ladder_bit_exact(oracle, T, maxM, tmp_path):
     for o in levels_o:
         _cls, _P, refl = e.formats.read_cbook(str(tmp_path / "data" / "codebooks" / "_" / f"eps_0.05_M_{o['M']:04d}.cbook"))
         assert np.array_equal(refl.view(np.uint64), o["reflections"].view(np.uint64))
+
+
+@pytest.mark.parametrize("Pn", [36, 70])
+def test_failed_cells_are_counted_like_the_oracle(oracle, Pn):
+    """Cells whose Levinson recursion fails (status 2 of src/lpc/lpca_r_rs.rs:37-39) keep their codeword and are counted
+    in e2vq_level_stats.failed_cells -- fused wave-per-cell kernel (P = 36) and thread-per-cell kernels (P = 70)."""
+    rng = np.random.default_rng(5)
+    good = e.synth.synth_frames(9, 2, Pn, 0, 300)
+    # r = [1, .9, -.9, 0...]: pe turns negative at k = 2, for the frame and for any sum of such frames
+    bad = np.zeros((200, Pn + 1))
+    bad[:, 0], bad[:, 1], bad[:, 2] = 1.0, 0.9, -0.9
+    bad[:, :3] *= (1.0 + 1e-3 * rng.standard_normal((200, 1)))
+    bad *= 40.0  # far from every codeword of the good frames: they gather in cells of their own
+    frames = np.concatenate([good, bad])
+    M = 4
+    refl = np.zeros((M, Pn + 1))
+    for i in range(M):
+        refl[i, 1:] = oracle.lpca_r(good[i * 50], Pn)[2][1:]
+    cq = oracle.reflections_to_cq(refl)
+    rc, st = oracle.data_stats(frames)
+    assert rc == 0
+    sh_r, _ = oracle.shifts(st.maxabs)
+    _s, _d, rows_o = oracle.run_pass(cq, frames, sh_r, oracle.dist_exponent(cq, st.maxabs))
+    refl_o, failed_o = oracle.update(rows_o, Pn, sh_r, refl)
+    assert failed_o >= 1
+    with e.VqSession(Pn) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.set_codebook(refl)
+        s.run_pass()
+        assert np.array_equal(s.get_rows(), rows_o)
+        ls = s.pass_stats()
+        s.update()
+        refl_g = s.get_codebook()
+    assert ls.failed_cells == failed_o
+    assert np.array_equal(refl_g.view(np.uint64), refl_o.view(np.uint64))
