@@ -191,9 +191,10 @@ def test_config4_sized_learn_properties(oracle):
         the same cells and its exact integer cell sums equal the GPU's rows of those cells word for word -- the
         accumulate of the full 16M-frame pass, checked exactly where it was sampled;
       * shard invariance: the first and second half of the set swept as separate quantize calls (different block /
-        chunk boundaries) give the same symbols."""
-    import torch
-
+        chunk boundaries) give the same symbols.
+    (No torch in this process: torch bundles its own HIP/HSA runtime, and a second runtime initialised after the
+    library's finds no device.  The symbols of the training pass are tied to the quantize entry's through the cell
+    counts, which must equal the histogram of the quantize symbols.)"""
     T, M = 1 << 24, 1024
     frames = e.synth.synth_frames(20244, 20, P, 0, T)
     os.environ["ECOZ2_VQ_QUIET"] = "1"
@@ -205,15 +206,12 @@ def test_config4_sized_learn_properties(oracle):
         assert [l.M for l in levels] == [2 << i for i in range(10)] and all(l.passes >= 2 for l in levels)
         assert all(a.avg_distortion > b.avg_distortion for a, b in zip(levels, levels[1:]))
         refl = s.get_codebook()
-        sym_d = torch.empty(T, dtype=torch.int16, device="cuda")
-        dmin_d = torch.empty(T, dtype=torch.float64, device="cuda")
-        s.run_pass(sym_d, dmin_d)
+        s.run_pass()
         st = s.pass_stats()
         rows = s.get_rows()
         prefiltered, fallback = s.last_pass_info()
-        sym = sym_d.cpu().numpy().view(np.uint16)
-        dmin = dmin_d.cpu().numpy()
-        del sym_d, dmin_d
+        # the same assignment through the quantize entry (other kernels, other chunk boundaries: 4M-frame chunks)
+        sym, dmin = s.quantize(frames)
         half = T // 2 + 12345
         sym_a = s.quantize(frames[:half], want_dmin=False)
         sym_b = s.quantize(frames[half:], want_dmin=False)
