@@ -4,6 +4,7 @@
 // and its mains (:151-216): same flag names, defaults, file-list resolution and messages.
 // Like the reference (src/vq/mod.rs:146-148) errors are printed and the exit code stays 0
 // unless the arguments themselves are unusable.
+#include "../../include/ecoz2_classify.h"
 #include "../../include/ecoz2_vq.h"
 #include "vq_io.h"
 
@@ -32,6 +33,9 @@ static int usage()
             "  ecoz2 vq show [-f <from>] [-t <to>] <codebook>\n"
             "  ecoz2 seq show [-c] [-L] [--full] [--pickle out.pkl -M <M> --tt <TRAIN|TEST> [--class-name c]] <file.seq|tt.csv>...\n"
             "  ecoz2 prd show [--from a] [--to b] <file.prd>\n"
+            "  ecoz2 {nb|mm} learn -M <M> [--class-name <class>] <file.seq|dirs|tt.csv>...\n"
+            "  ecoz2 {nb|mm} classify -M <M> [-r] --tt <TRAIN|TEST> --models <files|dirs>... --sequences <files|dirs|tt.csv>...\n"
+            "  ecoz2 {nb|mm} show --model <file>\n"
             "  ecoz2 cversion\n");
     return 2;
 }
@@ -315,6 +319,70 @@ static int prd_show(int argc, char** argv)
     return 0;
 }
 
+// `ecoz2 nb ...` / `ecoz2 mm ...`: option structs and mains of /root/reference/src/nb/mod.rs:32-161 and
+// src/mm/mod.rs:32-161 (identical shapes; the models differ)
+static bool is_csv_list(const std::vector<std::string>& v)
+{
+    return v.size() == 1 && v[0].size() > 4 && v[0].compare(v[0].size() - 4, 4, ".csv") == 0;
+}
+
+static int seq_model_cmd(bool nb, int argc, char** argv)
+{
+    if (argc < 1) return usage();
+    const std::string cmd = argv[0];
+    const char* ext = nb ? ".nb" : ".mm";
+    int M = -1;
+    bool ranked = false;
+    std::string cls, tt, model;
+    std::vector<std::string> models, sequences;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if ((a == "-M" || a == "--codebook-size") && i + 1 < argc) M = atoi(argv[++i]);
+        else if ((a == "--class-name") && i + 1 < argc) cls = argv[++i];
+        else if (a == "-r" || a == "--show-ranked") ranked = true;
+        else if (a == "--tt" && i + 1 < argc) tt = argv[++i];
+        else if ((a == "-m" || a == "--model") && i + 1 < argc) model = argv[++i];
+        else if (a == "--models") { while (i + 1 < argc && !is_flag(argv[i + 1])) models.push_back(argv[++i]); }
+        else if (a == "--sequences") { while (i + 1 < argc && !is_flag(argv[i + 1])) sequences.push_back(argv[++i]); }
+        else if (!is_flag(argv[i])) sequences.push_back(a);
+        else return usage();
+    }
+    if (cmd == "show") {
+        if (model.empty()) return usage();
+        if (nb ? ecoz2_nb_show(model.c_str()) : ecoz2_mm_show(model.c_str())) printf("%s\n", e2vq_last_error());
+        return 0;
+    }
+    if (M < 1 || sequences.empty()) return usage();
+    const std::string subdir = "sequences/M" + std::to_string(M);
+    std::vector<std::string> seq_files;
+    if (cmd == "learn") {  // main_nbayes_learn / main_mm_learn: resolve_files(sequences, "TRAIN", class_name, ..)
+        int rc = is_csv_list(sequences) ? e2vq_io::files_from_csv(sequences[0], "TRAIN", cls, subdir, ".seq", nullptr, seq_files)
+                                        : e2vq_io::resolve_filenames(sequences, ".seq", seq_files);
+        if (rc || seq_files.empty()) { printf("%s\n", rc ? e2vq_last_error() : "No sequences given"); return 0; }
+        auto ps = cptrs(seq_files);
+        if (nb ? ecoz2_nb_learn(M, ps.data(), (int)ps.size(), nullptr, 0) : ecoz2_mm_learn(M, ps.data(), (int)ps.size(), nullptr, 0))
+            printf("%s\n", e2vq_last_error());
+        return 0;
+    }
+    if (cmd == "classify") {  // main_nbayes_classify / main_mm_classify
+        if (tt.empty() || models.empty()) return usage();
+        std::vector<std::string> model_files;
+        e2vq_io::resolve_filenames(models, ext, model_files);
+        if (model_files.empty()) { printf("No models given\n"); return 0; }
+        int rc = is_csv_list(sequences) ? e2vq_io::files_from_csv(sequences[0], tt, "", subdir, ".seq", nullptr, seq_files)
+                                        : e2vq_io::resolve_filenames(sequences, ".seq", seq_files);
+        if (rc) { printf("%s\n", e2vq_last_error()); return 0; }
+        printf("number of %s models: %zu  number of sequences: %zu\n", nb ? "NBayes" : "MM", model_files.size(), seq_files.size());
+        printf("show_ranked = %s\n", ranked ? "true" : "false");
+        auto pm = cptrs(model_files), ps = cptrs(seq_files);
+        if (nb ? ecoz2_nb_classify(pm.data(), (int)pm.size(), ps.data(), (int)ps.size(), ranked, M)
+               : ecoz2_mm_classify(pm.data(), (int)pm.size(), ps.data(), (int)ps.size(), ranked, M))
+            printf("%s\n", e2vq_last_error());
+        return 0;
+    }
+    return usage();
+}
+
 int main(int argc, char** argv)
 {
     if (argc >= 2 && !strcmp(argv[1], "cversion")) {
@@ -323,6 +391,8 @@ int main(int argc, char** argv)
     }
     if (argc >= 3 && !strcmp(argv[1], "seq") && !strcmp(argv[2], "show")) return seq_show(argc - 3, argv + 3);
     if (argc >= 3 && !strcmp(argv[1], "prd") && !strcmp(argv[2], "show")) return prd_show(argc - 3, argv + 3);
+    if (argc >= 3 && !strcmp(argv[1], "nb")) return seq_model_cmd(true, argc - 2, argv + 2);
+    if (argc >= 3 && !strcmp(argv[1], "mm")) return seq_model_cmd(false, argc - 2, argv + 2);
     if (argc < 3 || strcmp(argv[1], "vq") != 0) return usage();
     const std::string cmd = argv[2];
     if (cmd == "learn") return vq_learn(argc - 3, argv + 3);

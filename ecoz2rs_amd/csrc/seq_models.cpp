@@ -13,6 +13,7 @@
 #include "../../include/ecoz2_vq.h"
 #include "vq_io.h"
 
+#include <errno.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -719,6 +720,11 @@ std::vector<std::string> to_strings(const char* const* v, int n)
     return out;
 }
 
+// the callers may be Python / Rust programs with their own stdout buffering: leave nothing in C stdio's buffer
+struct FlushStdout {
+    ~FlushStdout() { fflush(stdout); }
+};
+
 void copy_out(const std::string& s, char* out, int cap)
 {
     if (out && cap > 0) snprintf(out, (size_t)cap, "%s", s.c_str());
@@ -786,6 +792,7 @@ extern "C" int e2vq_c12n_run(const char* const* model_class_names, int num_model
                              const char* const* case_class_names, const char* const* case_titles, const double* probs,
                              int num_cases, int show_ranked, const char* out_base_name, int* result, int* confusion)
 {
+    FlushStdout flush_on_return;
     if (num_models < 1 || num_cases < 0) return e2vq_set_error("e2vq_c12n_run: bad arguments");
     C12nResults c(to_strings(model_class_names, num_models));
     for (int k = 0; k < num_cases; ++k) {
@@ -811,6 +818,7 @@ extern "C" int e2vq_c12n_run(const char* const* model_class_names, int num_model
 extern "C" int ecoz2_nb_learn(int codebook_size, const char* const* seq_filenames, int num_sequences, char* out_path,
                               int out_path_cap)
 {
+    FlushStdout flush_on_return;
     if (!seq_filenames || num_sequences < 1 || codebook_size < 1) return e2vq_set_error("ecoz2_nb_learn: bad arguments");
     // nbayes::learn, src/nb/nbayes.rs:63-114
     Sequence seq;
@@ -859,6 +867,7 @@ extern "C" int e2vq_nb_log_prob(const char* nb_filename, const char* seq_filenam
 extern "C" int ecoz2_nb_classify(const char* const* nb_filenames, int num_models, const char* const* seq_filenames,
                                  int num_sequences, int show_ranked, int codebook_size)
 {
+    FlushStdout flush_on_return;
     if (!nb_filenames || num_models < 1 || !seq_filenames || num_sequences < 0)
         return e2vq_set_error("ecoz2_nb_classify: bad arguments");
     // nbayes::classify, src/nb/nbayes.rs:116-153
@@ -892,6 +901,7 @@ extern "C" int ecoz2_nb_classify(const char* const* nb_filenames, int num_models
 
 extern "C" int ecoz2_nb_show(const char* nb_filename)
 {
+    FlushStdout flush_on_return;
     NBayes m;
     if (nb_load(nb_filename, m)) return 1;
     // NBayes::show, src/nb/nbayes.rs:21-35
@@ -909,6 +919,7 @@ extern "C" int ecoz2_nb_show(const char* nb_filename)
 extern "C" int ecoz2_mm_learn(int codebook_size, const char* const* seq_filenames, int num_sequences, char* out_path,
                               int out_path_cap)
 {
+    FlushStdout flush_on_return;
     if (!seq_filenames || num_sequences < 1 || codebook_size < 1) return e2vq_set_error("ecoz2_mm_learn: bad arguments");
     // markov::learn, src/mm/markov.rs:59-126
     Sequence seq;
@@ -990,6 +1001,7 @@ extern "C" int e2vq_mm_log_prob(const char* mm_filename, const char* seq_filenam
 extern "C" int ecoz2_mm_classify(const char* const* mm_filenames, int num_models, const char* const* seq_filenames,
                                  int num_sequences, int show_ranked, int codebook_size)
 {
+    FlushStdout flush_on_return;
     if (!mm_filenames || num_models < 1 || !seq_filenames || num_sequences < 0)
         return e2vq_set_error("ecoz2_mm_classify: bad arguments");
     // markov::classify, src/mm/markov.rs:128-167
@@ -1021,6 +1033,7 @@ extern "C" int ecoz2_mm_classify(const char* const* mm_filenames, int num_models
 
 extern "C" int ecoz2_mm_show(const char* mm_filename)
 {
+    FlushStdout flush_on_return;
     MM m;
     if (mm_load(mm_filename, m)) return 1;
     // MM::show, src/mm/markov.rs:27-40
