@@ -16,4 +16,4 @@ from .vq import (  # noqa: F401
     vq_show,
     version,
 )
-from . import classify, formats, synth  # noqa: F401
+from . import classify, formats, hmm, synth  # noqa: F401

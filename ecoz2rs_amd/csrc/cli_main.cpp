@@ -36,6 +36,12 @@ static int usage()
             "  ecoz2 {nb|mm} learn -M <M> [--class-name <class>] <file.seq|dirs|tt.csv>...\n"
             "  ecoz2 {nb|mm} classify -M <M> [-r] --tt <TRAIN|TEST> --models <files|dirs>... --sequences <files|dirs|tt.csv>...\n"
             "  ecoz2 {nb|mm} show --model <file>\n"
+            "  ecoz2 hmm learn [-N 5] -M <M> [-t 3] [-I -1] [-e 1e-05] [-a 0.3] [-s <seed>] [--ser] [--class-name c]\n"
+            "                  --sequences <file.seq|dirs|tt.csv>...\n"
+            "  ecoz2 hmm classify [-r] [-c|--c12n <out.csv>] -m|--models <files|dirs>... --tt <TRAIN|TEST> -M <M> [--class-name c]\n"
+            "                  (-s|--sequences <files|dirs|tt.csv>... | --predictors <files|dirs|tt.csv>... --codebooks <files|dirs>...\n"
+            "                   [--predictors-dir-template <t>])\n"
+            "  ecoz2 hmm show --hmm <file> [-f|--format \"%%Lg \"]\n"
             "  ecoz2 cversion\n");
     return 2;
 }
@@ -383,6 +389,106 @@ static int seq_model_cmd(bool nb, int argc, char** argv)
     return usage();
 }
 
+// `ecoz2 hmm {learn,classify,show}`: option structs and mains of /root/reference/src/hmm/mod.rs:40-291
+static void hmm_callback(char*, double) {}  // the reference's Rust callback is a no-op too (src/hmm/mod.rs:205-207)
+
+static int hmm_cmd(int argc, char** argv)
+{
+    if (argc < 1) return usage();
+    const std::string cmd = argv[0];
+    int N = 5, M = -1, type = 3, max_iterations = -1;
+    double epsilon = 1e-05, val_auto = 0.3;
+    long seed = -1;
+    bool ser = false, ranked = false;
+    std::string cls, tt, c12n, hmm, format = "%Lg ", tmpl = "data/predictors";
+    std::vector<std::string> sequences, models, predictors, codebooks;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&](const char* name) -> const char* {
+            if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", name); exit(2); }
+            return argv[++i];
+        };
+        auto many = [&](std::vector<std::string>& v) { while (i + 1 < argc && !is_flag(argv[i + 1])) v.push_back(argv[++i]); };
+        if (a == "-N" || a == "--num-states") N = atoi(val("-N"));
+        else if (a == "-M" || a == "--codebook-size") M = atoi(val("-M"));
+        else if (a == "-t") type = atoi(val("-t"));
+        else if (a == "-I" || a == "--max-iterations") max_iterations = atoi(val("-I"));
+        else if (a == "-e") epsilon = atof(val("-e"));
+        else if (a == "-a") val_auto = atof(val("-a"));
+        else if (cmd == "learn" && (a == "-s" || a == "--seed")) seed = atol(val("-s"));
+        else if (a == "--ser") ser = true;
+        else if (a == "--class-name") cls = val("--class-name");
+        else if (a == "-r" || a == "--show-ranked") ranked = true;
+        else if (a == "-c" || a == "--c12n") c12n = val("--c12n");
+        else if (a == "--tt") tt = val("--tt");
+        else if (a == "-m" || a == "--models") many(models);
+        else if (a == "-s" || a == "--sequences") many(sequences);
+        else if (a == "--predictors") many(predictors);
+        else if (a == "--predictors-dir-template") tmpl = val("--predictors-dir-template");
+        else if (a == "--codebooks") many(codebooks);
+        else if (a == "--hmm") hmm = val("--hmm");
+        else if (a == "-f" || a == "--format") format = val("--format");
+        else if (!is_flag(argv[i])) sequences.push_back(a);
+        else return usage();
+    }
+    if (cmd == "show") {  // main_hmm_show
+        if (hmm.empty()) return usage();
+        printf("hmm_show: hmm_filename=%s format=%s\n", hmm.c_str(), format.c_str());  // src/ecoz2_lib/mod.rs:482-486
+        if (ecoz2_hmm_show(hmm.c_str(), format.c_str())) printf("%s\n", e2vq_last_error());
+        return 0;
+    }
+    if (M < 1) return usage();
+    const std::string subdir = "sequences/M" + std::to_string(M);
+    if (cmd == "learn") {  // main_hmm_learn, src/hmm/mod.rs:172-217
+        std::vector<std::string> seq_files;
+        int rc = is_csv_list(sequences) ? e2vq_io::files_from_csv(sequences[0], "TRAIN", cls, subdir, ".seq", nullptr, seq_files)
+                                        : e2vq_io::resolve_filenames(sequences, ".seq", seq_files);
+        if (rc || seq_files.empty()) { printf("%s\n", rc ? e2vq_last_error() : "No sequences given"); return 0; }
+        printf("ECOZ2 C version: %s\n", ecoz2_version());
+        printf("sequences: %zu\n", seq_files.size());
+        printf("val_auto = %g\n", val_auto);
+        ecoz2_set_random_seed(seed);
+        auto ps = cptrs(seq_files);
+        if (ecoz2_hmm_learn(N, type, ps.data(), (unsigned)ps.size(), epsilon, val_auto, max_iterations, ser ? 0 : 1, hmm_callback))
+            printf("%s\n", e2vq_last_error());
+        return 0;
+    }
+    if (cmd == "classify") {  // main_hmm_classify, src/hmm/mod.rs:219-283
+        if (models.empty() || tt.empty() || (predictors.empty() == sequences.empty())) return usage();
+        std::vector<std::string> hmm_files;
+        e2vq_io::resolve_filenames(models, ".hmm", hmm_files);
+        if (hmm_files.empty()) { printf("No models given\n"); return 0; }
+        auto pm = cptrs(hmm_files);
+        const char* c12n_file = c12n.empty() ? nullptr : c12n.c_str();
+        if (!sequences.empty()) {
+            std::vector<std::string> seq_files;
+            int rc = is_csv_list(sequences) ? e2vq_io::files_from_csv(sequences[0], tt, cls, subdir, ".seq", nullptr, seq_files)
+                                            : e2vq_io::resolve_filenames(sequences, ".seq", seq_files);
+            if (rc) { printf("%s\n", e2vq_last_error()); return 0; }
+            printf("ECOZ2 C version: %s\n", ecoz2_version());
+            printf("number of HMM models: %zu  number of sequences: %zu\n", hmm_files.size(), seq_files.size());
+            printf("show_ranked = %s\n", ranked ? "true" : "false");
+            auto ps = cptrs(seq_files);
+            if (ecoz2_hmm_classify(pm.data(), (unsigned)pm.size(), ps.data(), (unsigned)ps.size(), ranked, c12n_file))
+                printf("%s\n", e2vq_last_error());
+        } else {
+            if (codebooks.empty()) return usage();
+            std::vector<std::string> cb_files, prd_files;
+            e2vq_io::resolve_filenames(codebooks, ".cbook", cb_files);
+            if (cb_files.empty()) { printf("No codebooks given\n"); return 0; }
+            int rc = is_csv_list(predictors) ? e2vq_io::files_from_csv(predictors[0], tt, cls, "", ".prd", &tmpl, prd_files)
+                                             : e2vq_io::resolve_filenames(predictors, ".prd", prd_files);
+            if (rc) { printf("%s\n", e2vq_last_error()); return 0; }
+            auto pc = cptrs(cb_files), pp = cptrs(prd_files);
+            if (ecoz2_hmm_classify_predictors(pm.data(), (unsigned)pm.size(), pc.data(), (int)pc.size(), pp.data(), (int)pp.size(),
+                                              ranked, c12n_file))
+                printf("%s\n", e2vq_last_error());
+        }
+        return 0;
+    }
+    return usage();
+}
+
 int main(int argc, char** argv)
 {
     if (argc >= 2 && !strcmp(argv[1], "cversion")) {
@@ -391,6 +497,7 @@ int main(int argc, char** argv)
     }
     if (argc >= 3 && !strcmp(argv[1], "seq") && !strcmp(argv[2], "show")) return seq_show(argc - 3, argv + 3);
     if (argc >= 3 && !strcmp(argv[1], "prd") && !strcmp(argv[2], "show")) return prd_show(argc - 3, argv + 3);
+    if (argc >= 3 && !strcmp(argv[1], "hmm")) return hmm_cmd(argc - 2, argv + 2);
     if (argc >= 3 && !strcmp(argv[1], "nb")) return seq_model_cmd(true, argc - 2, argv + 2);
     if (argc >= 3 && !strcmp(argv[1], "mm")) return seq_model_cmd(false, argc - 2, argv + 2);
     if (argc < 3 || strcmp(argv[1], "vq") != 0) return usage();

@@ -1,0 +1,298 @@
+// hmm_device.hip -- HIP kernels (gfx950) of the HMM consumers of the VQ path:
+//   k_hmm_score   scaled forward pass of every (sequence, model) pair: one wavefront per pair, lane = state
+//   k_hmm_fb      E-step of Baum-Welch: forward, backward and the expected counts of one sequence per wavefront,
+//                 added to exact fixed-point accumulators (int64 limb sums: order-free, hence deterministic and
+//                 shardable across GPUs with an integer all-reduce, like the VQ cell sums)
+//   k_hmm_reestimate / k_hmm_adjustb   M-step
+// Arithmetic: IEEE f64 multiply / fma / add / divide in the order oracle/hmm_oracle.h defines -- the kernels are
+// bit-exact against the oracle.  No transcendental runs on the device: P(O) leaves as (mantissa, exponent) and the
+// host takes the logarithm.
+//
+// Wave layout (N <= 64 states): lane j owns state j.  The sums over the other state index are lane-uniform loops that
+// broadcast one lane's value with v_readlane (SGPR operand of the fma) and read the transition matrix from LDS --
+// column access A[i][j] with j = lane for the forward pass, and a transposed copy AT[j][i] with i = lane for the
+// backward pass, so both are conflict-free.  Each step is a dependent chain (N fmas, N adds, one divide), so the
+// parallelism is across waves: S x K pairs for scoring, one wave per training sequence for the E-step.
+#include "hmm_device.h"
+#include "vq_fixed.h"
+
+namespace e2hmm {
+
+typedef long long i64;
+typedef unsigned long long u64;
+
+__device__ __forceinline__ double bcast(double x, int lane)
+{
+    // `lane` is wave-uniform: two v_readlane_b32
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// P = p * 2^E with p in [0.5, 1): one more factor c (frexp is exact; the product rounds once)
+__device__ __forceinline__ void scale_step(double c, double& p, i64& E)
+{
+    int e, e2;
+    const double m = frexp(c, &e);
+    p = frexp(p * m, &e2);
+    E += (i64)e + (i64)e2;
+}
+
+constexpr int SCORE_WAVES = 4;
+
+// grid: (ceil(S / SCORE_WAVES), K).  models[k]: N, M, pi, A, B.  out index: s * K + k.
+__global__ __launch_bounds__(64 * SCORE_WAVES) void k_hmm_score(const ModelDev* __restrict__ models, int K,
+                                                                 const unsigned short* __restrict__ sym,
+                                                                 const i64* __restrict__ offs, int S,
+                                                                 double* __restrict__ mant, i64* __restrict__ exp2,
+                                                                 int* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* As = (double*)smem;  // [N][N], row i = from-state
+    const int k = blockIdx.y;
+    const ModelDev md = models[k];
+    const int N = md.N, M = md.M;
+    for (int x = threadIdx.x; x < N * N; x += blockDim.x) As[x] = md.A[x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int s = blockIdx.x * SCORE_WAVES + wib;
+    if (s >= S) return;
+    const i64 base = offs[s];
+    const i64 T = offs[s + 1] - base;
+    const bool act = lane < N;
+    const double pij = act ? md.pi[lane] : 0.0;
+    const double* Brow = md.B + (size_t)(act ? lane : 0) * M;
+    double al = 0.0, p = 0.5;
+    i64 E = 1;
+    int st = 0;
+    for (i64 t0 = 0; t0 < T && st == 0; t0 += 64) {
+        // this chunk's symbols: one per lane, handed out by readlane
+        const int n = (int)((T - t0) < 64 ? (T - t0) : 64);
+        const int mysym = lane < n ? (int)sym[base + t0 + lane] : 0;
+        int o = __builtin_amdgcn_readlane(mysym, 0);
+        double b = (act && o < M) ? Brow[o] : 0.0;
+        for (int q = 0; q < n; ++q) {
+            const double bq = b;
+            const int oq = o;
+            if (q + 1 < n) {  // next step's emission probability is requested before this step's chain runs
+                o = __builtin_amdgcn_readlane(mysym, q + 1);
+                b = (act && o < M) ? Brow[o] : 0.0;
+            }
+            if (oq >= M) {  // symbol outside the model's alphabet
+                st = 2;
+                break;
+            }
+            double nx;
+            if (t0 + q == 0) {
+                nx = pij * bq;
+            } else {
+                double acc = 0.0;
+                for (int i = 0; i < N; ++i) acc = fma(bcast(al, i), act ? As[i * N + lane] : 0.0, acc);
+                nx = acc * bq;
+            }
+            if (!act) nx = 0.0;
+            double c = 0.0;
+            for (int j = 0; j < N; ++j) c = c + bcast(nx, j);
+            if (!(c > 0.0)) {
+                st = 1;
+                break;
+            }
+            al = nx / c;
+            scale_step(c, p, E);
+        }
+    }
+    if (lane == 0) {
+        const size_t idx = (size_t)s * K + k;
+        mant[idx] = st == 0 ? p : 0.0;
+        exp2[idx] = st == 0 ? E : 0;
+        status[idx] = st;
+    }
+}
+
+__device__ __forceinline__ void acc_add(i64* cell, double x)
+{
+    int hi, lo;
+    e2vq::fix2(x, ACC_SHIFT, hi, lo);
+    atomicAdd((u64*)&cell[0], (u64)(i64)hi);
+    atomicAdd((u64*)&cell[1], (u64)(i64)lo);
+}
+
+constexpr int FB_WAVES = 4;
+
+// E-step: one wave per sequence of ONE model.  alpha_buf: [total symbols][N] scratch, c_buf: [total symbols].
+__global__ __launch_bounds__(64 * FB_WAVES) void k_hmm_fb(ModelDev md, const unsigned short* __restrict__ sym,
+                                                           const i64* __restrict__ offs, int S,
+                                                           double* __restrict__ alpha_buf, double* __restrict__ c_buf,
+                                                           i64* __restrict__ acc, double* __restrict__ mant,
+                                                           i64* __restrict__ exp2, int* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int N = md.N, M = md.M;
+    double* As = (double*)smem;  // [i][j]
+    double* ATs = As + N * N;    // [j][i]
+    for (int x = threadIdx.x; x < N * N; x += blockDim.x) {
+        const double v = md.A[x];
+        As[x] = v;
+        ATs[(x % N) * N + (x / N)] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int s = blockIdx.x * FB_WAVES + wib;
+    if (s >= S) return;
+    i64* PI = acc;
+    i64* AN = PI + 2 * N;
+    i64* AD = AN + 2 * (i64)N * N;
+    i64* BN = AD + 2 * N;
+    i64* BD = BN + 2 * (i64)N * M;
+    i64* counts = BD + 2 * N;
+    const i64 base = offs[s];
+    const i64 T = offs[s + 1] - base;
+    const bool act = lane < N;
+    const int ln = act ? lane : 0;
+    const double* Brow = md.B + (size_t)ln * M;
+    double* alpha = alpha_buf + (size_t)base * N;
+    double* cs = c_buf + base;
+    // ---- forward (as k_hmm_score), keeping alpha^_t and c_t ------------------------------------------------
+    double al = 0.0, p = 0.5;
+    i64 E = 1;
+    int st = T < 1 ? 1 : 0;
+    const double pij = act ? md.pi[lane] : 0.0;
+    for (i64 t = 0; t < T && st == 0; ++t) {
+        const int o = (int)sym[base + t];  // wave-uniform (scalar load)
+        if (o >= M) {
+            st = 2;
+            break;
+        }
+        const double b = act ? Brow[o] : 0.0;
+        double nx;
+        if (t == 0) {
+            nx = pij * b;
+        } else {
+            double a = 0.0;
+            for (int i = 0; i < N; ++i) a = fma(bcast(al, i), As[i * N + ln], a);
+            nx = a * b;
+        }
+        if (!act) nx = 0.0;
+        double c = 0.0;
+        for (int j = 0; j < N; ++j) c = c + bcast(nx, j);
+        if (!(c > 0.0)) {
+            st = 1;
+            break;
+        }
+        al = nx / c;
+        if (act) alpha[(size_t)t * N + lane] = al;
+        if (lane == 0) cs[t] = c;
+        scale_step(c, p, E);
+    }
+    if (lane == 0) {
+        mant[s] = st == 0 ? p : (T < 1 ? 0.5 : 0.0);
+        exp2[s] = st == 0 ? E : (T < 1 ? 1 : 0);
+        status[s] = st;
+        atomicAdd((u64*)&counts[st == 0 ? 0 : 1], 1ull);
+    }
+    if (st != 0) return;  // (wave-uniform) the sequence contributes nothing
+    // ---- backward + expected counts ---------------------------------------------------------------------------
+    // `al` is alpha^_{T-1} already; every later alpha^_t was written by this very lane, so no fence is needed
+    double beta = 1.0;
+    for (i64 t = T - 1; t >= 0; --t) {
+        if (t < T - 1) {
+            al = act ? alpha[(size_t)t * N + lane] : 0.0;
+            const int o1 = (int)sym[base + t + 1];
+            // c_{t+1}: lane 0 re-reads its own store (same-thread order) and hands it to the wave
+            const double c1 = bcast(lane == 0 ? cs[t + 1] : 0.0, 0);
+            const double u = act ? (Brow[o1] * beta) / c1 : 0.0;  // u_j, j = lane
+            // xi_t(i, j) = (alpha^_t(i) * A_ij) * u_j   -- lane j, all i
+            for (int i = 0; i < N; ++i) {
+                const double x = (bcast(al, i) * As[i * N + ln]) * u;
+                if (act) acc_add(AN + 2 * ((i64)i * N + lane), x);
+            }
+            // beta^_t(i) = chain_j fma(A_ij, u_j)        -- lane i, all j (transposed copy)
+            double a = 0.0;
+            for (int j = 0; j < N; ++j) a = fma(ATs[j * N + ln], bcast(u, j), a);
+            beta = a;
+        }
+        if (act) {
+            const double g = al * beta;
+            const int o = (int)sym[base + t];
+            if (t < T - 1) acc_add(AD + 2 * lane, g);
+            acc_add(BN + 2 * ((i64)lane * M + o), g);
+            acc_add(BD + 2 * lane, g);
+            if (t == 0) acc_add(PI + 2 * lane, g);
+        }
+    }
+}
+
+// M-step: one thread per parameter
+__global__ void k_hmm_reestimate(int N, int M, const i64* __restrict__ acc, double* __restrict__ pi,
+                                 double* __restrict__ A, double* __restrict__ B)
+{
+    const i64* PI = acc;
+    const i64* AN = PI + 2 * N;
+    const i64* AD = AN + 2 * (i64)N * N;
+    const i64* BN = AD + 2 * N;
+    const i64* BD = BN + 2 * (i64)N * M;
+    const i64 used = BD[2 * N];
+    const i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < N) {
+        if (used > 0) pi[x] = e2vq::unfix(PI[2 * x], PI[2 * x + 1], ACC_SHIFT) / (double)used;
+    } else if (x < N + (i64)N * N) {
+        const i64 e = x - N;
+        const int i = (int)(e / N);
+        const double den = e2vq::unfix(AD[2 * i], AD[2 * i + 1], ACC_SHIFT);
+        if (den > 0.0) A[e] = e2vq::unfix(AN[2 * e], AN[2 * e + 1], ACC_SHIFT) / den;
+    } else if (x < N + (i64)N * N + (i64)N * M) {
+        const i64 e = x - N - (i64)N * N;
+        const int j = (int)(e / M);
+        const double den = e2vq::unfix(BD[2 * j], BD[2 * j + 1], ACC_SHIFT);
+        if (den > 0.0) B[e] = e2vq::unfix(BN[2 * e], BN[2 * e + 1], ACC_SHIFT) / den;
+    }
+}
+
+// hmm_adjustb: floor at epsilon, then divide the row by its sequential sum (one thread per state; M <= 65536)
+__global__ void k_hmm_adjustb(int N, int M, double epsilon, double* __restrict__ B)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    double* row = B + (size_t)j * M;
+    double s = 0.0;
+    for (int k = 0; k < M; ++k) {
+        double v = row[k];
+        if (v < epsilon) {
+            v = epsilon;
+            row[k] = v;
+        }
+        s = s + v;
+    }
+    for (int k = 0; k < M; ++k) row[k] = row[k] / s;
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------
+i64 acc_words(int N, int M) { return 2 * ((i64)N + (i64)N * N + N + (i64)N * M + N) + 2; }
+
+void launch_score(const ModelDev* models, int K, int maxN, const unsigned short* sym, const i64* offs, int S, double* mant,
+                  i64* exp2, int* status, hipStream_t st)
+{
+    if (S < 1 || K < 1) return;
+    const dim3 grid((unsigned)((S + SCORE_WAVES - 1) / SCORE_WAVES), (unsigned)K);
+    hipLaunchKernelGGL(k_hmm_score, grid, dim3(64 * SCORE_WAVES), (size_t)maxN * maxN * 8, st, models, K, sym, offs, S,
+                       mant, exp2, status);
+}
+
+void launch_fb(const ModelDev& md, const unsigned short* sym, const i64* offs, int S, double* alpha_buf, double* c_buf,
+               i64* acc, double* mant, i64* exp2, int* status, hipStream_t st)
+{
+    if (S < 1) return;
+    const size_t lds = (size_t)2 * md.N * md.N * 8;
+    (void)hipFuncSetAttribute((const void*)k_hmm_fb, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipLaunchKernelGGL(k_hmm_fb, dim3((unsigned)((S + FB_WAVES - 1) / FB_WAVES)), dim3(64 * FB_WAVES), lds, st, md, sym,
+                       offs, S, alpha_buf, c_buf, acc, mant, exp2, status);
+}
+
+void launch_reestimate(int N, int M, const i64* acc, double epsilon, double* pi, double* A, double* B, hipStream_t st)
+{
+    const i64 total = (i64)N + (i64)N * N + (i64)N * M;
+    hipLaunchKernelGGL(k_hmm_reestimate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, N, M, acc, pi, A, B);
+    if (epsilon > 0.0) hipLaunchKernelGGL(k_hmm_adjustb, dim3(1), dim3(64), 0, st, N, M, epsilon, B);
+}
+
+}  // namespace e2hmm

@@ -65,6 +65,74 @@ int e2vq_c12n_run(const char *const *model_class_names, int num_models, const in
                   const char *const *case_class_names, const char *const *case_titles, const double *probs,
                   int num_cases, int show_ranked, const char *out_base_name, int *result, int *confusion);
 
+/* =========================================================================================
+ * Part B -- hmm (the reference's FFI symbols; bodies in the absent C submodule -> definitions in DESIGN.md /
+ *           oracle/hmm_oracle.h; parity unpinned)
+ * ======================================================================================= */
+
+/* replaces `fn ecoz2_set_random_seed(seed: c_long) -> c_ulong`          src/ecoz2_lib/mod.rs:75
+ * seed < 0: time based (src/hmm/mod.rs:73-76).  Returns the seed in use.  Feeds the random model types of hmm learn. */
+unsigned long ecoz2_set_random_seed(long seed);
+
+/* `callback: extern "C" fn(*mut c_char, c_double)`                       src/ecoz2_lib/mod.rs:144
+ * called once per E-step with ("sum_log_prob", sum over the training sequences of ln P(O | model)) */
+typedef void (*ecoz2_hmm_learn_callback_t)(char *variable, double value);
+
+/* replaces `fn ecoz2_hmm_learn(N, model_type, sequence_filenames, num_sequences: c_uint, hmm_epsilon, val_auto,
+ *           max_iterations, use_par, callback)`                          src/ecoz2_lib/mod.rs:134-145
+ * Baum-Welch over all the given `.seq` files of ONE class (class name and M from the first sequence): E-step on the
+ * GPU (one wavefront per sequence, exact fixed-point expected counts), M-step on the GPU, until the increase of
+ * sum ln P drops to val_auto or max_iterations (>= 0) E+M steps ran.  hmm_epsilon > 0 floors B and renormalises.
+ * Writes data/hmms/N<N>__M<M>_t<type>__a<val_auto>[_I<max>]/<class>.hmm (+ .csv with the measure per iteration).
+ * use_par is accepted and ignored. */
+int ecoz2_hmm_learn(int N, int model_type, const char *const *sequence_filenames, unsigned num_sequences,
+                    double hmm_epsilon, double val_auto, int max_iterations, int use_par,
+                    ecoz2_hmm_learn_callback_t callback);
+
+/* replaces `fn ecoz2_hmm_classify(model_filenames, num_models: c_uint, sequence_filenames, num_sequences: c_uint,
+ *           show_ranked, classification_filename)`                       src/ecoz2_lib/mod.rs:147-154
+ * ln P(O | model) of every sequence under every model (GPU, one wavefront per pair); report in the layout of
+ * src/c12n/mod.rs; classification_filename (may be NULL): the CSV of CHANGELOG.md:273-284. */
+int ecoz2_hmm_classify(const char *const *model_filenames, unsigned num_models,
+                       const char *const *sequence_filenames, unsigned num_sequences, int show_ranked,
+                       const char *classification_filename);
+
+/* replaces `fn ecoz2_hmm_classify_predictors(model_filenames, num_models: c_uint, cb_filenames, num_codebooks: c_int,
+ *           prd_filenames, num_predictors: c_int, show_ranked, classification_filename)`   src/ecoz2_lib/mod.rs:156-165
+ * The on-the-fly consumer of the nearest-codeword kernel: every `.prd` is uploaded once, quantised on the GPU against
+ * the codebook of each model (a single codebook serves all models; several are matched to the models by class name)
+ * and scored where the symbols are. */
+int ecoz2_hmm_classify_predictors(const char *const *model_filenames, unsigned num_models,
+                                  const char *const *cb_filenames, int num_codebooks,
+                                  const char *const *prd_filenames, int num_predictors, int show_ranked,
+                                  const char *classification_filename);
+
+/* replaces `fn ecoz2_hmm_show(hmm_filename, format)`                      src/ecoz2_lib/mod.rs:167
+ * format: one printf floating-point conversion per value, default "%Lg " (src/hmm/mod.rs:153-154) */
+int ecoz2_hmm_show(const char *hmm_filename, const char *format);
+
+/* ---- array-level entry points over the same kernels (tests, Python mirror) ---------------------------------- */
+/* initial model of `hmm learn -t`: 0 random, 1 uniform, 2 cascade-2, 3 cascade-3 (random B); uses the generator
+ * seeded by ecoz2_set_random_seed.  pi[N], A[N*N], B[N*M]; N <= 64. */
+int e2vq_hmm_init(int N, int M, int model_type, double *pi, double *A, double *B);
+int e2vq_hmm_save(const char *path, const char *class_name, int N, int M, const double *pi, const double *A,
+                  const double *B);
+int e2vq_hmm_info(const char *path, char class_name[96], int *N, int *M);
+int e2vq_hmm_load(const char *path, double *pi, double *A, double *B);
+/* scaled forward pass of S sequences (concatenated u16 symbols + S+1 offsets) under K models sharing M; outputs at
+ * [s*K + k]: P(O) = mant * 2^exp2 (mant in [0.5,1)), status (0 ok, 1 cannot emit, 2 symbol >= M), ln P */
+int e2vq_hmm_score(int device, int K, const int *Ns, int M, const double *const *pis, const double *const *As,
+                   const double *const *Bs, const uint16_t *sym, const int64_t *offs, int S, double *mant,
+                   int64_t *exp2, int *status, double *log_probs);
+/* int64 words of the E-step accumulators: [hi, lo] limb pairs  PI[N] | AN[N][N] | AD[N] | BN[N][M] | BD[N] | used, skipped */
+int64_t e2vq_hmm_acc_words(int N, int M);
+int e2vq_hmm_estep(int device, int N, int M, const double *pi, const double *A, const double *B, const uint16_t *sym,
+                   const int64_t *offs, int S, int64_t *acc, double *mant, int64_t *exp2, int *status);
+/* the loop of ecoz2_hmm_learn on arrays, in place; sum_log_prob[0..*num_esteps) = the measure per E-step */
+int e2vq_hmm_train(int device, int N, int M, double *pi, double *A, double *B, const uint16_t *sym,
+                   const int64_t *offs, int S, double epsilon, double val_auto, int max_iterations,
+                   double *sum_log_prob, int cap, int *num_esteps);
+
 #ifdef __cplusplus
 }
 #endif

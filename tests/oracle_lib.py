@@ -194,3 +194,106 @@ def load(variant="libvqoracle.so"):
     if not os.path.exists(path):
         build()
     return Oracle(path)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# HMM oracle (oracle/hmm_oracle.c, in the same shared object).  TESTS ONLY.
+# ---------------------------------------------------------------------------------------------------------------
+HMM_CB = C.CFUNCTYPE(None, C.c_char_p, C.c_double)
+
+
+class HmmOracle:
+    ACC_SHIFT = 29
+
+    def __init__(self, path=None):
+        path = path or os.path.join(ORACLE_DIR, "_build", "libvqoracle.so")
+        if not os.path.exists(path):
+            build()
+        L = self.L = C.CDLL(path)
+        L.e2h_set_random_seed.restype = C.c_uint64
+        L.e2h_set_random_seed.argtypes = [C.c_int64]
+        L.e2h_uniform.restype = C.c_double
+        L.e2h_init.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.e2h_forward.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                  C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]
+        L.e2h_log_prob.restype = C.c_double
+        L.e2h_log_prob.argtypes = [C.c_double, C.c_int64]
+        L.e2h_acc_words.restype = C.c_int64
+        L.e2h_acc_words.argtypes = [C.c_int, C.c_int]
+        L.e2h_accumulate.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.e2h_reestimate.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.e2h_learn.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, HMM_CB]
+        L.e2h_save.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.e2h_load_info.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.e2h_load.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def seed(self, s):
+        return self.L.e2h_set_random_seed(int(s))
+
+    def init(self, N, M, type_):
+        pi, A, B = np.zeros(N), np.zeros((N, N)), np.zeros((N, M))
+        assert self.L.e2h_init(N, M, type_, _dp(pi), _dp(A), _dp(B)) == 0
+        return pi, A, B
+
+    def forward(self, pi, A, B, sym, want_alpha=False):
+        """-> (status, mant, exp2[, alpha_hat, c])"""
+        sym = np.ascontiguousarray(sym, dtype=np.uint16)
+        N, M, T = len(pi), B.shape[1], len(sym)
+        mant, e2 = C.c_double(), C.c_int64()
+        al = np.zeros((T, N)) if want_alpha else None
+        c = np.zeros(T) if want_alpha else None
+        st = self.L.e2h_forward(N, M, _dp(pi), _dp(A), _dp(B), _dp(sym), T, C.byref(mant), C.byref(e2),
+                                _dp(al) if want_alpha else None, _dp(c) if want_alpha else None)
+        return (st, mant.value, e2.value, al, c) if want_alpha else (st, mant.value, e2.value)
+
+    def log_prob(self, mant, e2):
+        return self.L.e2h_log_prob(mant, e2)
+
+    def acc_words(self, N, M):
+        return self.L.e2h_acc_words(N, M)
+
+    def accumulate(self, pi, A, B, seqs):
+        """E-step over the sequences: -> (acc int64 words, [(status, mant, exp2)...])"""
+        N, M = len(pi), B.shape[1]
+        acc = np.zeros(self.acc_words(N, M), dtype=np.int64)
+        res = []
+        for s in seqs:
+            s = np.ascontiguousarray(s, dtype=np.uint16)
+            mant, e2 = C.c_double(), C.c_int64()
+            st = self.L.e2h_accumulate(N, M, _dp(pi), _dp(A), _dp(B), _dp(s), len(s), _dp(acc), C.byref(mant), C.byref(e2))
+            res.append((st, mant.value, e2.value))
+        return acc, res
+
+    def reestimate(self, acc, eps, pi, A, B):
+        pi, A, B = pi.copy(), A.copy(), B.copy()
+        self.L.e2h_reestimate(len(pi), B.shape[1], _dp(acc), eps, _dp(pi), _dp(A), _dp(B))
+        return pi, A, B
+
+    def learn(self, pi, A, B, seqs, eps=1e-5, val_auto=0.3, max_iterations=-1):
+        """-> (pi, A, B, [sum_log_prob per E-step])"""
+        pi, A, B = pi.copy(), A.copy(), B.copy()
+        N, M, R = len(pi), B.shape[1], len(seqs)
+        arrs = [np.ascontiguousarray(s, dtype=np.uint16) for s in seqs]
+        ptrs = (C.c_void_p * R)(*[a.ctypes.data for a in arrs])
+        lens = np.array([len(a) for a in arrs], dtype=np.int64)
+        hist = np.zeros(4096)
+        n = self.L.e2h_learn(N, M, ptrs, _dp(lens), R, eps, val_auto, max_iterations, _dp(pi), _dp(A), _dp(B),
+                             _dp(hist), len(hist), HMM_CB(lambda _v, _x: None))
+        assert n >= 0
+        return pi, A, B, list(hist[:n])
+
+    def save(self, path, class_name, pi, A, B):
+        assert self.L.e2h_save(str(path).encode(), class_name.encode(), len(pi), B.shape[1], _dp(pi), _dp(A), _dp(B)) == 0
+
+    def load(self, path):
+        cls, N, M = C.create_string_buffer(96), C.c_int(), C.c_int()
+        assert self.L.e2h_load_info(str(path).encode(), cls, C.byref(N), C.byref(M)) == 0
+        pi, A, B = np.zeros(N.value), np.zeros((N.value, N.value)), np.zeros((N.value, M.value))
+        assert self.L.e2h_load(str(path).encode(), _dp(pi), _dp(A), _dp(B)) == 0
+        return cls.value.decode(), pi, A, B
+
+
+def load_hmm():
+    return HmmOracle()
