@@ -34,10 +34,14 @@ void launch_global_sums(const double* blk, long nblocks, int NC, int FB, const D
 int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const double* cbq, const double* cbm,
                 int M, const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                 long long* rows, hipStream_t s);
-// prefiltered pass (vq_prefilter.hip; P = 36): f16 limb images + exact candidate evaluation + fallback list
+// prediction orders with a prefiltered sweep (NC = P + 1): the usual LPC orders 12, 16, ..., 40
+#ifndef E2VQ_PRE_NC_LIST
+#define E2VQ_PRE_NC_LIST(X) X(13) X(17) X(21) X(25) X(29) X(33) X(37) X(41)
+#endif
+// prefiltered pass (vq_prefilter.hip): f16 limb images + exact candidate evaluation + fallback list
 bool prefilter_supports(int NC, int M);
-size_t prefilter_frame_image_bytes(long nblocks64);
-size_t prefilter_codebook_image_bytes(int M);
+size_t prefilter_frame_image_bytes(int NC, long nblocks64);
+size_t prefilter_codebook_image_bytes(int NC, int M);
 size_t prefilter_scalars_bytes();
 void launch_prefilter_frames(const double* blk, long T, long nblocks64, int NC, unsigned long long* colmax_bits, int* ea,
                              void* fimg, float* fg, hipStream_t s);

@@ -1112,18 +1112,24 @@ int launch_pass_fallback(int NC, bool accumulate, const double* blk, const doubl
                          const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows, const int* fb_list,
                          const int* fb_count, unsigned short* prev_sym, bool incremental, hipStream_t s)
 {
-    if (NC != 37) return 1;
-    constexpr int IMG = 2 * 37 + 5 + IMG_STRIDE_PAD;
     const int MT = (M + 15) / 16;
-    // one 4-wave workgroup per 16 listed frames at a time; LDS: the waves' row images + the (min, index) exchange
-    const size_t lds = (size_t)4 * 16 * IMG * 4 + (size_t)2 * 4 * 64 * (8 + 4);
-    if (accumulate)
-        hipLaunchKernelGGL((k_pass_mfma<37, 2, 256, 2>), dim3(1024), dim3(256), lds, s, blk, 0L, 0L, cbm, MT, M, sc,
-                           l1max_bits, sym, dmin, rows, 0, fb_list, fb_count, prev_sym, incremental ? 1 : 0);
-    else
-        hipLaunchKernelGGL((k_pass_mfma<37, 0, 256, 2>), dim3(1024), dim3(256), lds, s, blk, 0L, 0L, cbm, MT, M, sc,
-                           l1max_bits, sym, dmin, rows, 0, fb_list, fb_count);
-    return 0;
+    switch (NC) {
+#define X(N)                                                                                                           \
+    case N: {                                                                                                          \
+        /* one 4-wave workgroup per 16 listed frames at a time; LDS: the waves' row images + the (min, index) exchange */ \
+        const size_t lds = (size_t)4 * 16 * (2 * N + 5 + IMG_STRIDE_PAD) * 4 + (size_t)2 * 4 * 64 * (8 + 4);          \
+        if (accumulate)                                                                                                \
+            hipLaunchKernelGGL((k_pass_mfma<N, 2, 256, 2>), dim3(1024), dim3(256), lds, s, blk, 0L, 0L, cbm, MT, M, sc, \
+                               l1max_bits, sym, dmin, rows, 0, fb_list, fb_count, prev_sym, incremental ? 1 : 0);     \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_pass_mfma<N, 0, 256, 2>), dim3(1024), dim3(256), lds, s, blk, 0L, 0L, cbm, MT, M, sc, \
+                               l1max_bits, sym, dmin, rows, 0, fb_list, fb_count);                                     \
+        return 0;                                                                                                      \
+    }
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        default: return 1;
+    }
 }
 
 // incremental accumulation: the distortion elements of every row are rebuilt each pass, the cell sums persist

@@ -370,7 +370,7 @@ extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames
         s->d_fblist = nullptr;
         // 234 B per frame beside the 296 B of the blocked frames.  If the device cannot hold them, the session
         // simply keeps to the plain FP64 sweep (same results): use_prefilter() looks at d_fimg.
-        const bool fits = hipMalloc(&s->d_fimg, e2vq::prefilter_frame_image_bytes(s->nblocks)) == hipSuccess &&
+        const bool fits = hipMalloc(&s->d_fimg, e2vq::prefilter_frame_image_bytes(s->NC, s->nblocks)) == hipSuccess &&
                           hipMalloc(&s->d_fg, (size_t)s->nblocks * 64 * sizeof(float)) == hipSuccess &&
                           hipMalloc(&s->d_fblist, (size_t)s->nblocks * 64 * sizeof(int)) == hipSuccess &&
                           hipMalloc(&s->d_prev_sym, (size_t)s->nblocks * 64 * sizeof(unsigned short)) == hipSuccess;
@@ -556,7 +556,7 @@ static int ensure_codebook_image(e2vq_session* s)
     }
     s->cimg_cap = std::max(s->M, 2048);
     for (int k = 0; k < 2; ++k)
-        HIPCHK(hipMalloc(&s->d_cimg2[k], e2vq::prefilter_codebook_image_bytes(s->cimg_cap)));
+        HIPCHK(hipMalloc(&s->d_cimg2[k], e2vq::prefilter_codebook_image_bytes(s->NC, s->cimg_cap)));
     return 0;
 }
 
@@ -986,7 +986,7 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
             s->d_qfimg = nullptr;
             s->d_qfg = nullptr;
             s->d_qfblist = nullptr;
-            HIPCHK(hipMalloc(&s->d_qfimg, e2vq::prefilter_frame_image_bytes(nb)));
+            HIPCHK(hipMalloc(&s->d_qfimg, e2vq::prefilter_frame_image_bytes(s->NC, nb)));
             HIPCHK(hipMalloc(&s->d_qfg, (size_t)nb * 64 * sizeof(float)));
             HIPCHK(hipMalloc(&s->d_qfblist, (size_t)nb * 64 * sizeof(int)));
             s->qpre_cap = nb;
@@ -996,7 +996,7 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
             if (s->d_qcimg) HIPCHK(hipFree(s->d_qcimg));
             s->d_qcimg = nullptr;
             s->qcimg_cap = std::max(s->M, 2048);
-            HIPCHK(hipMalloc(&s->d_qcimg, e2vq::prefilter_codebook_image_bytes(s->qcimg_cap)));
+            HIPCHK(hipMalloc(&s->d_qcimg, e2vq::prefilter_codebook_image_bytes(s->NC, s->qcimg_cap)));
         }
         e2vq::launch_prefilter_quantize_prep((const double*)device_frames, T, nb, s->NC, s->d_cbq, s->M, s->d_ea_q,
                                              s->d_qblk, s->d_qfimg, s->d_qfg, s->stream);

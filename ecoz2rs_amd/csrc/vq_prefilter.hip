@@ -1,4 +1,4 @@
-// vq_prefilter.hip -- the prefiltered sweep: same results as the FP64 sweep (bit for bit), about half its time.
+// vq_prefilter.hip -- the prefiltered sweep: same results as the FP64 sweep (bit for bit), a fraction of its time.
 //
 // Idea.  argmin_m d(r, c_m) needs the FP64 chain only for the codewords that can win.  A cheap approximation
 // d~ with a PROVEN error bound eps finds them: every codeword whose d~ exceeds the smallest d~ by more than
@@ -8,22 +8,31 @@
 //   * per coefficient n a power of two a_n (vq learn: > max_t |r_t[n]|, one scan per upload; vq quantize: from the
 //     codebook, so that no pass over the data is needed), per frame a power of two A_t,
 //     per codebook a power of two C:   xi = r / (a A_t),  eta = c a / C,  both in (-1, 1),  d = A_t C sum xi eta
-//   * xi -> three integer limbs  X1 = rint(xi 2^9) (|X1| <= 512), X2, X3 (|.| <= 256):
-//         xi = X1 2^-9 + X2 2^-18 + X3 2^-27 + rho,  |rho| <= 2^-28;   eta likewise (Y1, Y2, Y3, sigma)
+//   * xi -> two integer limbs  X1 = rint(xi 2^9) (|X1| <= 512), X2 (|X2| <= 256):
+//         xi = X1 2^-9 + X2 2^-18 + rho,  |rho| <= 2^-19;   eta likewise (Y1, Y2, sigma)
 //   * the limb products of equal weight are summed by v_mfma_f32_32x32x16_f16 into separate f32 accumulators
-//         W0 = sum X1 Y1,   W1 = sum X1 Y2 + X2 Y1,   W2 = sum X1 Y3 + X2 Y2 + X3 Y1
-//     every partial sum is an integer below 2^24 (37 * 2^18, 74 * 2^17, 37 * 5 * 2^16), i.e. exactly representable:
+//         W0 = sum X1 Y1,   W1 = sum X1 Y2 + X2 Y1
+//     every partial sum is an integer below 2^24 (NC 2^18 each, NC <= 41), i.e. exactly representable:
 //     the MFMA results are exact in any summation order (checked on hardware: tools/probe/pre_sweep.hip)
-//   * v = W0 2^18 + W1 2^9 + W2 (two f32 fmas), key = v with its low mantissa bits replaced by the codeword index;
+//   * v = W0 2^9 + W1 (one f32 fma), key = v with its low mantissa bits replaced by the codeword index;
 //     a running (min, 2nd, 3rd) of the keys per frame costs three VALU ops per value
-//   * |2^36 sum xi eta - key| <= 2^8 (sum|xi| + max_m sum|eta_m| + 41) + |key| 2^-(22 - idxbits)     
+//   * |2^27 sum xi eta - key| <= 2^8 (sum|xi| + max_m sum|eta_m| + NC/2 + 1) + |key| 2^-(22 - idxbits)   
 //     If the third key is farther from the first than twice that (x1.27), the true argmin is one of the first two:
 //     both are evaluated with the canonical FP64 chain (on the FP64 matrix pipe, as the diagonal of a 16x16 tile of
 //     gathered codewords -- the same instruction sequence as the full sweep, so bit-identical values) and compared
 //     exactly (ties: lower index).  Otherwise -- or if the smallest key is not a positive normal number -- the frame
 //     goes to a list that k_pass_mfma<SRC = 2> sweeps in full FP64 right after.  Nothing is ever decided by d~.
 //
-// NC = 37 (P = 36, the reference's default) only: the K-slot packing below is specific to 37 = 32 + 5.
+// Two limbs, not three (round 1 carried a third, W2 = sum X1 Y3 + X2 Y2 + X3 Y1, 15 MFMAs per tile instead of 8):
+// the codeword index takes log2 M low mantissa bits of the key, so at M >= 256 the key keeps 15 significant bits or
+// fewer -- |key| 2^-(22 - idxbits) dominates the bound, the 2^-19-relative limb remainder is already below it, and
+// a third limb bought matrix work without certifying a single extra frame.
+//
+// K-slot packing for any NC = P + 1 <= 41 (PrePack): with G = NC / 16 and R = NC % 16, each limb fills G "pairs" of 16
+// coefficients (two 8-half granules, lane halves h = 0, 1 of the 32x32x16 operand); a tail of 1 <= R <= 8
+// coefficients shares ONE pair between the limbs (h = 0: X1 tail, h = 1: X2 tail), a longer tail gets a zero-padded
+// pair per limb.  W0 takes the X1 pairs (+ the shared one, whose X2 half meets zeros), W1 every pair.
+// NC = 37: 5 pairs = 160 B per frame, 3 + 5 = 8 MFMAs per 32x32 tile (74 of 80 + 48 slots carry a product).
 #include "vq_accum.h"
 #include "vq_device.h"
 #include "vq_fixed.h"
@@ -37,42 +46,47 @@ namespace e2vq {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-constexpr int PRE_NSTEP = 15;     // MFMA k-steps of 16: 3 (W0) + 5 (W1) + 7 (W2)
-constexpr int PRE_TILE_E = 1024;  // h8 granules per 32-codeword tile image (15 KB used, padded to 16 KB)
-constexpr int PRE_PAIRS = 7;      // frame granule pairs per 32-frame block: 14 granules of 8 halves = 224 B/frame
-
-__host__ __device__ constexpr int pre_step_level(int s) { return s < 3 ? 0 : (s < 8 ? 1 : 2); }
-// frame granule pair used by k-step s:  W0: p0 p1 p6 | W1: p0 p1 p2 p3 p6 | W2: p0 .. p6
-__host__ __device__ constexpr int pre_step_pair(int s)
-{
-    return s < 3 ? (s == 2 ? 6 : s) : (s < 8 ? (s == 7 ? 6 : s - 3) : (s - 8));
-}
-// element e of the granule (pair p, lane half h) of a frame: limb index fl (0..2) and coefficient n, or n = -1 (zero)
-//   p < 6 : limb p/2, coefficients 16 (p&1) + 8 h + e              (n < 32)
-//   p = 6 : h = 0: [X1[32..36], X2[32..34]]   h = 1: [X2[35..36], X3[32..36], 0]
-__host__ __device__ __forceinline__ void pre_slot(int p, int h, int e, int& fl, int& n)
-{
-    if (p < 6) {
-        fl = p >> 1;
-        n = 16 * (p & 1) + 8 * h + e;
-    } else if (h == 0) {
-        fl = e < 5 ? 0 : 1;
-        n = e < 5 ? 32 + e : 27 + e;
-    } else {
-        fl = e < 2 ? 1 : 2;
-        n = e < 2 ? 35 + e : (e < 7 ? 30 + e : -1);
+template <int NC>
+struct PrePack {
+    static constexpr int G = NC / 16, R = NC % 16;
+    static constexpr int FULL = R > 8 ? G + 1 : G;                // 16-coefficient pairs per limb
+    static constexpr int SHARED = (R >= 1 && R <= 8) ? 1 : 0;     // one pair holding both limbs' tails
+    static constexpr int PAIRS = 2 * FULL + SHARED;               // frame granule pairs (32 B each per frame)
+    static constexpr int NSTEP = 3 * FULL + 2 * SHARED;           // MFMA k-steps of 16: W0, then W1
+    static constexpr int W0_STEPS = FULL + SHARED;
+    static constexpr int TILE_E = NSTEP * 64;                     // h8 granules per 32-codeword tile image
+    static constexpr int NCX = (NC + 1) & ~1;
+    static_assert(NC >= 2 && NC <= 63, "partial sums must stay below 2^24: NC 2^18");
+    __host__ __device__ static constexpr int step_level(int s) { return s < W0_STEPS ? 0 : 1; }
+    // frame granule pair used by k-step s
+    __host__ __device__ static constexpr int step_pair(int s)
+    {
+        return s < FULL ? s : (s < W0_STEPS ? 2 * FULL : s - W0_STEPS);
     }
-}
+    // element e of the granule (pair p, lane half h) of a frame: limb index fl (0, 1) and coefficient n, or n = -1 (zero)
+    __host__ __device__ static __forceinline__ void slot(int p, int h, int e, int& fl, int& n)
+    {
+        if (p < FULL) {
+            fl = 0;
+            n = 16 * p + 8 * h + e;
+        } else if (p < 2 * FULL) {
+            fl = 1;
+            n = 16 * (p - FULL) + 8 * h + e;
+        } else {
+            fl = h;
+            n = e < R ? 16 * G + e : -1;
+        }
+        if (n >= NC) n = -1;
+    }
+};
 
-// x in [-1, 1] -> limbs; returns the three integers
-__device__ __forceinline__ void pre_split(double x, int& L1, int& L2, int& L3)
+// x in [-1, 1] -> the two integer limbs
+__device__ __forceinline__ void pre_split(double x, int& L1, int& L2)
 {
     const double s1 = x * 512.0, l1 = __builtin_rint(s1);
     const double s2 = (s1 - l1) * 512.0, l2 = __builtin_rint(s2);
-    const double s3 = (s2 - l2) * 512.0, l3 = __builtin_rint(s3);
     L1 = (int)l1;
     L2 = (int)l2;
-    L3 = (int)l3;
 }
 
 // ---- data statistic: per-coefficient max |r[n]| over the blocked training set -----------------------------
@@ -106,11 +120,13 @@ __global__ void k_pre_exponents(const u64* __restrict__ colmax_bits, int NC, int
 }
 
 // ---- frame image: [blk32][pair][h*32 + col][8 halves], fg[t] = sum_n |xi_n| (rounded up) -----------------
-__global__ __launch_bounds__(64) void k_pre_frames(const double* __restrict__ blk, long T, long nblk32, int NC,
+template <int NC>
+__global__ __launch_bounds__(64) void k_pre_frames(const double* __restrict__ blk, long T, long nblk32,
                                                    const int* __restrict__ ea, h8* __restrict__ fimg,
                                                    float* __restrict__ fg)
 {
-    __shared__ short X[3][32][40];
+    typedef PrePack<NC> PK;
+    __shared__ short X[2][32][PK::NCX];
     const int col = threadIdx.x & 31, hh = threadIdx.x >> 5;
     for (long b = blockIdx.x; b < nblk32; b += gridDim.x) {
         const long t = b * 32 + col;
@@ -126,29 +142,28 @@ __global__ __launch_bounds__(64) void k_pre_frames(const double* __restrict__ bl
             }
         if (eA == -100000) eA = 0;
         double g = 0.0;
-        for (int n = hh; n < 40; n += 2) {
-            int l1 = 0, l2 = 0, l3 = 0;
+        for (int n = hh; n < PK::NCX; n += 2) {
+            int l1 = 0, l2 = 0;
             if (n < NC && t < T) {
                 const double xi = ldexp(blk[mfma_blk_offset(NC, t, n)], -ea[n] - eA);
                 g += fabs(xi);
-                pre_split(xi, l1, l2, l3);
+                pre_split(xi, l1, l2);
             }
             X[0][col][n] = (short)l1;
             X[1][col][n] = (short)l2;
-            X[2][col][n] = (short)l3;
         }
         g += __shfl_xor(g, 32, 64);
         if (hh == 0 && t < T) fg[t] = (float)g * 1.000001f;
         __syncthreads();
-        for (int p = 0; p < PRE_PAIRS; ++p) {
+        for (int p = 0; p < PK::PAIRS; ++p) {
             h8 out;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 int fl, n;
-                pre_slot(p, hh, e, fl, n);
+                PK::slot(p, hh, e, fl, n);
                 out[e] = n >= 0 ? (_Float16)(int)X[fl][col][n] : (_Float16)0;
             }
-            fimg[(b * PRE_PAIRS + p) * 64 + threadIdx.x] = out;
+            fimg[(b * PK::PAIRS + p) * 64 + threadIdx.x] = out;
         }
         __syncthreads();
     }
@@ -183,8 +198,9 @@ __global__ __launch_bounds__(256) void k_pre_quant_prep(const double* __restrict
                                                         h8* __restrict__ fimg, float* __restrict__ fg)
 {
     constexpr int NS = (NC + 3) / 4;
+    typedef PrePack<NC> PK;
     __shared__ double stage[64 * NC];
-    __shared__ short X[3][64][40];
+    __shared__ short X[2][64][PK::NCX];
     __shared__ int eAs[64];
     __shared__ int eas[NC];
     for (int n = threadIdx.x; n < NC; n += 256) eas[n] = ea[n];
@@ -227,26 +243,25 @@ __global__ __launch_bounds__(256) void k_pre_quant_prep(const double* __restrict
             if (t < T) fg[t] = (float)g * 1.000001f;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < 64 * 40; i += 256) {
-            const int f = i / 40, n = i - f * 40;
-            int l1 = 0, l2 = 0, l3 = 0;
-            if (n < NC) pre_split(ldexp(stage[f * NC + n], -eas[n] - eAs[f]), l1, l2, l3);
+        for (int i = threadIdx.x; i < 64 * PK::NCX; i += 256) {
+            const int f = i / PK::NCX, n = i - f * PK::NCX;
+            int l1 = 0, l2 = 0;
+            if (n < NC) pre_split(ldexp(stage[f * NC + n], -eas[n] - eAs[f]), l1, l2);
             X[0][f][n] = (short)l1;
             X[1][f][n] = (short)l2;
-            X[2][f][n] = (short)l3;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < 2 * PRE_PAIRS * 64; i += 256) {
-            const int cb = i / (PRE_PAIRS * 64), r = i - cb * (PRE_PAIRS * 64), p = r >> 6, l = r & 63;
+        for (int i = threadIdx.x; i < 2 * PK::PAIRS * 64; i += 256) {
+            const int cb = i / (PK::PAIRS * 64), r = i - cb * (PK::PAIRS * 64), p = r >> 6, l = r & 63;
             const int hh = l >> 5, f = 32 * cb + (l & 31);
             h8 out;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 int fl, n;
-                pre_slot(p, hh, e, fl, n);
+                PK::slot(p, hh, e, fl, n);
                 out[e] = n >= 0 ? (_Float16)(int)X[fl][f][n] : (_Float16)0;
             }
-            fimg[((b * 2 + cb) * PRE_PAIRS + p) * 64 + l] = out;
+            fimg[((b * 2 + cb) * PK::PAIRS + p) * 64 + l] = out;
         }
     }
 }
@@ -280,22 +295,23 @@ __global__ void k_pre_cmax(const double* __restrict__ cbq, int M, int NC, int NP
     if (threadIdx.x == 0 && smax) atomicMax(&ps->eC_biased, smax);
 }
 
-// ---- codebook image: [tile][step][h*32 + row][8 halves] (+ 64 zero granules of padding per tile) ---------
-__global__ __launch_bounds__(256) void k_pre_codebook(const double* __restrict__ cbq, int M, int NC, int NPAD,
+// ---- codebook image: [tile][step][h*32 + row][8 halves] ------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void k_pre_codebook(const double* __restrict__ cbq, int M, int NPAD,
                                                       const int* __restrict__ ea, PreScalars* __restrict__ ps,
                                                       h8* __restrict__ cimg)
 {
-    __shared__ short Y[3][32][40];
+    typedef PrePack<NC> PK;
+    __shared__ short Y[2][32][PK::NCX];
     const int tile = blockIdx.x;
     const int eC = ps->eC_biased ? ps->eC_biased - PRE_EBIAS : 0;
-    for (int i = threadIdx.x; i < 32 * 40; i += 256) {
-        const int row = i / 40, n = i - row * 40;
+    for (int i = threadIdx.x; i < 32 * PK::NCX; i += 256) {
+        const int row = i / PK::NCX, n = i - row * PK::NCX;
         const int m = tile * 32 + row;
-        int l1 = 0, l2 = 0, l3 = 0;
-        if (n < NC && m < M) pre_split(ldexp(cbq[(long)m * NPAD + n], ea[n] - eC), l1, l2, l3);
+        int l1 = 0, l2 = 0;
+        if (n < NC && m < M) pre_split(ldexp(cbq[(long)m * NPAD + n], ea[n] - eC), l1, l2);
         Y[0][row][n] = (short)l1;
         Y[1][row][n] = (short)l2;
-        Y[2][row][n] = (short)l3;
     }
     if (threadIdx.x < 32) {  // sum_n |eta| of this tile's codewords -> global max (float bits, rounded up)
         const int m = tile * 32 + threadIdx.x;
@@ -305,20 +321,18 @@ __global__ __launch_bounds__(256) void k_pre_codebook(const double* __restrict__
         atomicMax(&ps->ymax_bits, __float_as_int((float)g * 1.000001f));
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < PRE_TILE_E; i += 256) {
+    for (int i = threadIdx.x; i < PK::TILE_E; i += 256) {
         h8 out = {0, 0, 0, 0, 0, 0, 0, 0};
         const int s = i >> 6, l = i & 63, hh = l >> 5, row = l & 31;
-        if (s < PRE_NSTEP) {
-            const int lv = pre_step_level(s), pr = pre_step_pair(s);
+        const int lv = PK::step_level(s), pr = PK::step_pair(s);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                int fl, n;
-                pre_slot(pr, hh, e, fl, n);
-                const int cl = lv - fl;  // codeword limb that meets frame limb fl at this weight
-                if (n >= 0 && cl >= 0 && cl <= 2) out[e] = (_Float16)(int)Y[cl][row][n];
-            }
+        for (int e = 0; e < 8; ++e) {
+            int fl, n;
+            PK::slot(pr, hh, e, fl, n);
+            const int cl = lv - fl;  // codeword limb that meets frame limb fl at this weight
+            if (n >= 0 && cl >= 0 && cl <= 1) out[e] = (_Float16)(int)Y[cl][row][n];
         }
-        cimg[(long)tile * PRE_TILE_E + i] = out;
+        cimg[(long)tile * PK::TILE_E + i] = out;
     }
 }
 
@@ -375,7 +389,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
                                                   i64* __restrict__ rows, int* __restrict__ fb_list, int stagger,
                                                   unsigned short* __restrict__ prev_sym, int incr)
 {
-    static_assert(NC == 37, "the K-slot packing of the prefilter is laid out for P = 36");
+    typedef PrePack<NC> PK;
     constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2;
     constexpr int NE = 2 * NC + 5, IMG = NE + IMG_STRIDE_PAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -416,28 +430,30 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 
     for (long b = wave; b < nblocks; b += nwaves) {
         // ---- f16 limb images of the wave's 64 frames: B operands, resident for the sweep ----------
-        h8 B[2][PRE_PAIRS];
+        h8 B[2][PK::PAIRS];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int p = 0; p < PRE_PAIRS; ++p) B[cb][p] = fimg[((b * 2 + cb) * PRE_PAIRS + p) * 64 + lane];
+            for (int p = 0; p < PK::PAIRS; ++p) B[cb][p] = fimg[((b * 2 + cb) * PK::PAIRS + p) * 64 + lane];
         float k1[2], k2[2], k3[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) k1[cb] = k2[cb] = k3[cb] = __int_as_float(0x7f7fffff);
 
-        f16v acc0[3], acc1[3];
+        f16v acc0[2], acc1[2];
 #pragma unroll
-        for (int l = 0; l < 3; ++l)
+        for (int l = 0; l < 2; ++l)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[l][r] = l == 2 ? 3.0e38f : 0.f;
+            for (int r = 0; r < 16; ++r) acc1[l][r] = l == 1 ? 3.0e38f : 0.f;
 
-        // one job = the 15 MFMAs of (tile, column block) interleaved with the key epilogue of the previous job:
-        // 1 MFMA (32 cycles, 8 of them blocking issue) : 6 VALU ops, pinned by sched_group_barrier
+        // one job = the NSTEP MFMAs of (tile, column block) interleaved with the key epilogue of the previous job
+        // (80 VALU ops: fma, and_or, three med3 per value), pinned by sched_group_barrier: with 8 MFMAs (NC = 37) the
+        // stream is VALU-issue bound at 10 ops per 32-cycle MFMA
+        constexpr int VALU_PER_MFMA = (80 + PK::NSTEP - 1) / PK::NSTEP;
 #define E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
     {                                                                                                             \
         const int sidx = __builtin_amdgcn_readfirstlane((PTILE) * 32 + 8 * (r >> 2) + (r & 3));                   \
-        const float v = __builtin_fmaf(PREV[0][r], 262144.f, __builtin_fmaf(PREV[1][r], 512.f, PREV[2][r]));     \
+        const float v = __builtin_fmaf(PREV[0][r], 512.f, PREV[1][r]);                                            \
         const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);                                     \
         k3[PCB] = med3f(k2[PCB], k3[PCB], key);                                                                   \
         k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                                   \
@@ -446,23 +462,23 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 #define E2VQ_PRE_JOB(ACC, BC, PREV, PTILE, PCB)                                                                   \
     {                                                                                                             \
         const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
-        _Pragma("unroll") for (int s = 0; s < PRE_NSTEP; ++s)                                                     \
+        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
         {                                                                                                         \
-            const int lv = pre_step_level(s), pr = pre_step_pair(s);                                              \
-            const bool first = s == 0 || s == 3 || s == 8;                                                        \
+            const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \
+            const bool first = s == 0 || s == PK::W0_STEPS;                                                       \
             ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
         }                                                                                                         \
         E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
-        _Pragma("unroll") for (int s = 0; s < PRE_NSTEP; ++s)                                                     \
+        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
         {                                                                                                         \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                    \
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                                    \
+            __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);                                        \
         }                                                                                                         \
     }
         for (int t = 0; t < MT; ++t) {
-            h8 A[PRE_NSTEP];
+            h8 A[PK::NSTEP];
 #pragma unroll
-            for (int s = 0; s < PRE_NSTEP; ++s) A[s] = cimg[(long)t * PRE_TILE_E + s * 64 + lane];
+            for (int s = 0; s < PK::NSTEP; ++s) A[s] = cimg[(long)t * PK::TILE_E + s * 64 + lane];
             E2VQ_PRE_JOB(acc0, B[0], acc1, (t - 1) & 0xffff, 1)  // (t = 0: the "previous" accumulators hold 3e38)
             E2VQ_PRE_JOB(acc1, B[1], acc0, t, 0)
         }
@@ -485,7 +501,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             // t1 <= u2 <= w3: the three smallest keys of frame 32 cb + (lane & 31)
             const long t = b * 64 + 32 * cb + (lane & 31);
             const float g = t < T ? fg[t] : 0.f;
-            const float tau = 1.27f * (512.f * (g + ymax1 + 41.f) + relk * t1);
+            const float tau = 1.27f * (512.f * (g + ymax1 + (0.5f * NC + 1.0f)) + relk * t1);
             cert[cb] = t1 >= 1.0e-30f && t1 < 1.0e37f && w3 > t1 + tau;
             amb[cb] = !(u2 > t1 + tau);  // the runner-up is within reach: it needs the exact evaluation too
             c1[cb] = __float_as_int(t1) & ~idxmask;
@@ -595,10 +611,39 @@ static inline int pre_grid(long items, int per_block, int cap)
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+static bool pre_has_nc(int NC)
+{
+    switch (NC) {
+#define X(N) case N:
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        return true;
+        default: return false;
+    }
+}
+template <int NC> static size_t frame_image_bytes_t(long nb) { return (size_t)nb * 2 * PrePack<NC>::PAIRS * 64 * 16; }
+template <int NC> static size_t codebook_image_bytes_t(int M) { return (size_t)((M + 31) / 32) * PrePack<NC>::TILE_E * 16; }
+
 // (the codeword index shares the f32 key with the value: beyond 4096 codewords too few mantissa bits would be left)
-bool prefilter_supports(int NC, int M) { return NC == 37 && M >= 64 && M % 32 == 0 && M <= 4096; }
-size_t prefilter_frame_image_bytes(long nblocks64) { return (size_t)nblocks64 * 2 * PRE_PAIRS * 64 * 16; }
-size_t prefilter_codebook_image_bytes(int M) { return (size_t)((M + 31) / 32) * PRE_TILE_E * 16; }
+bool prefilter_supports(int NC, int M) { return pre_has_nc(NC) && M >= 64 && M % 32 == 0 && M <= 4096; }
+size_t prefilter_frame_image_bytes(int NC, long nblocks64)
+{
+    switch (NC) {
+#define X(N) case N: return frame_image_bytes_t<N>(nblocks64);
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        default: return 0;
+    }
+}
+size_t prefilter_codebook_image_bytes(int NC, int M)
+{
+    switch (NC) {
+#define X(N) case N: return codebook_image_bytes_t<N>(M);
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        default: return 0;
+    }
+}
 size_t prefilter_scalars_bytes() { return sizeof(PreScalars); }
 
 void launch_prefilter_frames(const double* blk, long T, long nblocks64, int NC, unsigned long long* colmax_bits, int* ea,
@@ -608,8 +653,16 @@ void launch_prefilter_frames(const double* blk, long T, long nblocks64, int NC, 
     hipLaunchKernelGGL(k_pre_colmax, dim3(pre_grid(nblocks64 * NC * 64, 256 * 8, 2048)), dim3(256), 0, s, blk, nblocks64,
                        NC, (u64*)colmax_bits);
     hipLaunchKernelGGL(k_pre_exponents, dim3(1), dim3(256), 0, s, (const u64*)colmax_bits, NC, ea);
-    hipLaunchKernelGGL(k_pre_frames, dim3(pre_grid(nblocks64 * 2, 1, 16384)), dim3(64), 0, s, blk, T, nblocks64 * 2, NC,
-                       (const int*)ea, (h8*)fimg, fg);
+    switch (NC) {
+#define X(N)                                                                                                        \
+    case N:                                                                                                         \
+        hipLaunchKernelGGL((k_pre_frames<N>), dim3(pre_grid(nblocks64 * 2, 1, 16384)), dim3(64), 0, s, blk, T,      \
+                           nblocks64 * 2, (const int*)ea, (h8*)fimg, fg);                                           \
+        break;
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        default: break;
+    }
 }
 
 void launch_prefilter_quantize_prep(const double* aos, long T, long nblocks64, int NC, const double* cbq, int M, int* ea,
@@ -617,8 +670,16 @@ void launch_prefilter_quantize_prep(const double* aos, long T, long nblocks64, i
 {
     const int NPAD = (NC + 7) & ~7;
     hipLaunchKernelGGL(k_pre_ea_from_codebook, dim3(1), dim3(1024), 0, s, cbq, M, NC, NPAD, ea);
-    hipLaunchKernelGGL((k_pre_quant_prep<37>), dim3(pre_grid(nblocks64, 1, 4096)), dim3(256), 0, s, aos, T, nblocks64,
-                       (const int*)ea, blk, (h8*)fimg, fg);
+    switch (NC) {
+#define X(N)                                                                                                        \
+    case N:                                                                                                         \
+        hipLaunchKernelGGL((k_pre_quant_prep<N>), dim3(pre_grid(nblocks64, 1, 4096)), dim3(256), 0, s, aos, T,      \
+                           nblocks64, (const int*)ea, blk, (h8*)fimg, fg);                                          \
+        break;
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        default: break;
+    }
 }
 
 const int* prefilter_fallback_count(const void* ps) { return &((const PreScalars*)ps)->fb_count; }
@@ -630,8 +691,16 @@ void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, 
     (void)hipMemsetAsync(ps, 0, sizeof(PreScalars), s);
     hipLaunchKernelGGL(k_pre_cmax, dim3(pre_grid((long)M * NC, 1024, 32)), dim3(256), 0, s, cbq, M, NC, NPAD, ea,
                        (PreScalars*)ps);
-    hipLaunchKernelGGL(k_pre_codebook, dim3((M + 31) / 32), dim3(256), 0, s, cbq, M, NC, NPAD, ea, (PreScalars*)ps,
-                       (h8*)cimg);
+    switch (NC) {
+#define X(N)                                                                                                        \
+    case N:                                                                                                         \
+        hipLaunchKernelGGL((k_pre_codebook<N>), dim3((M + 31) / 32), dim3(256), 0, s, cbq, M, NPAD, ea,             \
+                           (PreScalars*)ps, (h8*)cimg);                                                             \
+        break;
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        default: break;
+    }
 }
 
 // hybrid_table (full accumulation only): cells < mfma_hybrid_cells(NC) accumulate in the workgroup's LDS table.
@@ -639,14 +708,14 @@ void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, 
 // `incremental` the rows must be those of the previous pass over the same frames (distortion elements zeroed) and
 // prev_sym its cells.  Runs after launch_prefilter_codebook of the same pass; afterwards
 // *prefilter_fallback_count(ps) frames wait in fb_list for launch_pass_fallback.
-int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, long nblocks, const void* fimg,
-                            const float* fg, const void* cimg, void* ps, const double* cbq, int M,
-                            const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
-                            long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
-                            hipStream_t s)
+template <int NC>
+static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T, long nblocks, const void* fimg,
+                                     const float* fg, const void* cimg, void* ps, const double* cbq, int M,
+                                     const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym,
+                                     double* dmin, long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental,
+                                     bool hybrid_table, hipStream_t s)
 {
-    if (!prefilter_supports(NC, M) || (hybrid_table && incremental)) return 1;
-    constexpr int IMG = 2 * 37 + 5 + IMG_STRIDE_PAD;
+    constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
     constexpr int TPBM = 512;  // 8 waves = 2 per SIMD, one persistent workgroup per CU
     const size_t lds = (size_t)(TPBM / 64) * 16 * IMG * 4;
     int bits = 0;
@@ -655,26 +724,44 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
     const int grid = pre_grid(nblocks, TPBM / 64, 256);
     static const int stagger = getenv("ECOZ2_VQ_PRE_STAGGER") ? atoi(getenv("ECOZ2_VQ_PRE_STAGGER")) : 1;
     if (accumulate && hybrid_table) {  // full accumulation with the workgroup's LDS table for the first cells
-        const size_t lds5 = (size_t)mfma_hyb_cells(37) * (((2 * 37 + 5 + 7) & ~7) * 8) + lds;
-        (void)hipFuncSetAttribute((const void*)k_pass_pre<37, 5, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        const size_t lds5 = (size_t)mfma_hyb_cells(NC) * (((2 * NC + 5 + 7) & ~7) * 8) + lds;
+        (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 5, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
-        hipLaunchKernelGGL((k_pass_pre<37, 5, TPBM>), dim3(grid), dim3(TPBM), lds5, s, blk, T, nblocks, (const h8*)fimg, fg,
+        hipLaunchKernelGGL((k_pass_pre<NC, 5, TPBM>), dim3(grid), dim3(TPBM), lds5, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
                            dmin, rows, fb_list, stagger, prev_sym, 0);
     } else if (accumulate) {
-        (void)hipFuncSetAttribute((const void*)k_pass_pre<37, 2, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 2, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
-        hipLaunchKernelGGL((k_pass_pre<37, 2, TPBM>), dim3(grid), dim3(TPBM), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
+        hipLaunchKernelGGL((k_pass_pre<NC, 2, TPBM>), dim3(grid), dim3(TPBM), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
                            dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0);
     } else {
-        (void)hipFuncSetAttribute((const void*)k_pass_pre<37, 0, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 0, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
-        hipLaunchKernelGGL((k_pass_pre<37, 0, TPBM>), dim3(grid), dim3(TPBM), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
+        hipLaunchKernelGGL((k_pass_pre<NC, 0, TPBM>), dim3(grid), dim3(TPBM), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
                            dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0);
     }
     return 0;
+}
+
+int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, long nblocks, const void* fimg,
+                            const float* fg, const void* cimg, void* ps, const double* cbq, int M,
+                            const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
+                            long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
+                            hipStream_t s)
+{
+    if (!prefilter_supports(NC, M) || (hybrid_table && incremental)) return 1;
+    switch (NC) {
+#define X(N)                                                                                                          \
+    case N:                                                                                                           \
+        return launch_pass_prefiltered_t<N>(accumulate, blk, T, nblocks, fimg, fg, cimg, ps, cbq, M, sc, l1max_bits, sym, \
+                                            dmin, rows, fb_list, prev_sym, incremental, hybrid_table, s);
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        default: return 1;
+    }
 }
 
 }  // namespace e2vq

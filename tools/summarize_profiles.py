@@ -42,9 +42,11 @@ def bench_line(name):
 
 def is_dominant(kname, family):
     # the training sweep itself: k_pass_pre<...> or k_pass_mfma<37, m, 512> (the FP64 fallback sweep is <.., 256, 2>)
+    # (rocprofv3 leaves k_pass_pre mangled -- its _Float16 vector parameters defeat the demangler: _ZN4e2vq10k_pass_preILi37E..)
     if family == "k_pass_pre":
-        return "k_pass_pre<" in kname
-    return "k_pass_mfma<" in kname and ", 2>" not in kname.split("(")[0][-6:] or "k_pass_generic" in kname
+        return "k_pass_pre" in kname
+    head = kname.split("(")[0]
+    return ("k_pass_mfma<" in head and not head.rstrip().endswith(", 2>")) or "k_pass_generic" in head
 
 
 def ms(r):
@@ -80,7 +82,7 @@ def main():
     d = [ms(r) for r in rows]
     by_pos = [[d[i] for i in range(len(d)) if i % L == k] for k in range(L)]
     out = {
-        "kernel": rows[0]["Kernel_Name"].split("(")[0],
+        "kernel": rows[0]["Kernel_Name"].split("(")[0][:80],
         "dispatches": len(d), "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d),
         "avg_ms_by_pass_of_level": [sum(x) / len(x) for x in by_pos if x],
         "note": f"timed region = {len(d) // L} repetitions of the real M={M} level ({L} passes: pass 0 accumulates in full, "
