@@ -8,31 +8,31 @@
 //   * per coefficient n a power of two a_n (vq learn: > max_t |r_t[n]|, one scan per upload; vq quantize: from the
 //     codebook, so that no pass over the data is needed), per frame a power of two A_t,
 //     per codebook a power of two C:   xi = r / (a A_t),  eta = c a / C,  both in (-1, 1),  d = A_t C sum xi eta
-//   * xi -> two integer limbs  X1 = rint(xi 2^9) (|X1| <= 512), X2 (|X2| <= 256):
-//         xi = X1 2^-9 + X2 2^-18 + rho,  |rho| <= 2^-19;   eta likewise (Y1, Y2, sigma)
+//   * xi -> three integer limbs  X1 = rint(xi 2^9) (|X1| <= 512), X2, X3 (|.| <= 256):
+//         xi = X1 2^-9 + X2 2^-18 + X3 2^-27 + rho,  |rho| <= 2^-28;   eta likewise (Y1, Y2, Y3, sigma)
 //   * the limb products of equal weight are summed by v_mfma_f32_32x32x16_f16 into separate f32 accumulators
-//         W0 = sum X1 Y1,   W1 = sum X1 Y2 + X2 Y1
-//     every partial sum is an integer below 2^24 (NC 2^18 each, NC <= 41), i.e. exactly representable:
-//     the MFMA results are exact in any summation order (checked on hardware: tools/probe/pre_sweep.hip)
-//   * v = W0 2^9 + W1 (one f32 fma), key = v with its low mantissa bits replaced by the codeword index;
+//         W0 = sum X1 Y1,   W1 = sum X1 Y2 + X2 Y1,   W2 = sum X1 Y3 + X2 Y2 + X3 Y1
+//     every partial sum is an integer below 2^24 (NC 2^18, 2 NC 2^17, 5 NC 2^16 with NC <= 41), i.e. exactly
+//     representable: the MFMA results are exact in any summation order (checked on hardware: tools/probe/pre_sweep.hip)
+//   * v = W0 2^18 + W1 2^9 + W2 (two f32 fmas), key = v with its low mantissa bits replaced by the codeword index;
 //     a running (min, 2nd, 3rd) of the keys per frame costs three VALU ops per value
-//   * |2^27 sum xi eta - key| <= 2^8 (sum|xi| + max_m sum|eta_m| + NC/2 + 1) + |key| 2^-(22 - idxbits)   
+//   * |2^36 sum xi eta - key| <= 2^8 (sum|xi| + max_m sum|eta_m| + NC + 4) + |key| 2^-(22 - idxbits)     
 //     If the third key is farther from the first than twice that (x1.27), the true argmin is one of the first two:
 //     both are evaluated with the canonical FP64 chain (on the FP64 matrix pipe, as the diagonal of a 16x16 tile of
 //     gathered codewords -- the same instruction sequence as the full sweep, so bit-identical values) and compared
 //     exactly (ties: lower index).  Otherwise -- or if the smallest key is not a positive normal number -- the frame
 //     goes to a list that k_pass_mfma<SRC = 2> sweeps in full FP64 right after.  Nothing is ever decided by d~.
 //
-// Two limbs, not three (round 1 carried a third, W2 = sum X1 Y3 + X2 Y2 + X3 Y1, 15 MFMAs per tile instead of 8):
-// the codeword index takes log2 M low mantissa bits of the key, so at M >= 256 the key keeps 15 significant bits or
-// fewer -- |key| 2^-(22 - idxbits) dominates the bound, the 2^-19-relative limb remainder is already below it, and
-// a third limb bought matrix work without certifying a single extra frame.
+// Why three limbs: d = sum r[n] cq[n] is the small difference of large terms (sum xi eta ~ 3e-4 against sum |xi eta|
+// ~ 1 on LPC data), and the two best codewords of a frame are typically 5 % apart: the approximation must resolve
+// ~1e-6 of the term scale.  Two limbs (2^-19, 8 MFMAs per tile) were tried in round 2: bit-identical results, but
+// 99.7 % of the frames failed the certification and took the FP64 fallback.
 //
 // K-slot packing for any NC = P + 1 <= 41 (PrePack): with G = NC / 16 and R = NC % 16, each limb fills G "pairs" of 16
-// coefficients (two 8-half granules, lane halves h = 0, 1 of the 32x32x16 operand); a tail of 1 <= R <= 8
-// coefficients shares ONE pair between the limbs (h = 0: X1 tail, h = 1: X2 tail), a longer tail gets a zero-padded
-// pair per limb.  W0 takes the X1 pairs (+ the shared one, whose X2 half meets zeros), W1 every pair.
-// NC = 37: 5 pairs = 160 B per frame, 3 + 5 = 8 MFMAs per 32x32 tile (74 of 80 + 48 slots carry a product).
+// coefficients (two 8-half granules: lane halves h = 0, 1 of the 32x32x16 operand); the three R-coefficient tails
+// are packed back to back into ceil(3R / 16) further pairs.  W0 takes the pairs that hold X1 slots, W1 those with X1 or
+// X2 slots, W2 all of them; the codeword image puts the matching limb -- or zero -- in each slot.
+// NC = 37: 7 pairs = 224 B per frame, 3 + 5 + 7 = 15 MFMAs per 32x32 tile (222 of 240 slots carry a product).
 #include "vq_accum.h"
 #include "vq_device.h"
 #include "vq_fixed.h"
@@ -48,45 +48,55 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 template <int NC>
 struct PrePack {
+    static constexpr int NL = 3;                                  // limbs per value
     static constexpr int G = NC / 16, R = NC % 16;
-    static constexpr int FULL = R > 8 ? G + 1 : G;                // 16-coefficient pairs per limb
-    static constexpr int SHARED = (R >= 1 && R <= 8) ? 1 : 0;     // one pair holding both limbs' tails
-    static constexpr int PAIRS = 2 * FULL + SHARED;               // frame granule pairs (32 B each per frame)
-    static constexpr int NSTEP = 3 * FULL + 2 * SHARED;           // MFMA k-steps of 16: W0, then W1
-    static constexpr int W0_STEPS = FULL + SHARED;
+    static constexpr int TAILP = (NL * R + 15) / 16;              // pairs holding the limbs' tails back to back
+    static constexpr int PAIRS = NL * G + TAILP;                  // frame granule pairs (32 B each per frame)
+    // tail pairs that contain slots of limbs 0..l (the tails are laid out limb after limb)
+    __host__ __device__ static constexpr int tail_pairs_upto(int l) { return ((l + 1) * R + 15) / 16; }
+    // k-steps of weight level lv = frame limb + codeword limb: every pair holding a frame limb <= lv
+    __host__ __device__ static constexpr int level_steps(int lv) { return (lv + 1) * G + tail_pairs_upto(lv); }
+    static constexpr int NSTEP = level_steps(0) + level_steps(1) + level_steps(2);
     static constexpr int TILE_E = NSTEP * 64;                     // h8 granules per 32-codeword tile image
     static constexpr int NCX = (NC + 1) & ~1;
-    static_assert(NC >= 2 && NC <= 63, "partial sums must stay below 2^24: NC 2^18");
-    __host__ __device__ static constexpr int step_level(int s) { return s < W0_STEPS ? 0 : 1; }
-    // frame granule pair used by k-step s
+    static_assert(NC >= 2 && 5 * NC * 65536 < (1 << 24), "partial sums must stay below 2^24");
+    __host__ __device__ static constexpr int step_level(int s)
+    {
+        return s < level_steps(0) ? 0 : (s < level_steps(0) + level_steps(1) ? 1 : 2);
+    }
+    __host__ __device__ static constexpr int level_first(int lv)
+    {
+        return lv == 0 ? 0 : (lv == 1 ? level_steps(0) : level_steps(0) + level_steps(1));
+    }
+    // frame granule pair used by k-step s: the full pairs of limbs 0..lv first, then the tail pairs
     __host__ __device__ static constexpr int step_pair(int s)
     {
-        return s < FULL ? s : (s < W0_STEPS ? 2 * FULL : s - W0_STEPS);
+        const int lv = step_level(s), k = s - level_first(lv);
+        return k < (lv + 1) * G ? k : NL * G + (k - (lv + 1) * G);
     }
-    // element e of the granule (pair p, lane half h) of a frame: limb index fl (0, 1) and coefficient n, or n = -1 (zero)
+    // element e of the granule (pair p, lane half h) of a frame: limb index fl and coefficient n, or n = -1 (zero)
     __host__ __device__ static __forceinline__ void slot(int p, int h, int e, int& fl, int& n)
     {
-        if (p < FULL) {
-            fl = 0;
-            n = 16 * p + 8 * h + e;
-        } else if (p < 2 * FULL) {
-            fl = 1;
-            n = 16 * (p - FULL) + 8 * h + e;
+        if (p < NL * G) {
+            fl = p / (G > 0 ? G : 1);
+            n = 16 * (p - fl * G) + 8 * h + e;
         } else {
-            fl = h;
-            n = e < R ? 16 * G + e : -1;
+            const int k = 16 * (p - NL * G) + 8 * h + e;  // position in the run of tails
+            fl = R > 0 ? k / R : 0;
+            n = (R > 0 && k < NL * R) ? 16 * G + (k - fl * R) : -1;
         }
-        if (n >= NC) n = -1;
     }
 };
 
-// x in [-1, 1] -> the two integer limbs
-__device__ __forceinline__ void pre_split(double x, int& L1, int& L2)
+// x in [-1, 1] -> the three integer limbs
+__device__ __forceinline__ void pre_split(double x, int (&L)[3])
 {
     const double s1 = x * 512.0, l1 = __builtin_rint(s1);
     const double s2 = (s1 - l1) * 512.0, l2 = __builtin_rint(s2);
-    L1 = (int)l1;
-    L2 = (int)l2;
+    const double s3 = (s2 - l2) * 512.0, l3 = __builtin_rint(s3);
+    L[0] = (int)l1;
+    L[1] = (int)l2;
+    L[2] = (int)l3;
 }
 
 // ---- data statistic: per-coefficient max |r[n]| over the blocked training set -----------------------------
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(64) void k_pre_frames(const double* __restrict__ bl
                                                    float* __restrict__ fg)
 {
     typedef PrePack<NC> PK;
-    __shared__ short X[2][32][PK::NCX];
+    __shared__ short X[3][32][PK::NCX];
     const int col = threadIdx.x & 31, hh = threadIdx.x >> 5;
     for (long b = blockIdx.x; b < nblk32; b += gridDim.x) {
         const long t = b * 32 + col;
@@ -143,14 +153,15 @@ __global__ __launch_bounds__(64) void k_pre_frames(const double* __restrict__ bl
         if (eA == -100000) eA = 0;
         double g = 0.0;
         for (int n = hh; n < PK::NCX; n += 2) {
-            int l1 = 0, l2 = 0;
+            int L[3] = {0, 0, 0};
             if (n < NC && t < T) {
                 const double xi = ldexp(blk[mfma_blk_offset(NC, t, n)], -ea[n] - eA);
                 g += fabs(xi);
-                pre_split(xi, l1, l2);
+                pre_split(xi, L);
             }
-            X[0][col][n] = (short)l1;
-            X[1][col][n] = (short)l2;
+            X[0][col][n] = (short)L[0];
+            X[1][col][n] = (short)L[1];
+            X[2][col][n] = (short)L[2];
         }
         g += __shfl_xor(g, 32, 64);
         if (hh == 0 && t < T) fg[t] = (float)g * 1.000001f;
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(256) void k_pre_quant_prep(const double* __restrict
     constexpr int NS = (NC + 3) / 4;
     typedef PrePack<NC> PK;
     __shared__ double stage[64 * NC];
-    __shared__ short X[2][64][PK::NCX];
+    __shared__ short X[3][64][PK::NCX];
     __shared__ int eAs[64];
     __shared__ int eas[NC];
     for (int n = threadIdx.x; n < NC; n += 256) eas[n] = ea[n];
@@ -245,10 +256,11 @@ __global__ __launch_bounds__(256) void k_pre_quant_prep(const double* __restrict
         __syncthreads();
         for (int i = threadIdx.x; i < 64 * PK::NCX; i += 256) {
             const int f = i / PK::NCX, n = i - f * PK::NCX;
-            int l1 = 0, l2 = 0;
-            if (n < NC) pre_split(ldexp(stage[f * NC + n], -eas[n] - eAs[f]), l1, l2);
-            X[0][f][n] = (short)l1;
-            X[1][f][n] = (short)l2;
+            int L[3] = {0, 0, 0};
+            if (n < NC) pre_split(ldexp(stage[f * NC + n], -eas[n] - eAs[f]), L);
+            X[0][f][n] = (short)L[0];
+            X[1][f][n] = (short)L[1];
+            X[2][f][n] = (short)L[2];
         }
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * PK::PAIRS * 64; i += 256) {
@@ -302,16 +314,17 @@ __global__ __launch_bounds__(256) void k_pre_codebook(const double* __restrict__
                                                       h8* __restrict__ cimg)
 {
     typedef PrePack<NC> PK;
-    __shared__ short Y[2][32][PK::NCX];
+    __shared__ short Y[3][32][PK::NCX];
     const int tile = blockIdx.x;
     const int eC = ps->eC_biased ? ps->eC_biased - PRE_EBIAS : 0;
     for (int i = threadIdx.x; i < 32 * PK::NCX; i += 256) {
         const int row = i / PK::NCX, n = i - row * PK::NCX;
         const int m = tile * 32 + row;
-        int l1 = 0, l2 = 0;
-        if (n < NC && m < M) pre_split(ldexp(cbq[(long)m * NPAD + n], ea[n] - eC), l1, l2);
-        Y[0][row][n] = (short)l1;
-        Y[1][row][n] = (short)l2;
+        int L[3] = {0, 0, 0};
+        if (n < NC && m < M) pre_split(ldexp(cbq[(long)m * NPAD + n], ea[n] - eC), L);
+        Y[0][row][n] = (short)L[0];
+        Y[1][row][n] = (short)L[1];
+        Y[2][row][n] = (short)L[2];
     }
     if (threadIdx.x < 32) {  // sum_n |eta| of this tile's codewords -> global max (float bits, rounded up)
         const int m = tile * 32 + threadIdx.x;
@@ -330,7 +343,7 @@ __global__ __launch_bounds__(256) void k_pre_codebook(const double* __restrict__
             int fl, n;
             PK::slot(pr, hh, e, fl, n);
             const int cl = lv - fl;  // codeword limb that meets frame limb fl at this weight
-            if (n >= 0 && cl >= 0 && cl <= 1) out[e] = (_Float16)(int)Y[cl][row][n];
+            if (n >= 0 && cl >= 0 && cl <= 2) out[e] = (_Float16)(int)Y[cl][row][n];
         }
         cimg[(long)tile * PK::TILE_E + i] = out;
     }
@@ -439,21 +452,21 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) k1[cb] = k2[cb] = k3[cb] = __int_as_float(0x7f7fffff);
 
-        f16v acc0[2], acc1[2];
+        f16v acc0[3], acc1[3];
 #pragma unroll
-        for (int l = 0; l < 2; ++l)
+        for (int l = 0; l < 3; ++l)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[l][r] = l == 1 ? 3.0e38f : 0.f;
+            for (int r = 0; r < 16; ++r) acc1[l][r] = l == 2 ? 3.0e38f : 0.f;
 
         // one job = the NSTEP MFMAs of (tile, column block) interleaved with the key epilogue of the previous job
-        // (80 VALU ops: fma, and_or, three med3 per value), pinned by sched_group_barrier: with 8 MFMAs (NC = 37) the
-        // stream is VALU-issue bound at 10 ops per 32-cycle MFMA
-        constexpr int VALU_PER_MFMA = (80 + PK::NSTEP - 1) / PK::NSTEP;
+        // (96 VALU ops: two fmas, and_or, three med3 per value), pinned by sched_group_barrier; NC = 37: 15 MFMAs,
+        // 1 MFMA (32 cycles, 8 of them blocking issue) : 6 VALU ops (+ 1 per MFMA of slack for the shorter orders)
+        constexpr int VALU_PER_MFMA = (96 + PK::NSTEP - 1) / PK::NSTEP;
 #define E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
     {                                                                                                             \
         const int sidx = __builtin_amdgcn_readfirstlane((PTILE) * 32 + 8 * (r >> 2) + (r & 3));                   \
-        const float v = __builtin_fmaf(PREV[0][r], 512.f, PREV[1][r]);                                            \
+        const float v = __builtin_fmaf(PREV[0][r], 262144.f, __builtin_fmaf(PREV[1][r], 512.f, PREV[2][r]));     \
         const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);                                     \
         k3[PCB] = med3f(k2[PCB], k3[PCB], key);                                                                   \
         k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                                   \
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
         _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
         {                                                                                                         \
             const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \
-            const bool first = s == 0 || s == PK::W0_STEPS;                                                       \
+            const bool first = s == PK::level_first(lv);                                                         \
             ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
         }                                                                                                         \
         E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
@@ -501,7 +514,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             // t1 <= u2 <= w3: the three smallest keys of frame 32 cb + (lane & 31)
             const long t = b * 64 + 32 * cb + (lane & 31);
             const float g = t < T ? fg[t] : 0.f;
-            const float tau = 1.27f * (512.f * (g + ymax1 + (0.5f * NC + 1.0f)) + relk * t1);
+            const float tau = 1.27f * (512.f * (g + ymax1 + (NC + 4.0f)) + relk * t1);
             cert[cb] = t1 >= 1.0e-30f && t1 < 1.0e37f && w3 > t1 + tau;
             amb[cb] = !(u2 > t1 + tau);  // the runner-up is within reach: it needs the exact evaluation too
             c1[cb] = __float_as_int(t1) & ~idxmask;

@@ -248,3 +248,48 @@ def test_iterate_is_pass_stats_update(oracle, monkeypatch):
             ls = s.iterate()
             assert (ls.DD, ls.avg_distortion, ls.sigma, ls.inertia) == (ls_o.DD, ls_o.avg, ls_o.sigma, ls_o.inertia)
             assert np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64))
+
+
+@pytest.mark.parametrize("Pn", [12, 16, 20, 24, 28, 32, 40])
+def test_prefilter_for_other_prediction_orders(oracle, monkeypatch, Pn):
+    """the K-slot packing is generic in the prediction order (P = 12, 16, ..., 40; `-P` is a free parameter of the
+    reference's CLI, src/vq/mod.rs:44): whole ladders to M = 512 with the prefiltered sweep from M = 64 (full and
+    incremental accumulates, fallback list), a quantize through the prefiltered quantize path, and one pass with
+    adversarial frames -- all bit-identical to the oracle"""
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER", "1")
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
+    frames = e.synth.synth_frames(20270 + Pn, 6, Pn, 0, 12000)
+    rc, levels_o, cbs_o = oracle.learn(frames, 0.05, 512)
+    assert rc == 0
+    cbs, used = [], []
+    with e.VqSession(Pn) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        levels = s.learn(0.05, 512, callback=lambda M, a, sg, i: (cbs.append((M, a, sg, i)), used.append(s.last_pass_info())))
+        refl = s.get_codebook()
+        sym, dmin = s.quantize(frames)
+        # adversarial pass: rescaled / zero / sign-flipped frames, duplicated codewords
+        rng = np.random.default_rng(Pn)
+        bad = frames[:3000].copy()
+        bad[::7] *= 10.0 ** rng.integers(-15, 15, size=bad[::7].shape[0])[:, None]
+        bad[5::11] = 0.0
+        bad[3::13] *= -1.0
+        twins = np.concatenate([refl[:128], refl[:128]], axis=0)
+        s.set_frames(bad)
+        s.prepare()
+        s.set_codebook(twins)
+        s.run_pass()
+        rows_bad = s.get_rows()
+        pre_bad, fb_bad = s.last_pass_info()
+    assert [(l.M, l.passes) for l in levels] == [(l["M"], l["passes"]) for l in levels_o] and cbs == cbs_o
+    assert np.array_equal(refl.view(np.uint64), levels_o[-1]["reflections"].view(np.uint64))
+    assert [u[0] for u in used] == [lv["M"] >= 64 for lv in levels_o]  # the prefiltered kernel did serve M >= 64
+    assert all(u[1] < 0.2 * len(frames) for u in used)
+    sym_o, dmin_o = oracle.quantize(oracle.reflections_to_cq(refl), frames)
+    assert np.array_equal(sym, sym_o) and np.array_equal(dmin.view(np.uint64), dmin_o.view(np.uint64))
+    cq = oracle.reflections_to_cq(twins)
+    rc, st = oracle.data_stats(bad)
+    sh_r, _ = oracle.shifts(st.maxabs)
+    _s, _d, rows_o = oracle.run_pass(cq, bad, sh_r, oracle.dist_exponent(cq, st.maxabs))
+    assert pre_bad and fb_bad > 0 and np.array_equal(rows_bad, rows_o)

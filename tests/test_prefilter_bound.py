@@ -1,9 +1,9 @@
 """CPU check of the mathematics behind the prefiltered sweep (ecoz2rs_amd/csrc/vq_prefilter.hip).
 
-A numpy restatement of the limb split, the two exact integer sums and the f32 key, on synthetic frames and
+A numpy restatement of the limb split, the three exact integer sums and the f32 key, on synthetic frames and
 codebooks of several kinds, checks what the kernel relies on:
   * every limb is within its range and every |W| partial-sum bound stays below 2^24 (exact f32 accumulation),
-  * |2^27 sum(xi eta) - key| <= 2^8 (sum|xi| + max sum|eta| + NC/2 + 1) + |key| 2^-(22 - idxbits)   (the proven bound),
+  * |2^36 sum(xi eta) - key| <= 2^8 (sum|xi| + max sum|eta| + 41) + |key| 2^-(22 - idxbits)   (the proven bound),
   * whenever the third key is farther than tau from the first, the true argmin is one of the first two.
 No GPU and no product code involved: this pins the host-side logic (scales, tolerance) the kernels implement."""
 import numpy as np
@@ -20,7 +20,9 @@ def _split(x):
     l1 = np.rint(s1)
     s2 = (s1 - l1) * 512.0
     l2 = np.rint(s2)
-    return l1, l2
+    s3 = (s2 - l2) * 512.0
+    l3 = np.rint(s3)
+    return l1, l2, l3
 
 
 def _ilogb(a):
@@ -39,17 +41,20 @@ def _keys(frames, cq, ea):
     eta = np.ldexp(cq, (ea[None, :] - eC).astype(np.int64))
     assert np.abs(xi).max() < 1.0 and np.abs(eta).max() < 1.0
     X, Y = _split(xi), _split(eta)
-    for L, lim in zip(X + Y, (512, 256) * 2):
+    for L, lim in zip(X + Y, (512, 256, 256) * 2):
         assert np.abs(L).max() <= lim
     W0 = X[0] @ Y[0].T
     W1 = X[0] @ Y[1].T + X[1] @ Y[0].T
+    W2 = X[0] @ Y[2].T + X[1] @ Y[1].T + X[2] @ Y[0].T
     # bounds on every partial sum (sums of absolute values): exact in f32 whatever the summation order
     assert (np.abs(X[0]) @ np.abs(Y[0]).T).max() < 2 ** 24
     assert (np.abs(X[0]) @ np.abs(Y[1]).T + np.abs(X[1]) @ np.abs(Y[0]).T).max() < 2 ** 24
-    v = (W0 * 512.0 + W1).astype(np.float32)  # one rounding: what fmaf does (the exact value is an integer < 2^34)
+    assert (np.abs(X[0]) @ np.abs(Y[2]).T + np.abs(X[1]) @ np.abs(Y[1]).T + np.abs(X[2]) @ np.abs(Y[0]).T).max() < 2 ** 24
+    v1 = (W1 * 512.0 + W2).astype(np.float32).astype(np.float64)  # one rounding: what fmaf does
+    v = (W0 * 262144.0 + v1).astype(np.float32)
     g = np.abs(xi).sum(axis=1)
     ymax = np.abs(eta).sum(axis=1).max()
-    exact = (xi @ eta.T) * 2.0 ** 27  # 2^27 sum xi eta (float64: error ~1e-16 relative of sum |terms|, negligible)
+    exact = (xi @ eta.T) * 2.0 ** 36  # 2^36 sum xi eta (float64: error ~1e-16 relative of sum |terms|, negligible)
     return v, exact, g, ymax
 
 
@@ -81,16 +86,62 @@ def test_limb_prefilter_bound_and_certification(oracle, kind):
     bits = 8  # log2 M
     mask = np.uint32(~((1 << bits) - 1) & 0xFFFFFFFF)
     key = ((v.view(np.uint32) & mask) | np.arange(M, dtype=np.uint32)[None, :]).view(np.float32).astype(np.float64)
-    CONST = 0.5 * NC + 1.0
-    eps = 256.0 * (g[:, None] + ymax + CONST) + np.abs(key) * 2.0 ** -(22 - bits)
+    eps = 256.0 * (g[:, None] + ymax + 41.0) + np.abs(key) * 2.0 ** -(22 - bits)
     assert (np.abs(exact - key) <= eps).all(), "the proven bound does not hold"
     # certification as in k_pass_pre
     order = np.argsort(key, axis=1, kind="stable")
     k = np.take_along_axis(key, order[:, :3], axis=1)
-    tau = 1.27 * (512.0 * (g + ymax + CONST) + 2.0 * 2.0 ** -(22 - bits) * k[:, 0])
+    tau = 1.27 * (512.0 * (g + ymax + 41.0) + 2.0 * 2.0 ** -(22 - bits) * k[:, 0])
     cert = (k[:, 0] >= 1e-30) & (k[:, 2] > k[:, 0] + tau)
     d = frames @ cq.T  # the distortions themselves (any tie inside float64 noise would sit inside tau anyway)
     best = d.argmin(axis=1)
     in_top2 = (best == order[:, 0]) | (best == order[:, 1])
     assert in_top2[cert].all(), "a certified frame lost its argmin"
     assert cert.mean() > (0.5 if kind != "twins" else 0.2)  # the prefilter certifies most ordinary frames
+
+
+def _pack(NC, NL=3):
+    """PrePack<NC> of vq_prefilter.hip restated: (pairs, steps, step -> (level, pair), slot(pair, h, e) -> (limb, n))"""
+    G, R = NC // 16, NC % 16
+    tails_upto = lambda l: ((l + 1) * R + 15) // 16
+    level_steps = lambda lv: (lv + 1) * G + tails_upto(lv)
+    first = [0, level_steps(0), level_steps(0) + level_steps(1)]
+    nstep = sum(level_steps(lv) for lv in range(3))
+
+    def slot(p, h, e):
+        if p < NL * G:
+            fl = p // max(G, 1)
+            return fl, 16 * (p - fl * G) + 8 * h + e
+        k = 16 * (p - NL * G) + 8 * h + e
+        fl = k // R if R > 0 else 0
+        return fl, (16 * G + (k - fl * R)) if (R > 0 and k < NL * R) else -1
+
+    def step(s):
+        lv = 0 if s < first[1] else (1 if s < first[2] else 2)
+        k = s - first[lv]
+        return lv, (k if k < (lv + 1) * G else NL * G + (k - (lv + 1) * G))
+
+    return NL * G + (NL * R + 15) // 16, nstep, step, slot
+
+
+@pytest.mark.parametrize("nc", [5, 13, 16, 17, 21, 25, 29, 32, 33, 37, 40, 41])
+def test_k_slot_packing_carries_every_limb_product_once(nc):
+    """the K-slot packing generic in the prediction order: at weight level lv the MFMA steps multiply every
+    (frame limb fl, codeword limb lv - fl, coefficient n) pair exactly once, and nothing else"""
+    pairs, nstep, step, slot = _pack(nc)
+    for lv in range(3):
+        seen = {}
+        for s in range(nstep):
+            l, p = step(s)
+            if l != lv:
+                continue
+            assert 0 <= p < pairs
+            for h in range(2):
+                for e in range(8):
+                    fl, n = slot(p, h, e)
+                    if n >= 0 and 0 <= lv - fl <= 2:
+                        seen[(fl, n)] = seen.get((fl, n), 0) + 1
+        assert set(seen) == {(fl, n) for fl in range(lv + 1) for n in range(nc)} and set(seen.values()) == {1}
+    if nc == 37:
+        assert (pairs, nstep) == (7, 15)  # 224 B per frame, 3 + 5 + 7 MFMAs per 32x32 tile
+    assert 5 * nc * 65536 < 2 ** 24  # exact f32 partial sums
