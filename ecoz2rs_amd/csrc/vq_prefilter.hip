@@ -460,8 +460,8 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 
         // one job = the NSTEP MFMAs of (tile, column block) interleaved with the key epilogue of the previous job
         // (96 VALU ops: two fmas, and_or, three med3 per value), pinned by sched_group_barrier; NC = 37: 15 MFMAs,
-        // 1 MFMA (32 cycles, 8 of them blocking issue) : 6 VALU ops (+ 1 per MFMA of slack for the shorter orders)
-        constexpr int VALU_PER_MFMA = (96 + PK::NSTEP - 1) / PK::NSTEP;
+        // 1 MFMA (32 cycles, 8 of them blocking issue) : 6 VALU ops
+        constexpr int VALU_PER_MFMA = 96 / PK::NSTEP;
 #define E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
     {                                                                                                             \
