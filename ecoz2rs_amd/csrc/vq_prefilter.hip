@@ -461,7 +461,11 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
         // one job = the NSTEP MFMAs of (tile, column block) interleaved with the key epilogue of the previous job
         // (96 VALU ops: two fmas, and_or, three med3 per value), pinned by sched_group_barrier; NC = 37: 15 MFMAs,
         // 1 MFMA (32 cycles, 8 of them blocking issue) : 6 VALU ops
+#ifdef E2VQ_PRE_VPM  // A/B knob (tools/probe/ab): VALU ops pinned behind each MFMA of a job
+        constexpr int VALU_PER_MFMA = E2VQ_PRE_VPM;
+#else
         constexpr int VALU_PER_MFMA = 96 / PK::NSTEP;
+#endif
 #define E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
     {                                                                                                             \
@@ -472,6 +476,23 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
         k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                                   \
         k1[PCB] = med3f(k1[PCB], key, ninf);                                                                      \
     }
+#if defined(E2VQ_PRE_NOSCHED)  // A/B: leave the interleave to the compiler
+#define E2VQ_PRE_PIN
+#elif defined(E2VQ_PRE_PAIRSCHED)  // A/B: two MFMAs, then twice the VALU ops
+#define E2VQ_PRE_PIN                                                                                              \
+    _Pragma("unroll") for (int s = 0; s < (PK::NSTEP + 1) / 2; ++s)                                               \
+    {                                                                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2 * VALU_PER_MFMA, 0);                                        \
+    }
+#else
+#define E2VQ_PRE_PIN                                                                                              \
+    _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                         \
+    {                                                                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);                                            \
+    }
+#endif
 #define E2VQ_PRE_JOB(ACC, BC, PREV, PTILE, PCB)                                                                   \
     {                                                                                                             \
         const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
@@ -482,11 +503,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
         }                                                                                                         \
         E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
-        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
-        {                                                                                                         \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                    \
-            __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);                                        \
-        }                                                                                                         \
+        E2VQ_PRE_PIN                                                                                              \
     }
         for (int t = 0; t < MT; ++t) {
             h8 A[PK::NSTEP];
@@ -497,6 +514,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
         }
         E2VQ_PRE_EPILOGUE(acc1, MT - 1, 1)
 #undef E2VQ_PRE_JOB
+#undef E2VQ_PRE_PIN
 #undef E2VQ_PRE_EPILOGUE
 
         // ---- per frame: merge the two lane halves (rows 4h..4h+3 of every 8), certify the top two -------------
