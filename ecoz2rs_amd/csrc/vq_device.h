@@ -64,7 +64,13 @@ void launch_rows_stats(const long long* rows, int M, int NC, const DevScalars* s
                        long long* lstats, hipStream_t s);
 void launch_centroids(const long long* rows, const double* S, int M, int NC, const double* refl_in, double* refl_out,
                       long long* lstats, hipStream_t s);
-void launch_combine_i64(long long* dst, const long long* stage, int nsrc, long count, int op, hipStream_t s);
+// in-process multi-GPU exchange: the caller's slice [lo, hi) of `count` words is combined over the n ranks' buffers
+// (peer pointers) and written back to all of them
+constexpr int E2VQ_MAX_LOCAL_RANKS = 16;
+struct PeerBuffers {
+    long long* p[E2VQ_MAX_LOCAL_RANKS];
+};
+void launch_reduce_slice_i64(const PeerBuffers& bufs, int n, long lo, long hi, int op, hipStream_t s);
 // copies the level statistics to host-mapped memory, zeroes the slots for the next pass, then stores `seq` at *h_seq
 // (all pointers device-visible)
 void launch_publish_stats(long long* lstats, const unsigned long long* l1max_bits, const double* within, int M,

@@ -1193,22 +1193,25 @@ void launch_finish_q(const i64* stats, int NC, DevScalars* sc, hipStream_t s)
     hipLaunchKernelGGL(k_finish_q, dim3(1), dim3(64), 0, s, stats, NC, sc);
 }
 
-// in-process multi-GPU exchange: dst[i] (op)= src_k[i] for k < nsrc, 64-bit integers (sum or max), exact
-__global__ void k_combine_i64(i64* __restrict__ dst, const i64* __restrict__ stage, int nsrc, long count, int op)
+// in-process multi-GPU exchange (reduce-scatter + all-gather in one kernel per rank): the launching rank owns words
+// [lo, hi); it reads them from every rank's buffer (peer access over xGMI), combines (64-bit integer sum or unsigned
+// max: exact, order-free) and writes the result back into every rank's buffer
+__global__ void k_reduce_slice_i64(PeerBuffers bufs, int n, long lo, long hi, int op)
 {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
-        i64 v = dst[i];
-        for (int k = 0; k < nsrc; ++k) {
-            const i64 o = stage[(long)k * count + i];
+    for (long i = lo + (long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (long)gridDim.x * blockDim.x) {
+        i64 v = bufs.p[0][i];
+        for (int k = 1; k < n; ++k) {
+            const i64 o = bufs.p[k][i];
             v = op == 0 ? v + o : ((u64)o > (u64)v ? o : v);
         }
-        dst[i] = v;
+        for (int k = 0; k < n; ++k) bufs.p[k][i] = v;
     }
 }
 
-void launch_combine_i64(i64* dst, const i64* stage, int nsrc, long count, int op, hipStream_t s)
+void launch_reduce_slice_i64(const PeerBuffers& bufs, int n, long lo, long hi, int op, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_combine_i64, dim3(grid_for(count, 256, 1024)), dim3(256), 0, s, dst, stage, nsrc, count, op);
+    if (hi <= lo) return;
+    hipLaunchKernelGGL(k_reduce_slice_i64, dim3(grid_for(hi - lo, 256, 256)), dim3(256), 0, s, bufs, n, lo, hi, op);
 }
 
 bool has_cell_update(int NC) { return NC <= 64; }

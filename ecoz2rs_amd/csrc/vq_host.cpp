@@ -1058,9 +1058,11 @@ extern "C" int e2vq_avg_distortion_host(e2vq_session* s, const double* frames, i
 
 // ==========================================================================================
 // In-process group: N sessions (one per GPU, one host thread each) behind the single-process entry points.
-// The per-pass exchange of the int64 cell sums runs GPU-to-GPU: every rank copies its buffer to a staging area on
-// rank 0's device (hipMemcpyPeerAsync: xGMI between the GPUs of a node), rank 0 combines with an integer kernel
-// and the result is copied back.  Integer sums: the outcome is bit-identical for any N.
+// The per-pass exchange of the int64 cell sums is a reduce-scatter + all-gather over peer-to-peer memory: rank r owns
+// slice r of the buffer; ONE kernel per rank, all running at the same time, reads that slice from every rank's buffer
+// (xGMI between the GPUs of a node), adds, and writes the sum back into every buffer.  Ordering is carried by events
+// (producers done -> slice kernels -> consumers); the two host barriers only make sure an event has been recorded
+// before another rank's stream is told to wait for it.  Integer sums: bit-identical for any N.
 // Opt-in: ECOZ2_VQ_GPUS=N (ranks beyond the device count share devices, which is how the single-GPU tests run it).
 // ==========================================================================================
 namespace {
@@ -1072,13 +1074,9 @@ struct LocalGroup {
     int arrived = 0;
     long generation = 0;
     bool failed = false;
-    // exchange state
-    int dev0 = 0;
-    i64* stage = nullptr;  // on dev0: (n-1) x stage_cap words
-    long stage_cap = 0;
-    i64* buf0 = nullptr;
-    std::vector<hipEvent_t> ev_up, ev_back;
-    hipEvent_t ev_done = nullptr;
+    // exchange state: every rank publishes its buffer and records its events, then waits on the others'
+    e2vq::PeerBuffers bufs{};
+    std::vector<hipEvent_t> ev_ready, ev_done;
 
     // reusable barrier; returns false if the group has failed
     bool barrier()
@@ -1127,40 +1125,21 @@ int local_allreduce(void* user, void* buf, int64_t count, int op, void* stream_)
     LocalRank* lr = (LocalRank*)user;
     LocalGroup* g = lr->g;
     hipStream_t stream = (hipStream_t)stream_;
-    const int r = lr->rank;
-    const size_t bytes = (size_t)count * 8;
-    if (r == 0) {
-        GRPCHK(hipSetDevice(g->dev0));
-        if (count > g->stage_cap) {  // (grown before anyone copies: ranks > 0 wait at barrier A0)
-            if (g->stage) (void)hipFree(g->stage);
-            g->stage = nullptr;
-            GRPCHK(hipMalloc(&g->stage, (size_t)(g->n - 1) * bytes));
-            g->stage_cap = count;
-        }
-        g->buf0 = (i64*)buf;
-    }
-    if (!g->barrier()) return e2vq_set_error("in-process group: another rank failed");  // A0: staging area and buf0 published
-    if (r > 0) {
-        GRPCHK(hipSetDevice(lr->device));
-        GRPCHK(hipMemcpyPeerAsync(g->stage + (size_t)(r - 1) * count, g->dev0, buf, lr->device, bytes, stream));
-        GRPCHK(hipEventRecord(g->ev_up[r], stream));
-    }
-    if (!g->barrier()) return 1;  // A: every upload is enqueued and its event recorded
-    if (r == 0) {
-        for (int k = 1; k < g->n; ++k) GRPCHK(hipStreamWaitEvent(stream, g->ev_up[k], 0));
-        e2vq::launch_combine_i64((i64*)buf, g->stage, g->n - 1, count, op, stream);
-        GRPCHK(hipGetLastError());
-        GRPCHK(hipEventRecord(g->ev_done, stream));
-    }
-    if (!g->barrier()) return 1;  // B: the combine is enqueued on rank 0's stream
-    if (r > 0) {
-        GRPCHK(hipStreamWaitEvent(stream, g->ev_done, 0));
-        GRPCHK(hipMemcpyPeerAsync(buf, lr->device, g->buf0, g->dev0, bytes, stream));
-        GRPCHK(hipEventRecord(g->ev_back[r], stream));
-    }
-    if (!g->barrier()) return 1;  // C: every copy-back is enqueued
-    if (r == 0)  // later work on rank 0's stream (e.g. zeroing the rows) must not overtake the copy-backs
-        for (int k = 1; k < g->n; ++k) GRPCHK(hipStreamWaitEvent(stream, g->ev_back[k], 0));
+    const int r = lr->rank, n = g->n;
+    GRPCHK(hipSetDevice(lr->device));
+    g->bufs.p[r] = (long long*)buf;
+    GRPCHK(hipEventRecord(g->ev_ready[r], stream));  // this rank's words are final once the stream gets here
+    if (!g->barrier()) return e2vq_set_error("in-process group: another rank failed");  // A: buffers + ready events published
+    for (int k = 0; k < n; ++k)
+        if (k != r) GRPCHK(hipStreamWaitEvent(stream, g->ev_ready[k], 0));
+    const long lo = (long)((int64_t)r * count / n), hi = (long)((int64_t)(r + 1) * count / n);
+    e2vq::launch_reduce_slice_i64(g->bufs, n, lo, hi, op, stream);
+    GRPCHK(hipGetLastError());
+    GRPCHK(hipEventRecord(g->ev_done[r], stream));
+    if (!g->barrier()) return e2vq_set_error("in-process group: another rank failed");  // B: every slice kernel is enqueued
+    // nobody touches its buffer again (reads the sums, zeroes the rows) before every slice has been written everywhere
+    for (int k = 0; k < n; ++k)
+        if (k != r) GRPCHK(hipStreamWaitEvent(stream, g->ev_done[k], 0));
     return 0;
 }
 
@@ -1249,48 +1228,43 @@ static int learn_common(int P, double eps, const char* class_name, const double*
 
     // ---- in-process group: rank r on device (dev0 + r) % ndev, contiguous frame shards --------------------------
     printf("sharding over %d rank(s) on %d device(s)\n", world, ndev);
+    if (world > e2vq::E2VQ_MAX_LOCAL_RANKS) return e2vq_set_error("ECOZ2_VQ_GPUS=%d exceeds %d in-process ranks", world, e2vq::E2VQ_MAX_LOCAL_RANKS);
     LocalGroup g;
     g.n = world;
-    g.dev0 = dev0 % ndev;
-    g.ev_up.assign((size_t)world, nullptr);
-    g.ev_back.assign((size_t)world, nullptr);
-    struct GroupCleanup {  // events and the staging area are released on every return path
+    g.ev_ready.assign((size_t)world, nullptr);
+    g.ev_done.assign((size_t)world, nullptr);
+    struct GroupCleanup {  // events are released on every return path
         LocalGroup& g;
         ~GroupCleanup()
         {
-            for (hipEvent_t ev : g.ev_up)
+            for (hipEvent_t ev : g.ev_ready)
                 if (ev) (void)hipEventDestroy(ev);
-            for (hipEvent_t ev : g.ev_back)
+            for (hipEvent_t ev : g.ev_done)
                 if (ev) (void)hipEventDestroy(ev);
-            if (g.ev_done) (void)hipEventDestroy(g.ev_done);
-            if (g.stage) {
-                (void)hipSetDevice(g.dev0);
-                (void)hipFree(g.stage);
-            }
         }
     } cleanup{g};
     std::vector<LocalRank> ranks((size_t)world);
     for (int r = 0; r < world; ++r) {
         ranks[r] = LocalRank{&g, r, (dev0 + r) % ndev};
         HIPCHK(hipSetDevice(ranks[r].device));
-        HIPCHK(hipEventCreateWithFlags(&g.ev_up[r], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&g.ev_back[r], hipEventDisableTiming));
-        if (ranks[r].device != g.dev0) {  // peer access both ways; "already enabled" is the only tolerated failure
-            for (int dir = 0; dir < 2; ++dir) {
-                const int from = dir ? g.dev0 : ranks[r].device, to = dir ? ranks[r].device : g.dev0;
-                int can = 0;
-                HIPCHK(hipDeviceCanAccessPeer(&can, from, to));
-                if (!can) return e2vq_set_error("device %d cannot access device %d (no peer path): ECOZ2_VQ_GPUS needs P2P", from, to);
-                HIPCHK(hipSetDevice(from));
-                const hipError_t pe = hipDeviceEnablePeerAccess(to, 0);
-                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
-                    return e2vq_set_error("hipDeviceEnablePeerAccess(%d -> %d) failed: %s", from, to, hipGetErrorString(pe));
-                (void)hipGetLastError();
-            }
-        }
+        HIPCHK(hipEventCreateWithFlags(&g.ev_ready[r], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&g.ev_done[r], hipEventDisableTiming));
     }
-    HIPCHK(hipSetDevice(g.dev0));
-    HIPCHK(hipEventCreateWithFlags(&g.ev_done, hipEventDisableTiming));
+    // every rank's slice kernel reads and writes every other rank's buffer: peer access between all pairs of distinct
+    // devices ("already enabled" is the only tolerated failure)
+    for (int a = 0; a < world; ++a)
+        for (int b = 0; b < world; ++b) {
+            const int from = ranks[a].device, to = ranks[b].device;
+            if (from == to) continue;
+            int can = 0;
+            HIPCHK(hipDeviceCanAccessPeer(&can, from, to));
+            if (!can) return e2vq_set_error("device %d cannot access device %d (no peer path): ECOZ2_VQ_GPUS needs P2P", from, to);
+            HIPCHK(hipSetDevice(from));
+            const hipError_t pe = hipDeviceEnablePeerAccess(to, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                return e2vq_set_error("hipDeviceEnablePeerAccess(%d -> %d) failed: %s", from, to, hipGetErrorString(pe));
+            (void)hipGetLastError();
+        }
     std::vector<int> rcs((size_t)world, 0);
     std::vector<std::thread> th;
     auto shard = [&](int r, i64* lo, i64* hi) {
@@ -1347,6 +1321,142 @@ extern "C" int ecoz2_vq_learn_using_base_codebook(const char* base_codebook, dou
     return learn_common(P, epsilon, cls, refl.data(), M, predictor_filenames, num_predictors, target, callback);
 }
 
+// ---- vq quantize / vq classify: predictor files through the GPU with I/O, copies and sweeps overlapped ------------
+namespace {
+
+bool all_finite(const double* v, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        if (!(fabs(v[i]) <= DBL_MAX)) return false;
+    return true;
+}
+
+// one in-flight predictor file of a quantize worker: pinned host buffers, device buffers, completion event
+struct QSlot {
+    double* h_frames = nullptr;
+    uint16_t* h_sym = nullptr;
+    double* h_dmin = nullptr;
+    double* d_frames = nullptr;
+    unsigned short* d_sym = nullptr;
+    double* d_dmin = nullptr;
+    i64 cap = 0;
+    hipEvent_t done = nullptr;
+    int file = -1;  // index of the file in flight, -1 = free
+    i64 T = 0;
+    char cls[96];
+    void release()
+    {
+        if (h_frames) (void)hipHostFree(h_frames);
+        if (h_sym) (void)hipHostFree(h_sym);
+        if (h_dmin) (void)hipHostFree(h_dmin);
+        if (d_frames) (void)hipFree(d_frames);
+        if (d_sym) (void)hipFree(d_sym);
+        if (d_dmin) (void)hipFree(d_dmin);
+        if (done) (void)hipEventDestroy(done);
+        h_frames = nullptr; h_sym = nullptr; h_dmin = nullptr; d_frames = nullptr; d_sym = nullptr; d_dmin = nullptr;
+        done = nullptr; cap = 0;
+    }
+    int ensure(i64 T, int NC)
+    {
+        if (!done) HIPCHK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        if (T <= cap) return 0;
+        hipEvent_t keep = done;
+        done = nullptr;
+        release();
+        done = keep;
+        const i64 c = std::max<i64>(T, 1024);
+        HIPCHK(hipHostMalloc(&h_frames, (size_t)c * NC * 8, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&h_sym, (size_t)c * 2 + 64, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&h_dmin, (size_t)c * 8, hipHostMallocDefault));
+        HIPCHK(hipMalloc(&d_frames, (size_t)c * NC * 8));
+        HIPCHK(hipMalloc(&d_sym, (size_t)c * 2 + 64));
+        HIPCHK(hipMalloc(&d_dmin, (size_t)c * 8));
+        cap = c;
+        return 0;
+    }
+};
+
+struct QFileResult {
+    int rc = 0;
+    i64 T = 0;
+    double e = 0.0;  // sum over the file's frames of (dmin - 1), frame order
+    std::string cls, seq_path, error;
+};
+
+// worker w of W: files w, w + W, ... on `device`.  Two slots: while the GPU sweeps file k, the host reads file k + 1
+// into pinned memory and writes the .seq of file k - 1.
+int quantize_worker(int device, int w, int W, int P, int M, const double* refl, const char* const* files, int n,
+                    const char* root, std::vector<QFileResult>& results)
+{
+    e2vq_session* s = nullptr;
+    if (e2vq_session_create(device, P, &s)) return 1;
+    hipStream_t st = nullptr;
+    QSlot slots[2];
+    int rc = e2vq_set_codebook(s, refl, M);
+    if (!rc && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = e2vq_set_error("stream creation failed");
+    if (!rc) rc = e2vq_set_stream(s, (void*)st);
+    const int NC = P + 1;
+    auto finish = [&](QSlot& q) -> int {  // results of the file in flight in q: distortion sum + .seq
+        if (q.file < 0) return 0;
+        HIPCHK(hipEventSynchronize(q.done));
+        QFileResult& r = results[(size_t)q.file];
+        double e = 0.0;
+        for (i64 t = 0; t < q.T; ++t) e += q.h_dmin[t] - 1.0;
+        r.e = e;
+        r.T = q.T;
+        r.cls = q.cls;
+        const std::string base = e2vq_io::basename_noext(files[q.file]);
+        char path[4096];
+        snprintf(path, sizeof path, "%s/data/sequences/M%d/%s/%s.seq", root, M, q.cls, base.c_str());
+        r.seq_path = path;
+        q.file = -1;
+        return e2vq_seq_write(path, r.cls.c_str(), M, q.h_sym, q.T);
+    };
+    int k = 0;
+    for (int i = w; i < n && !rc; i += W, ++k) {
+        QSlot& q = slots[k & 1];
+        rc = finish(q);
+        if (rc) break;
+        int p;
+        int64_t T;
+        rc = e2vq_prd_info(files[i], q.cls, &p, &T);
+        if (rc) break;
+        if (p != P) {
+            rc = e2vq_set_error("%s: prediction order %d differs from the codebook's %d", files[i], p, P);
+            break;
+        }
+        rc = q.ensure(T, NC);
+        if (rc) break;
+        rc = e2vq_prd_read(files[i], q.h_frames, T);
+        if (rc) break;
+        if (!all_finite(q.h_frames, (size_t)T * NC)) {
+            rc = e2vq_set_error("%s: contains NaN or infinite values", files[i]);
+            break;
+        }
+        q.file = i;
+        q.T = T;
+        if (T > 0) {
+            hipError_t e = hipMemcpyAsync(q.d_frames, q.h_frames, (size_t)T * NC * 8, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) rc = e2vq_quantize_device(s, q.d_frames, T, q.d_sym, q.d_dmin);
+            if (e == hipSuccess && !rc) e = hipMemcpyAsync(q.h_sym, q.d_sym, (size_t)T * 2, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && !rc) e = hipMemcpyAsync(q.h_dmin, q.d_dmin, (size_t)T * 8, hipMemcpyDeviceToHost, st);
+            if (e != hipSuccess) rc = e2vq_set_error("%s: copy failed: %s", files[i], hipGetErrorString(e));
+        }
+        if (!rc && hipEventRecord(q.done, st) != hipSuccess) rc = e2vq_set_error("event record failed");
+    }
+    for (int j = 0; j < 2 && !rc; ++j) rc = finish(slots[(k + j) & 1]);  // oldest first
+    if (st) (void)hipStreamSynchronize(st);
+    for (QSlot& q : slots) q.release();
+    e2vq_session_destroy(s);
+    if (st) (void)hipStreamDestroy(st);
+    return rc;
+}
+
+}  // namespace
+
+// ECOZ2_VQ_GPUS = N: the files are dealt round-robin to N workers (one session + host thread per GPU; ranks beyond the
+// device count share devices).  Frames are independent, so there is no collective; every .seq, and the totals (summed in
+// file order on the calling thread), are the same for any N.
 extern "C" int ecoz2_vq_quantize(const char* nom_raas, const char* const* predictor_filenames, int num_predictors,
                                  int show_filenames)
 {
@@ -1356,48 +1466,42 @@ extern "C" int ecoz2_vq_quantize(const char* nom_raas, const char* const* predic
     if (e2vq_cbook_info(nom_raas, cb_cls, &P, &M)) return 1;
     std::vector<double> refl((size_t)M * (P + 1));
     if (e2vq_cbook_read(nom_raas, refl.data(), M)) return 1;
-    e2vq_session* s = nullptr;
-    if (e2vq_session_create(env_int("ECOZ2_VQ_DEVICE", 0), P, &s)) return 1;
-    int rc = e2vq_set_codebook(s, refl.data(), M);
+    const int ndev = e2vq_device_count();
+    if (ndev < 1) return e2vq_set_error("no HIP device available; this library has no CPU path");
+    const int dev0 = env_int("ECOZ2_VQ_DEVICE", 0);
+    int W = std::max(1, env_int("ECOZ2_VQ_GPUS", 1));
+    W = std::max(1, std::min(W, num_predictors));
     const char* root = env_str("ECOZ2_VQ_OUT_ROOT", ".");
-    std::vector<double> frames;
-    std::vector<uint16_t> sym;
-    std::vector<double> dmin;
+    std::vector<QFileResult> results((size_t)num_predictors);
+    std::vector<int> rcs((size_t)W, 0);
+    std::vector<std::string> errs((size_t)W);
+    std::vector<std::thread> th;
+    auto run = [&](int w) {
+        rcs[(size_t)w] = quantize_worker((dev0 + w) % ndev, w, W, P, M, refl.data(), predictor_filenames, num_predictors, root,
+                                         results);
+        if (rcs[(size_t)w]) errs[(size_t)w] = g_err;
+    };
+    for (int w = 1; w < W; ++w) th.emplace_back(run, w);
+    run(0);
+    for (auto& t : th) t.join();
+    for (int w = 0; w < W; ++w)
+        if (rcs[(size_t)w]) {
+            if (w > 0) snprintf(g_err, sizeof g_err, "%s", errs[(size_t)w].c_str());
+            return rcs[(size_t)w];
+        }
     double total_e = 0.0;
     i64 total_T = 0;
-    for (int i = 0; i < num_predictors && !rc; ++i) {
-        char cls[96];
-        int p;
-        int64_t T;
-        rc = e2vq_prd_info(predictor_filenames[i], cls, &p, &T);
-        if (rc) break;
-        if (p != P) {
-            rc = e2vq_set_error("%s: prediction order %d differs from the codebook's %d", predictor_filenames[i], p, P);
-            break;
-        }
-        frames.resize((size_t)T * (P + 1));
-        sym.resize((size_t)T);
-        dmin.resize((size_t)T);
-        rc = e2vq_prd_read(predictor_filenames[i], frames.data(), T);
-        if (!rc && T > 0) rc = e2vq_quantize_host(s, frames.data(), T, sym.data(), dmin.data());
-        if (rc) break;
-        double e = 0.0;
-        for (i64 t = 0; t < T; ++t) e += dmin[(size_t)t] - 1.0;
-        total_e += e;
-        total_T += T;
-        const std::string base = e2vq_io::basename_noext(predictor_filenames[i]);
-        char path[4096];
-        snprintf(path, sizeof path, "%s/data/sequences/M%d/%s/%s.seq", root, M, cls, base.c_str());
-        rc = e2vq_seq_write(path, cls, M, sym.data(), T);
+    for (int i = 0; i < num_predictors; ++i) {
+        const QFileResult& r = results[(size_t)i];
+        total_e += r.e;
+        total_T += r.T;
         if (show_filenames)
-            printf("%s: '%s' T=%lld avg distortion=%g -> %s\n", predictor_filenames[i], cls, (long long)T,
-                   T ? e / (double)T : 0.0, path);
+            printf("%s: '%s' T=%lld avg distortion=%g -> %s\n", predictor_filenames[i], r.cls.c_str(), (long long)r.T,
+                   r.T ? r.e / (double)r.T : 0.0, r.seq_path.c_str());
     }
-    if (!rc)
-        printf("total: %d predictor file(s), %lld vectors, M=%d, avg distortion=%g\n", num_predictors,
-               (long long)total_T, M, total_T ? total_e / (double)total_T : 0.0);
-    e2vq_session_destroy(s);
-    return rc;
+    printf("total: %d predictor file(s), %lld vectors, M=%d, avg distortion=%g\n", num_predictors, (long long)total_T, M,
+           total_T ? total_e / (double)total_T : 0.0);
+    return 0;
 }
 
 extern "C" int ecoz2_vq_classify(const char* const* cb_filenames, int num_codebooks, const char* const* prd_filenames,
@@ -1419,37 +1523,64 @@ extern "C" int ecoz2_vq_classify(const char* const* cb_filenames, int num_codebo
         if (e2vq_cbook_read(cb_filenames[i], cbs[i].refl.data(), cbs[i].M)) return 1;
         if (cbs[i].P != cbs[0].P) return e2vq_set_error("%s: prediction order differs from the first codebook", cb_filenames[i]);
     }
-    const int P = cbs[0].P;
-    // load all predictor files once
+    const int P = cbs[0].P, NC = P + 1;
+    // all predictor files into ONE host array: uploaded once, swept once per codebook where it lies
     struct Prd {
         std::string cls;
         int64_t T;
-        std::vector<double> frames;
+        i64 off;
     };
     std::vector<Prd> prds((size_t)num_predictors);
+    std::vector<double> frames;
+    i64 total = 0;
     for (int k = 0; k < num_predictors; ++k) {
         char cls[96];
         int p;
         if (e2vq_prd_info(prd_filenames[k], cls, &p, &prds[k].T)) return 1;
         if (p != P) return e2vq_set_error("%s: prediction order %d differs from the codebooks' %d", prd_filenames[k], p, P);
         prds[k].cls = cls;
-        prds[k].frames.resize((size_t)prds[k].T * (P + 1));
-        if (e2vq_prd_read(prd_filenames[k], prds[k].frames.data(), prds[k].T)) return 1;
+        prds[k].off = total;
+        frames.resize((size_t)(total + prds[k].T) * NC);
+        if (prds[k].T > 0 && e2vq_prd_read(prd_filenames[k], frames.data() + (size_t)total * NC, prds[k].T)) return 1;
+        total += prds[k].T;
     }
+    if (!all_finite(frames.data(), frames.size())) return e2vq_set_error("predictor files contain NaN or infinite values");
     e2vq_session* s = nullptr;
     if (e2vq_session_create(env_int("ECOZ2_VQ_DEVICE", 0), P, &s)) return 1;
     std::vector<double> score((size_t)num_predictors * num_codebooks, 0.0);
     int rc = 0;
-    for (int i = 0; i < num_codebooks && !rc; ++i) {  // codebook-major: one codebook upload per class
+    double* d_frames = nullptr;
+    unsigned short* d_sym = nullptr;
+    double* d_dmin = nullptr;
+    std::vector<double> dmin((size_t)total);
+    if (total > 0) {
+        if (hipMalloc(&d_frames, (size_t)total * NC * 8) != hipSuccess || hipMalloc(&d_sym, (size_t)total * 2 + 64) != hipSuccess ||
+            hipMalloc(&d_dmin, (size_t)total * 8) != hipSuccess)
+            rc = e2vq_set_error("no device memory for %lld predictor vectors", (long long)total);
+        if (!rc && hipMemcpy(d_frames, frames.data(), (size_t)total * NC * 8, hipMemcpyHostToDevice) != hipSuccess)
+            rc = e2vq_set_error("upload of the predictor vectors failed");
+    }
+    for (int i = 0; i < num_codebooks && !rc && total > 0; ++i) {  // codebook-major: one codebook upload per class
         rc = e2vq_set_codebook(s, cbs[i].refl.data(), cbs[i].M);
+        const i64 CH = 1 << 24;
+        for (i64 t0 = 0; t0 < total && !rc; t0 += CH)
+            rc = e2vq_quantize_device(s, d_frames + (size_t)t0 * NC, std::min(CH, total - t0), d_sym + t0, d_dmin + t0);
+        if (!rc) rc = e2vq_synchronize(s);
+        if (!rc && hipMemcpy(dmin.data(), d_dmin, (size_t)total * 8, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = e2vq_set_error("download of the distortions failed");
         for (int k = 0; k < num_predictors && !rc; ++k) {
             if (prds[k].T < 1) continue;
-            rc = e2vq_avg_distortion_host(s, prds[k].frames.data(), prds[k].T, &score[(size_t)k * num_codebooks + i]);
+            double e = 0.0;  // average distortion: sum of (dmin - 1) in frame order, then / T (as e2vq_avg_distortion_host)
+            for (int64_t t = 0; t < prds[k].T; ++t) e += dmin[(size_t)(prds[k].off + t)] - 1.0;
+            score[(size_t)k * num_codebooks + i] = e / (double)prds[k].T;
         }
     }
+    if (d_frames) (void)hipFree(d_frames);
+    if (d_sym) (void)hipFree(d_sym);
+    if (d_dmin) (void)hipFree(d_dmin);
     e2vq_session_destroy(s);
     if (rc) return rc;
-    int correct = 0, total = 0;
+    int correct = 0, total_n = 0;
     std::vector<std::string> classes;
     std::vector<int> ok_by, n_by;
     for (int k = 0; k < num_predictors; ++k) {
@@ -1469,7 +1600,7 @@ extern "C" int ecoz2_vq_classify(const char* const* cb_filenames, int num_codebo
         }
         n_by[ci]++;
         ok_by[ci] += ok;
-        total++;
+        total_n++;
         correct += ok;
         if (!ok && show_ranked) {
             std::vector<int> order((size_t)num_codebooks);
@@ -1483,7 +1614,7 @@ extern "C" int ecoz2_vq_classify(const char* const* cb_filenames, int num_codebo
     printf("\n%-24s %8s %8s %8s\n", "class", "tests", "correct", "percent");
     for (size_t ci = 0; ci < classes.size(); ++ci)
         printf("%-24s %8d %8d %7.2f%%\n", classes[ci].c_str(), n_by[ci], ok_by[ci], 100.0 * ok_by[ci] / n_by[ci]);
-    printf("%-24s %8d %8d %7.2f%%\n", "TOTAL", total, correct, total ? 100.0 * correct / total : 0.0);
+    printf("%-24s %8d %8d %7.2f%%\n", "TOTAL", total_n, correct, total_n ? 100.0 * correct / total_n : 0.0);
     return 0;
 }
 

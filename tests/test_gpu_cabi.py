@@ -476,3 +476,46 @@ def test_in_process_group_reproduces_golden_codebooks(tmp_path, monkeypatch, ran
         name = f"eps_0.05_M_{g['M']:04d}.cbook"
         got = open(tmp_path / "data" / "codebooks" / "_" / name, "rb").read()
         assert got == open(os.path.join(GOLD, "config1_" + name), "rb").read()
+
+
+@pytest.mark.parametrize("workers", [1, 2, 5])
+def test_quantize_workers_give_identical_seq_files(tmp_path, monkeypatch, capfd, oracle, workers):
+    """ecoz2_vq_quantize with ECOZ2_VQ_GPUS=N (frames are independent -- files dealt to N workers, no
+    collective; the workers share the one GPU here): every .seq byte-identical to the oracle's symbols whatever N, totals
+    summed in file order.  Ragged files, an empty file, more workers than some ranks have files."""
+    M = 64
+    frames = e.synth.synth_frames(808, 4, P, 0, 30000)
+    refl = np.zeros((M, P + 1))
+    for i in range(M):
+        refl[i, 1:] = oracle.lpca_r(frames[i * 401], P)[2][1:]
+    cb = tmp_path / "data" / "codebooks" / "_" / "cb.cbook"
+    e.formats.write_cbook(str(cb), "_", refl)
+    cuts = [0, 1, 500, 500, 4097, 9000, 17000, 17064, 30000]  # (one empty file)
+    files = []
+    for i, (a, b) in enumerate(zip(cuts, cuts[1:])):
+        f = tmp_path / "data" / "predictors" / f"c{i % 3}" / f"{i:05d}.prd"
+        e.formats.write_prd(str(f), f"c{i % 3}", frames[a:b])
+        files.append(str(f))
+    monkeypatch.setenv("ECOZ2_VQ_OUT_ROOT", str(tmp_path))
+    monkeypatch.setenv("ECOZ2_VQ_GPUS", str(workers))
+    capfd.readouterr()
+    e.vq_quantize(str(cb), files, True)
+    out = capfd.readouterr().out
+    sym_o, dmin_o = oracle.quantize(oracle.reflections_to_cq(refl), frames)
+    total = 0.0
+    for i, (a, b) in enumerate(zip(cuts, cuts[1:])):
+        cls, m, sym = e.formats.read_seq(str(tmp_path / "data" / "sequences" / f"M{M}" / f"c{i % 3}" / f"{i:05d}.seq"))
+        assert (cls, m) == (f"c{i % 3}", M) and np.array_equal(sym, sym_o[a:b])
+        acc = 0.0
+        for d in dmin_o[a:b]:
+            acc += d - 1.0
+        total += acc
+        assert f"{files[i]}: 'c{i % 3}' T={b - a} avg distortion={(acc / (b - a) if b > a else 0.0):g} ->" in out
+    assert f"total: 8 predictor file(s), 30000 vectors, M={M}, avg distortion={total / 30000:g}" in out
+    # non-finite input is refused (the file entry points check it; the sweep's argmin assumes finite data)
+    bad = frames[:10].copy()
+    bad[3, 5] = np.nan
+    fb = tmp_path / "bad.prd"
+    e.formats.write_prd(str(fb), "x", bad)
+    with pytest.raises(e.Ecoz2Error, match="NaN or infinite"):
+        e.vq_quantize(str(cb), files[:2] + [str(fb)])
