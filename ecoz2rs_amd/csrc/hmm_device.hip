@@ -119,7 +119,22 @@ __device__ __forceinline__ void acc_add(i64* cell, double x)
 
 constexpr int FB_WAVES = 4;
 
-// E-step: one wave per sequence of ONE model.  alpha_buf: [total symbols][N] scratch, c_buf: [total symbols].
+__device__ __forceinline__ void acc_local(i64 (&cell)[2], double x)
+{
+    int hi, lo;
+    e2vq::fix2(x, ACC_SHIFT, hi, lo);
+    cell[0] += (i64)hi;
+    cell[1] += (i64)lo;
+}
+
+// E-step: one wave per sequence of ONE model; persistent workgroups stride over the sequences.
+// alpha_buf: [total symbols][N] scratch, c_buf: [total symbols].
+// Where the expected counts go (all of them exact integer limb sums, so the routes are interchangeable bit for bit):
+//   xi  -> AN : a workgroup-wide LDS table (ds_add_u64), flushed with N^2 global atomics per workgroup at the end --
+//               per-step global atomics on the N^2 hot words serialise at the memory side (measured: 40 ms per
+//               E-step for 600 k symbols at N = 5, all of it same-address contention)
+//   gamma -> AD, BD, PI : per-lane registers over the wave's sequences, one global atomic per lane at the end
+//   gamma -> BN[j][o_t] : global atomics (N x M words: spread out)
 __global__ __launch_bounds__(64 * FB_WAVES) void k_hmm_fb(ModelDev md, const unsigned short* __restrict__ sym,
                                                            const i64* __restrict__ offs, int S,
                                                            double* __restrict__ alpha_buf, double* __restrict__ c_buf,
@@ -128,97 +143,128 @@ __global__ __launch_bounds__(64 * FB_WAVES) void k_hmm_fb(ModelDev md, const uns
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int N = md.N, M = md.M;
-    double* As = (double*)smem;  // [i][j]
-    double* ATs = As + N * N;    // [j][i]
+    double* As = (double*)smem;       // [i][j]
+    double* ATs = As + N * N;         // [j][i]
+    i64* ANs = (i64*)(ATs + N * N);   // [i][j][hi, lo]
     for (int x = threadIdx.x; x < N * N; x += blockDim.x) {
         const double v = md.A[x];
         As[x] = v;
         ATs[(x % N) * N + (x / N)] = v;
+        ANs[2 * x] = 0;
+        ANs[2 * x + 1] = 0;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int s = blockIdx.x * FB_WAVES + wib;
-    if (s >= S) return;
     i64* PI = acc;
     i64* AN = PI + 2 * N;
     i64* AD = AN + 2 * (i64)N * N;
     i64* BN = AD + 2 * N;
     i64* BD = BN + 2 * (i64)N * M;
     i64* counts = BD + 2 * N;
-    const i64 base = offs[s];
-    const i64 T = offs[s + 1] - base;
     const bool act = lane < N;
     const int ln = act ? lane : 0;
     const double* Brow = md.B + (size_t)ln * M;
-    double* alpha = alpha_buf + (size_t)base * N;
-    double* cs = c_buf + base;
-    // ---- forward (as k_hmm_score), keeping alpha^_t and c_t ------------------------------------------------
-    double al = 0.0, p = 0.5;
-    i64 E = 1;
-    int st = T < 1 ? 1 : 0;
     const double pij = act ? md.pi[lane] : 0.0;
-    for (i64 t = 0; t < T && st == 0; ++t) {
-        const int o = (int)sym[base + t];  // wave-uniform (scalar load)
-        if (o >= M) {
-            st = 2;
-            break;
+    i64 ad[2] = {0, 0}, bd[2] = {0, 0}, pic[2] = {0, 0};
+    int used = 0, skipped = 0;
+    for (int s = blockIdx.x * FB_WAVES + wib; s < S; s += gridDim.x * FB_WAVES) {
+        const i64 base = offs[s];
+        const i64 T = offs[s + 1] - base;
+        double* alpha = alpha_buf + (size_t)base * N;
+        double* cs = c_buf + base;
+        // ---- forward (as k_hmm_score), keeping alpha^_t and c_t --------------------------------------------
+        double al = 0.0, p = 0.5;
+        i64 E = 1;
+        int st = T < 1 ? 1 : 0;
+        for (i64 t = 0; t < T && st == 0; ++t) {
+            const int o = (int)sym[base + t];  // wave-uniform (scalar load)
+            if (o >= M) {
+                st = 2;
+                break;
+            }
+            const double b = act ? Brow[o] : 0.0;
+            double nx;
+            if (t == 0) {
+                nx = pij * b;
+            } else {
+                double a = 0.0;
+                for (int i = 0; i < N; ++i) a = fma(bcast(al, i), As[i * N + ln], a);
+                nx = a * b;
+            }
+            if (!act) nx = 0.0;
+            double c = 0.0;
+            for (int j = 0; j < N; ++j) c = c + bcast(nx, j);
+            if (!(c > 0.0)) {
+                st = 1;
+                break;
+            }
+            al = nx / c;
+            if (act) alpha[(size_t)t * N + lane] = al;
+            if (lane == 0) cs[t] = c;
+            scale_step(c, p, E);
         }
-        const double b = act ? Brow[o] : 0.0;
-        double nx;
-        if (t == 0) {
-            nx = pij * b;
-        } else {
-            double a = 0.0;
-            for (int i = 0; i < N; ++i) a = fma(bcast(al, i), As[i * N + ln], a);
-            nx = a * b;
+        if (lane == 0) {
+            mant[s] = st == 0 ? p : (T < 1 ? 0.5 : 0.0);
+            exp2[s] = st == 0 ? E : (T < 1 ? 1 : 0);
+            status[s] = st;
         }
-        if (!act) nx = 0.0;
-        double c = 0.0;
-        for (int j = 0; j < N; ++j) c = c + bcast(nx, j);
-        if (!(c > 0.0)) {
-            st = 1;
-            break;
+        if (st != 0) {  // (wave-uniform) the sequence contributes nothing
+            ++skipped;
+            continue;
         }
-        al = nx / c;
-        if (act) alpha[(size_t)t * N + lane] = al;
-        if (lane == 0) cs[t] = c;
-        scale_step(c, p, E);
+        ++used;
+        // ---- backward + expected counts -----------------------------------------------------------------------
+        // `al` is alpha^_{T-1} already; every later alpha^_t was written by this very lane, so no fence is needed
+        double beta = 1.0;
+        for (i64 t = T - 1; t >= 0; --t) {
+            if (t < T - 1) {
+                al = act ? alpha[(size_t)t * N + lane] : 0.0;
+                const int o1 = (int)sym[base + t + 1];
+                // c_{t+1}: lane 0 re-reads its own store (same-thread order) and hands it to the wave
+                const double c1 = bcast(lane == 0 ? cs[t + 1] : 0.0, 0);
+                const double u = act ? (Brow[o1] * beta) / c1 : 0.0;  // u_j, j = lane
+                // xi_t(i, j) = (alpha^_t(i) * A_ij) * u_j   -- lane j, all i
+                for (int i = 0; i < N; ++i) {
+                    const double x = (bcast(al, i) * As[i * N + ln]) * u;
+                    if (act) {
+                        int hi, lo;
+                        e2vq::fix2(x, ACC_SHIFT, hi, lo);
+                        atomicAdd((u64*)&ANs[2 * (i * N + lane)], (u64)(i64)hi);
+                        atomicAdd((u64*)&ANs[2 * (i * N + lane) + 1], (u64)(i64)lo);
+                    }
+                }
+                // beta^_t(i) = chain_j fma(A_ij, u_j)        -- lane i, all j (transposed copy)
+                double a = 0.0;
+                for (int j = 0; j < N; ++j) a = fma(ATs[j * N + ln], bcast(u, j), a);
+                beta = a;
+            }
+            if (act) {
+                const double g = al * beta;
+                const int o = (int)sym[base + t];
+                if (t < T - 1) acc_local(ad, g);
+                acc_add(BN + 2 * ((i64)lane * M + o), g);
+                acc_local(bd, g);
+                if (t == 0) acc_local(pic, g);
+            }
+        }
+    }
+    // ---- flush: per-lane sums, the workgroup's AN table, the sequence counts ---------------------------------------
+    if (act) {
+        if (ad[0]) atomicAdd((u64*)&AD[2 * lane], (u64)ad[0]);
+        if (ad[1]) atomicAdd((u64*)&AD[2 * lane + 1], (u64)ad[1]);
+        if (bd[0]) atomicAdd((u64*)&BD[2 * lane], (u64)bd[0]);
+        if (bd[1]) atomicAdd((u64*)&BD[2 * lane + 1], (u64)bd[1]);
+        if (pic[0]) atomicAdd((u64*)&PI[2 * lane], (u64)pic[0]);
+        if (pic[1]) atomicAdd((u64*)&PI[2 * lane + 1], (u64)pic[1]);
     }
     if (lane == 0) {
-        mant[s] = st == 0 ? p : (T < 1 ? 0.5 : 0.0);
-        exp2[s] = st == 0 ? E : (T < 1 ? 1 : 0);
-        status[s] = st;
-        atomicAdd((u64*)&counts[st == 0 ? 0 : 1], 1ull);
+        if (used) atomicAdd((u64*)&counts[0], (u64)used);
+        if (skipped) atomicAdd((u64*)&counts[1], (u64)skipped);
     }
-    if (st != 0) return;  // (wave-uniform) the sequence contributes nothing
-    // ---- backward + expected counts ---------------------------------------------------------------------------
-    // `al` is alpha^_{T-1} already; every later alpha^_t was written by this very lane, so no fence is needed
-    double beta = 1.0;
-    for (i64 t = T - 1; t >= 0; --t) {
-        if (t < T - 1) {
-            al = act ? alpha[(size_t)t * N + lane] : 0.0;
-            const int o1 = (int)sym[base + t + 1];
-            // c_{t+1}: lane 0 re-reads its own store (same-thread order) and hands it to the wave
-            const double c1 = bcast(lane == 0 ? cs[t + 1] : 0.0, 0);
-            const double u = act ? (Brow[o1] * beta) / c1 : 0.0;  // u_j, j = lane
-            // xi_t(i, j) = (alpha^_t(i) * A_ij) * u_j   -- lane j, all i
-            for (int i = 0; i < N; ++i) {
-                const double x = (bcast(al, i) * As[i * N + ln]) * u;
-                if (act) acc_add(AN + 2 * ((i64)i * N + lane), x);
-            }
-            // beta^_t(i) = chain_j fma(A_ij, u_j)        -- lane i, all j (transposed copy)
-            double a = 0.0;
-            for (int j = 0; j < N; ++j) a = fma(ATs[j * N + ln], bcast(u, j), a);
-            beta = a;
-        }
-        if (act) {
-            const double g = al * beta;
-            const int o = (int)sym[base + t];
-            if (t < T - 1) acc_add(AD + 2 * lane, g);
-            acc_add(BN + 2 * ((i64)lane * M + o), g);
-            acc_add(BD + 2 * lane, g);
-            if (t == 0) acc_add(PI + 2 * lane, g);
-        }
+    __syncthreads();
+    for (int x = threadIdx.x; x < 2 * N * N; x += blockDim.x) {
+        const i64 v = ANs[x];
+        if (v != 0) atomicAdd((u64*)&AN[x], (u64)v);
     }
 }
 
@@ -282,10 +328,12 @@ void launch_fb(const ModelDev& md, const unsigned short* sym, const i64* offs, i
                i64* acc, double* mant, i64* exp2, int* status, hipStream_t st)
 {
     if (S < 1) return;
-    const size_t lds = (size_t)2 * md.N * md.N * 8;
-    (void)hipFuncSetAttribute((const void*)k_hmm_fb, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    hipLaunchKernelGGL(k_hmm_fb, dim3((unsigned)((S + FB_WAVES - 1) / FB_WAVES)), dim3(64 * FB_WAVES), lds, st, md, sym,
-                       offs, S, alpha_buf, c_buf, acc, mant, exp2, status);
+    const size_t lds = (size_t)md.N * md.N * (2 * 8 + 16);  // A, A^T, and the workgroup's AN limb table: 128 KB at N = 64
+    (void)hipFuncSetAttribute((const void*)k_hmm_fb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int blocks = (S + FB_WAVES - 1) / FB_WAVES;
+    const int grid = blocks < 2048 ? blocks : 2048;  // persistent: each workgroup flushes its AN table once
+    hipLaunchKernelGGL(k_hmm_fb, dim3((unsigned)grid), dim3(64 * FB_WAVES), lds, st, md, sym, offs, S, alpha_buf, c_buf, acc,
+                       mant, exp2, status);
 }
 
 void launch_reestimate(int N, int M, const i64* acc, double epsilon, double* pi, double* A, double* B, hipStream_t st)
