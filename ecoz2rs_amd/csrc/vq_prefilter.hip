@@ -505,6 +505,39 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
         E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
         E2VQ_PRE_PIN                                                                                              \
     }
+#ifdef E2VQ_PRE_ROLL
+        // A/B knob (off: 4-7 % SLOWER on MI355X as the compiler schedules it -- the 15 loads end up bunched late in the
+        // second job and the loop head still waits for vmcnt(0), with 17 more spilled registers).  Rolling operand
+        // prefetch: the second job of a tile is the last reader of A[s]; right behind its MFMA the register takes the
+        // same granule of the NEXT tile, so that no iteration starts on an s_waitcnt
+#define E2VQ_PRE_JOB_ROLL(ACC, BC, PREV, PTILE, PCB, TNEXT)                                                       \
+    {                                                                                                             \
+        const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
+        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
+        {                                                                                                         \
+            const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \
+            const bool first = s == PK::level_first(lv);                                                         \
+            ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
+            A[s] = cimg[(long)(TNEXT) * PK::TILE_E + s * 64 + lane];                                              \
+        }                                                                                                         \
+        E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
+        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
+        {                                                                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                    \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                    \
+            __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);                                        \
+        }                                                                                                         \
+    }
+        h8 A[PK::NSTEP];
+#pragma unroll
+        for (int s = 0; s < PK::NSTEP; ++s) A[s] = cimg[s * 64 + lane];
+        for (int t = 0; t < MT; ++t) {
+            const int tn = t + 1 < MT ? t + 1 : t;  // (last tile: a harmless reload of itself)
+            E2VQ_PRE_JOB(acc0, B[0], acc1, (t - 1) & 0xffff, 1)  // (t = 0: the "previous" accumulators hold 3e38)
+            E2VQ_PRE_JOB_ROLL(acc1, B[1], acc0, t, 0, tn)
+        }
+#undef E2VQ_PRE_JOB_ROLL
+#else
         for (int t = 0; t < MT; ++t) {
             h8 A[PK::NSTEP];
 #pragma unroll
@@ -512,6 +545,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             E2VQ_PRE_JOB(acc0, B[0], acc1, (t - 1) & 0xffff, 1)  // (t = 0: the "previous" accumulators hold 3e38)
             E2VQ_PRE_JOB(acc1, B[1], acc0, t, 0)
         }
+#endif
         E2VQ_PRE_EPILOGUE(acc1, MT - 1, 1)
 #undef E2VQ_PRE_JOB
 #undef E2VQ_PRE_PIN

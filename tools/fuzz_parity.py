@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle parity fuzz (bit-exact): random T, M, P, codebooks; one pass + update + quantize each.
-usage: tools/fuzz_parity.py [n_cases] [seed] [pre]
-`pre`: aim at the prefiltered sweep -- P = 36, M a multiple of 32 in 64..2048 (prefilter forced from M = 64), frames
+usage: tools/fuzz_parity.py [n_cases] [seed] [pre|hmm]
+`hmm`: the HMM kernels -- random N (1..64), M, model type, ragged / empty / impossible sequences: scores, E-step
+accumulator words and whole trainings against the oracle.
+`pre`: aim at the prefiltered sweep -- P from 12, 16, ..., 40 (mostly 36), M a multiple of 32 in 64..2048 (prefilter forced from M = 64), frames
 rescaled / zeroed / sign-flipped at random, duplicated and twinned codewords, three passes with updates in between
 (the second and third accumulate incrementally)."""
 import os, sys, time
@@ -18,6 +20,8 @@ def main():
     os.environ["ECOZ2_VQ_QUIET"] = "1"
     if len(sys.argv) > 3 and sys.argv[3] == "pre":
         return fuzz_prefilter(n, rng, oracle)
+    if len(sys.argv) > 3 and sys.argv[3] == "hmm":
+        return fuzz_hmm(n, rng)
     bad = 0
     t0 = time.time()
     for case in range(n):
@@ -62,8 +66,9 @@ def fuzz_prefilter(n, rng, oracle):
     os.environ["ECOZ2_VQ_PREFILTER"] = "1"
     os.environ["ECOZ2_VQ_PREFILTER_MIN_M"] = "64"
     os.environ["ECOZ2_VQ_PLAIN_FIRST"] = "0"
-    P, bad, fallback, frames_total, t0 = 36, 0, 0, 0, time.time()
+    bad, fallback, frames_total, t0 = 0, 0, 0, time.time()
     for case in range(n):
+        P = int(rng.choice([36, 36, 36, 12, 16, 20, 24, 28, 32, 40]))
         T = int(rng.choice([rng.integers(1, 300), rng.integers(300, 8000), rng.integers(8000, 30000)]))
         M = 32 * int(rng.choice([rng.integers(2, 9), rng.integers(9, 33), rng.integers(33, 65)]))
         frames = e.synth.synth_frames(int(rng.integers(1, 1 << 30)), int(rng.integers(1, 12)), P, int(rng.integers(0, 1000)), T)
@@ -107,11 +112,67 @@ def fuzz_prefilter(n, rng, oracle):
                     break
         if not ok:
             bad += 1
-            print(f"MISMATCH case {case}: kind={kind} T={T} M={M}: {what}", flush=True)
+            print(f"MISMATCH case {case}: kind={kind} P={P} T={T} M={M}: {what}", flush=True)
         if case % 25 == 24:
             print(f"{case + 1} cases, {bad} mismatches, {fallback}/{frames_total} frame-passes via the FP64 fallback, "
                   f"{time.time() - t0:.0f}s", flush=True)
     print(f"prefilter fuzz done: {n} cases x 3 passes, {bad} mismatches, {fallback}/{frames_total} frame-passes via the fallback")
+    sys.exit(1 if bad else 0)
+
+
+def fuzz_hmm(n, rng):
+    H = oracle_lib.load_hmm()
+    bad, t0, steps = 0, time.time(), 0
+    for case in range(n):
+        N = int(rng.choice([1, 2, 3, 5, 5, 8, 16, 17, 33, 64]))
+        M = int(rng.choice([2, 8, 64, 256, 1024]))
+        typ = int(rng.integers(0, 4))
+        seed = int(rng.integers(0, 1 << 30))
+        H.seed(seed)
+        assert e.hmm.set_random_seed(seed) == seed
+        pi, A, B = H.init(N, M, typ)
+        pg = e.hmm.init_model(N, M, typ)
+        ok = all(np.array_equal(a.view(np.uint64), b.view(np.uint64)) for a, b in zip((pi, A, B), pg))
+        kind = int(rng.integers(0, 4))
+        if kind == 1:  # some symbols no state can emit: impossible sequences, skipped by the E-step
+            B = B.copy()
+            B[:, rng.random(M) < 0.2] = 0.0
+            B[:, 0] += 1e-3
+            B /= B.sum(1, keepdims=True)
+        S = int(rng.integers(1, 40))
+        lens = rng.integers(0, int(rng.choice([8, 70, 400])), S)
+        if kind == 2:  # structured: symbols drift along the sequence
+            seqs = [np.clip((np.linspace(0, M - 1, max(int(L), 1)) + rng.normal(0, M / 6, max(int(L), 1))).round(), 0, M - 1).astype(np.uint16)[:int(L)] for L in lens]
+        else:
+            seqs = [rng.integers(0, M, int(L)).astype(np.uint16) for L in lens]
+        what = "init" if not ok else ""
+        if ok:
+            got = e.hmm.score([(pi, A, B)], seqs)
+            for s_i, sq in enumerate(seqs):
+                st, m, ex = H.forward(pi, A, B, sq)
+                if (got["status"][s_i, 0], got["mant"][s_i, 0], got["exp2"][s_i, 0]) != (st, m, ex):
+                    ok, what = False, f"score of sequence {s_i} (T={len(sq)})"
+                    break
+        if ok:
+            acc_o, res = H.accumulate(pi, A, B, seqs)
+            acc, mant, ex, st = e.hmm.estep(pi, A, B, seqs)
+            if not (np.array_equal(acc, acc_o) and st.tolist() == [r[0] for r in res]):
+                ok, what = False, "E-step accumulators"
+        if ok:
+            eps, auto, maxit = float(rng.choice([0.0, 1e-5, 1e-3])), float(rng.choice([0.0, 0.05, 0.3])), int(rng.choice([-1, 1, 4]))
+            if maxit < 0 and auto == 0.0:
+                maxit = 12
+            po, Ao, Bo, hist_o = H.learn(pi, A, B, seqs, eps, auto, maxit)
+            pg2, Ag, Bg, hist = e.hmm.train(pi, A, B, seqs, eps, auto, maxit)
+            if not (hist == hist_o and all(np.array_equal(a.view(np.uint64), b.view(np.uint64)) for a, b in zip((po, Ao, Bo), (pg2, Ag, Bg)))):
+                ok, what = False, f"training (eps={eps} auto={auto} I={maxit}; {len(hist)} vs {len(hist_o)} E-steps)"
+            steps += len(hist_o) * int(lens.sum())
+        if not ok:
+            bad += 1
+            print(f"MISMATCH case {case}: N={N} M={M} type={typ} kind={kind} S={S}: {what}", flush=True)
+        if case % 25 == 24:
+            print(f"{case + 1} cases, {bad} mismatches, {steps} training symbol-steps, {time.time() - t0:.0f}s", flush=True)
+    print(f"hmm fuzz done: {n} cases, {bad} mismatches")
     sys.exit(1 if bad else 0)
 
 

@@ -353,7 +353,11 @@ int main(int argc, char** argv)
     int bits = 0;
     while ((1 << bits) < M) ++bits;
     const int idxmask = ~((1 << bits) - 1);
+#ifdef LDS_KB  // occupancy knob: a workgroup that asks for > 80 KB is alone on its CU (WPB=4: one wave per SIMD)
+    const size_t lds = (size_t)LDS_KB * 1024;
+#else
     const size_t lds = (size_t)4 * 1024 * 16;
+#endif
     CK(hipFuncSetAttribute((const void*)k_pre_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = (int)((nblk32 / 2 + WPB - 1) / WPB);
     hipEvent_t e0, e1;
