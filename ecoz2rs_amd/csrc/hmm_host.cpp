@@ -373,6 +373,7 @@ struct Trainer {
 };
 
 typedef void (*hmm_learn_callback_t)(char* variable, double value);
+constexpr int MAX_ESTEPS = 1000;  // safety cap, same in the oracle (val_auto <= 0 with no iteration limit would never stop)
 
 // the training loop of oracle/hmm_oracle.h (e2h_learn): returns the number of E-steps through *n_esteps
 int train(Hmm& h, const SeqSet& ss, double epsilon, double val_auto, int max_iterations, hmm_learn_callback_t callback,
@@ -390,7 +391,7 @@ int train(Hmm& h, const SeqSet& ss, double epsilon, double val_auto, int max_ite
     double Lprev = 0.0;
     hist.clear();
     for (;;) {
-        if (max_iterations >= 0 && it >= max_iterations) break;
+        if ((max_iterations >= 0 && it >= max_iterations) || it >= MAX_ESTEPS) break;
         double L;
         i64 used, skipped;
         if (tr.estep(d_sym.p, d_offs.p, &L, &used, &skipped)) return 1;

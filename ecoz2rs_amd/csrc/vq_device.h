@@ -21,8 +21,6 @@ inline int cb_pad(int NC) { return (NC + 7) & ~7; }
 bool uses_mfma(int NC);            // P = 4 .. 40: the sweep runs on the FP64 matrix pipe
 int mfma_hybrid_cells(int NC);     // cells of the hybrid accumulate's LDS table
 inline long cbm_doubles(int NC, int M) { return (long)((M + 15) / 16) * (((((NC + 3) / 4) + 1) / 2) * 128 + 16); }
-int frames_per_lane(int NC);       // F of the kernel that will serve this NC (block = 64*F frames)
-bool has_register_kernel(int NC);
 
 bool launch_blockify(const double* aos, long T, int NC, int FB, double* blk, long nblocks,
                      unsigned long long* maxabs_bits, int* bad, hipStream_t s);

@@ -1026,14 +1026,6 @@ void launch_global_sums(const double* blk, long nblocks, int NC, int FB, const D
                        stats);
 }
 
-int frames_per_lane(int NC)
-{
-    (void)NC;
-    return 1;  // every kernel works on blocks of 64 frames
-}
-
-bool has_register_kernel(int NC) { return uses_mfma(NC); }
-
 template <int NC>
 static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, const double* cbm, int M,
                             const DevScalars* sc, const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows,

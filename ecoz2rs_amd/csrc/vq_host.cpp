@@ -68,7 +68,7 @@ extern "C" int e2vq_device_count(void)
 // session
 // ------------------------------------------------------------------------------------------
 struct e2vq_session {
-    int device = 0, P = 0, NC = 0, F = 1, FB = 64, RS = 0, NPAD = 0;
+    int device = 0, P = 0, NC = 0, FB = 64, RS = 0, NPAD = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // training set (blocked layout)
     double* d_blk = nullptr;
@@ -267,8 +267,7 @@ extern "C" int e2vq_session_create(int device, int prediction_order, e2vq_sessio
     s->device = device;
     s->P = prediction_order;
     s->NC = prediction_order + 1;
-    s->F = e2vq::frames_per_lane(s->NC);
-    s->FB = 64 * s->F;
+    s->FB = 64;  // every kernel works on blocks of 64 frames
     s->RS = e2vq::row_stride(s->NC);
     s->NPAD = e2vq::cb_pad(s->NC);
     if (session_init(s)) {  // message already set; release whatever was created

@@ -84,7 +84,21 @@ int resolve_filenames(const std::vector<std::string>& given, const char* file_ex
             out.push_back(g);
         }
     }
-    std::sort(out.begin(), out.end());
+    // `filenames.sort()` on Vec<PathBuf> (src/utl/mod.rs:216-218): paths compare component by component, not
+    // byte by byte ("a/b.prd" sorts before "a-b/c.prd" although '-' < '/')
+    std::sort(out.begin(), out.end(), [](const std::string& a, const std::string& b) {
+        size_t i = 0, j = 0;
+        for (;;) {
+            while (i < a.size() && a[i] == '/') ++i;  // (repeated separators do not make components)
+            while (j < b.size() && b[j] == '/') ++j;
+            if (i >= a.size() || j >= b.size()) return i >= a.size() && j < b.size();
+            const size_t ie = std::min(a.find('/', i), a.size()), je = std::min(b.find('/', j), b.size());
+            const int c = a.compare(i, ie - i, b, j, je - j);
+            if (c != 0) return c < 0;
+            i = ie;
+            j = je;
+        }
+    });
     return 0;
 }
 

@@ -215,7 +215,7 @@ int e2h_learn(int N, int M, const uint16_t *const *seqs, const int64_t *lens, in
     double Lprev = 0.0;
     static char var[] = "sum_log_prob";
     for (;;) {
-        if (max_iterations >= 0 && it >= max_iterations) break;
+        if ((max_iterations >= 0 && it >= max_iterations) || it >= E2H_MAX_ESTEPS) break;
         memset(acc, 0, (size_t)W * sizeof(int64_t));
         double L = 0.0;
         for (int r = 0; r < R; r++) {

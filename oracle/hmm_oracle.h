@@ -28,6 +28,7 @@ extern "C" {
 #endif
 
 #define E2H_MAX_N 64
+#define E2H_MAX_ESTEPS 1000 /* safety cap (val_auto <= 0 with no iteration limit would never stop) */
 #define E2H_ACC_SHIFT 29 /* accumulated quantities are < 2: x ~= (hi*2^31 + lo) * 2^-(29+31) */
 
 /* ---- generator (ecoz2_set_random_seed) ----------------------------------------------------- */
@@ -66,7 +67,7 @@ int e2h_accumulate(int N, int M, const double *pi, const double *A, const double
 void e2h_reestimate(int N, int M, const int64_t *acc, double epsilon, double *pi, double *A, double *B);
 
 typedef void (*e2h_learn_callback_t)(char *variable, double value);
-/* Whole training: it = 0; loop { if (max_iterations >= 0 && it >= max_iterations) stop; E-step over all sequences
+/* Whole training: it = 0; loop { if ((max_iterations >= 0 && it >= max_iterations) || it >= E2H_MAX_ESTEPS) stop; E-step over all sequences
  * (L_it = sequential sum of log P of the used sequences); callback("sum_log_prob", L_it);
  * if (it > 0 && L_it - L_{it-1} <= val_auto) stop (model of this E-step kept); M-step; it++ }.
  * sum_log_prob receives the L_it (capacity cap); returns the number of E-steps run, < 0 on error. */

@@ -161,6 +161,13 @@ def test_cli_seq_show_pickle(tmp_path):
     assert pickle.load(open(tmp_path / "a.pkl", "rb")) == want[:2]
     r = _cli("seq", "show", "--pickle", "x.pkl", "tt.csv", cwd=tmp_path)
     assert "--codebook-size and --tt required when --pickle given" in r.stdout
+    # directories are walked and the files sorted as Vec<PathBuf>::sort does (src/utl/mod.rs:216-218): component by
+    # component, so "d/a/x.seq" comes before "d/a-b/y.seq" although '-' < '/' as bytes
+    order = {"d/a/x.seq": [1], "d/a-b/y.seq": [2], "d/a/b/z.seq": [3], "d/a0.seq": [4]}
+    for name, sym in order.items():
+        e.formats.write_seq(str(tmp_path / name), "A", 2048, np.array(sym, dtype=np.uint16))
+    r = _cli("seq", "show", "--pickle", "o.pkl", "-M", "2048", "--tt", "TRAIN", "d", cwd=tmp_path)
+    assert pickle.load(open(tmp_path / "o.pkl", "rb")) == [[3], [1], [2], [4]]  # a/b/z < a/x < a-b/y < a0.seq
 
 
 def test_prd_cbook_header_field_order_is_resolved_by_payload_size(tmp_path):

@@ -519,3 +519,33 @@ def test_quantize_workers_give_identical_seq_files(tmp_path, monkeypatch, capfd,
     e.formats.write_prd(str(fb), "x", bad)
     with pytest.raises(e.Ecoz2Error, match="NaN or infinite"):
         e.vq_quantize(str(cb), files[:2] + [str(fb)])
+
+
+def test_restored_level_repeats_the_uninterrupted_ladder(oracle):
+    """bench.py times the real M = 1024 level by restoring the converged M = 512 codebook and its DD
+    (e2vq_set_codebook + e2vq_set_prev_distortion) and running the level again through e2vq_learn: the repetition must be
+    the level the uninterrupted ladder ran -- same passes, DD, statistics, codebook -- every time (here 128 -> 256)."""
+    frames = e.synth.synth_frames(909, 6, P, 0, 40000)
+    os.environ["ECOZ2_VQ_QUIET"] = "1"
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        levels = s.learn(0.05, 128)
+        cb128, dd128 = s.get_codebook(), levels[-1].DD
+        assert s.prev_distortion() == dd128
+        ref = s.learn(0.05, 256)[0]
+        cb256 = s.get_codebook()
+        for _ in range(3):
+            s.set_codebook(cb128)
+            s.set_prev_distortion(dd128)
+            again = s.learn(0.05, 256)[0]
+            assert again == ref and np.array_equal(s.get_codebook().view(np.uint64), cb256.view(np.uint64))
+        # without the DD the stopping rule sees another ratio on pass 1 (it may or may not change the pass count,
+        # but DDprv must be what was set)
+        s.set_codebook(cb128)
+        s.set_prev_distortion(1.0)
+        assert s.prev_distortion() == 1.0
+    rc, levels_o, _ = oracle.learn(frames, 0.05, 256)
+    assert (ref.passes, ref.DD) == (levels_o[-1]["passes"], levels_o[-1]["DD"])
+    assert np.array_equal(cb256.view(np.uint64), levels_o[-1]["reflections"].view(np.uint64))
