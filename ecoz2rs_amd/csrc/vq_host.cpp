@@ -1160,13 +1160,20 @@ static const char* env_str(const char* name, const char* dflt)
     return v && *v ? v : dflt;
 }
 
-// load every .prd (all must share P) into one host array, in the given order
-static int load_predictors(const char* const* files, int n, int P_expected, std::vector<double>& frames, i64* T_out,
-                           int* P_out)
+// the training set as a list of files: per file its vector count and the global index of its first vector
+struct PrdSet {
+    const char* const* files = nullptr;
+    int n = 0, P = 0;
+    std::vector<i64> first;  // n + 1 entries
+    i64 T = 0;
+};
+
+static int scan_predictors(const char* const* files, int n, int P_expected, PrdSet& ps)
 {
-    i64 total = 0;
+    ps.files = files;
+    ps.n = n;
+    ps.first.assign(1, 0);
     int P = P_expected;
-    std::vector<i64> Ts((size_t)n);
     for (int i = 0; i < n; ++i) {
         char cls[96];
         int p;
@@ -1174,31 +1181,74 @@ static int load_predictors(const char* const* files, int n, int P_expected, std:
         if (e2vq_prd_info(files[i], cls, &p, &t)) return 1;
         if (P < 0) P = p;
         if (p != P) return e2vq_set_error("%s: prediction order %d, expected %d", files[i], p, P);
-        Ts[(size_t)i] = t;
-        total += t;
+        ps.first.push_back(ps.first.back() + t);
     }
-    if (total < 1) return e2vq_set_error("no training vectors");
-    frames.resize((size_t)total * (P + 1));
-    i64 off = 0;
-    for (int i = 0; i < n; ++i) {
-        if (e2vq_prd_read(files[i], frames.data() + (size_t)off * (P + 1), Ts[(size_t)i])) return 1;
-        off += Ts[(size_t)i];
-    }
-    *T_out = total;
-    *P_out = P;
+    ps.T = ps.first.back();
+    ps.P = P;
+    if (ps.T < 1) return e2vq_set_error("no training vectors");
     return 0;
+}
+
+// Frames [lo, hi) of the set (file order = frame order) into the session: each rank reads only its own range, in
+// chunks through two pinned buffers, so that reading chunk k + 1 from the files overlaps the host-to-device copy of
+// chunk k; the row-major device copy is then re-laid out by e2vq_set_frames_device.
+static int upload_predictors(e2vq_session* s, const PrdSet& ps, i64 lo, i64 hi)
+{
+    const int NC = ps.P + 1;
+    const i64 T = hi - lo;
+    if (T < 1) return e2vq_set_error("empty training shard");
+    HIPCHK(hipSetDevice(s->device));
+    struct Res {
+        double* d = nullptr;
+        double* h[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        hipStream_t st = nullptr;
+        ~Res()
+        {
+            if (d) (void)hipFree(d);
+            for (int k = 0; k < 2; ++k) {
+                if (h[k]) (void)hipHostFree(h[k]);
+                if (ev[k]) (void)hipEventDestroy(ev[k]);
+            }
+            if (st) (void)hipStreamDestroy(st);
+        }
+    } r;
+    const i64 CH = std::min<i64>(T, 1 << 18);  // 78 MB of predictor vectors per chunk at P = 36
+    HIPCHK(hipMalloc(&r.d, (size_t)T * NC * 8));
+    HIPCHK(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(hipHostMalloc(&r.h[k], (size_t)CH * NC * 8, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&r.ev[k], hipEventDisableTiming));
+    }
+    int file = (int)(std::upper_bound(ps.first.begin(), ps.first.end(), lo) - ps.first.begin()) - 1;
+    int k = 0;
+    for (i64 t0 = lo; t0 < hi; t0 += CH, k ^= 1) {
+        const i64 n = std::min(CH, hi - t0);
+        HIPCHK(hipEventSynchronize(r.ev[k]));  // (never recorded: returns at once) the copy out of this buffer is done
+        for (i64 got = 0; got < n;) {          // a chunk may span several files
+            while (ps.first[(size_t)file + 1] <= t0 + got) ++file;
+            const i64 in_file = t0 + got - ps.first[(size_t)file];
+            const i64 take = std::min(n - got, ps.first[(size_t)file + 1] - (t0 + got));
+            if (e2vq_io::prd_read_range(ps.files[file], ps.P, in_file, take, r.h[k] + (size_t)got * NC)) return 1;
+            got += take;
+        }
+        HIPCHK(hipMemcpyAsync(r.d + (size_t)(t0 - lo) * NC, r.h[k], (size_t)n * NC * 8, hipMemcpyHostToDevice, r.st));
+        HIPCHK(hipEventRecord(r.ev[k], r.st));
+    }
+    HIPCHK(hipStreamSynchronize(r.st));
+    return e2vq_set_frames_device(s, r.d, T);  // (synchronises: the row-major copy can go)
 }
 
 // one rank of a learn: session on `device`, frames [lo, hi) of the training set.
 // Every failing path of a group rank marks the group failed, so the other ranks leave their barriers.
-static int learn_rank(int device, int P, double eps, const char* class_name, const double* base_refl, int base_M,
-                      const double* frames, i64 lo, i64 hi, LocalRank* lr, int world, void* target,
+static int learn_rank(int device, double eps, const char* class_name, const double* base_refl, int base_M,
+                      const PrdSet& ps, i64 lo, i64 hi, LocalRank* lr, int world, void* target,
                       ecoz2_vq_learn_callback_t cb)
 {
     e2vq_session* s = nullptr;
-    int rc = e2vq_session_create(device, P, &s);
+    int rc = e2vq_session_create(device, ps.P, &s);
     if (!rc && lr) rc = e2vq_set_allreduce(s, local_allreduce, lr, lr->rank, world);
-    if (!rc) rc = e2vq_set_frames_host(s, frames + (size_t)lo * (P + 1), hi - lo);
+    if (!rc) rc = upload_predictors(s, ps, lo, hi);
     if (!rc) rc = e2vq_prepare(s);
     if (!rc) rc = base_refl ? e2vq_set_codebook(s, base_refl, base_M) : e2vq_init_codebook(s);
     if (!rc)
@@ -1212,10 +1262,9 @@ static int learn_rank(int device, int P, double eps, const char* class_name, con
 static int learn_common(int P, double eps, const char* class_name, const double* base_refl, int base_M,
                         const char* const* files, int n, void* target, ecoz2_vq_learn_callback_t cb)
 {
-    std::vector<double> frames;
-    i64 T = 0;
-    int Pf = 0;
-    if (load_predictors(files, n, P, frames, &T, &Pf)) return 1;
+    PrdSet ps;
+    if (scan_predictors(files, n, P, ps)) return 1;
+    const i64 T = ps.T;
     printf("Codebook generation:\n\n%lld training vectors (ε=%g)\n", (long long)T, eps);
     const int ndev = e2vq_device_count();
     if (ndev < 1) return e2vq_set_error("no HIP device available; this library has no CPU path");
@@ -1223,7 +1272,7 @@ static int learn_common(int P, double eps, const char* class_name, const double*
     int world = env_int("ECOZ2_VQ_GPUS", 1);
     if (world < 1) world = 1;
     if ((i64)world > T) world = (int)T;  // every rank needs at least one training vector
-    if (world == 1) return learn_rank(dev0, P, eps, class_name, base_refl, base_M, frames.data(), 0, T, nullptr, 1, target, cb);
+    if (world == 1) return learn_rank(dev0, eps, class_name, base_refl, base_M, ps, 0, T, nullptr, 1, target, cb);
 
     // ---- in-process group: rank r on device (dev0 + r) % ndev, contiguous frame shards --------------------------
     printf("sharding over %d rank(s) on %d device(s)\n", world, ndev);
@@ -1275,15 +1324,14 @@ static int learn_common(int P, double eps, const char* class_name, const double*
         th.emplace_back([&, r]() {
             i64 lo, hi;
             shard(r, &lo, &hi);
-            rcs[r] = learn_rank(ranks[r].device, P, eps, class_name, base_refl, base_M, frames.data(), lo, hi, &ranks[r],
-                                world, nullptr, nullptr);
+            rcs[r] = learn_rank(ranks[r].device, eps, class_name, base_refl, base_M, ps, lo, hi, &ranks[r], world, nullptr,
+                                nullptr);
         });
     }
     {  // rank 0 runs on the calling thread: files, messages and the callback come from here
         i64 lo, hi;
         shard(0, &lo, &hi);
-        rcs[0] = learn_rank(ranks[0].device, P, eps, class_name, base_refl, base_M, frames.data(), lo, hi, &ranks[0], world,
-                            target, cb);
+        rcs[0] = learn_rank(ranks[0].device, eps, class_name, base_refl, base_M, ps, lo, hi, &ranks[0], world, target, cb);
     }
     for (auto& t : th) t.join();
     for (int rc : rcs)

@@ -235,6 +235,19 @@ extern "C" int e2vq_prd_read(const char* path, double* frames, int64_t capacity_
     return rc;
 }
 
+// frames [first, first + count) of a .prd whose header e2vq_prd_info has validated (payload at byte 120)
+int e2vq_io::prd_read_range(const char* path, int P, int64_t first, int64_t count, double* frames)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return e2vq_set_error("%s: %s", path, strerror(errno));
+    const size_t row = (size_t)(P + 1) * sizeof(double);
+    int rc = 0;
+    if (fseeko(f, (off_t)(120 + (unsigned long long)first * row), SEEK_SET) != 0) rc = e2vq_set_error("%s: seek failed", path);
+    if (!rc && fread(frames, row, (size_t)count, f) != (size_t)count) rc = e2vq_set_error("%s: truncated payload", path);
+    fclose(f);
+    return rc;
+}
+
 extern "C" int e2vq_prd_write(const char* path, const char* class_name, int P, const double* frames, int64_t T)
 {
     // the header carries the vector count as u32 (src/sequence/mod.rs:60 for .seq; .prd by analogy)

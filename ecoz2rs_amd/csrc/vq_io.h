@@ -1,5 +1,7 @@
 // vq_io.h -- file helpers shared by the host driver and the CLI (internal)
 #pragma once
+#include <stdint.h>
+
 #include <string>
 #include <vector>
 
@@ -15,4 +17,6 @@ int resolve_filenames(const std::vector<std::string>& given, const char* file_ex
 int files_from_csv(const std::string& csv, const std::string& tt, const std::string& class_name,
                    const std::string& subdir, const char* file_ext, const std::string* subdir_template,
                    std::vector<std::string>& out);
+// frames [first, first + count) of a .prd file whose header has been validated by e2vq_prd_info
+int prd_read_range(const char* path, int P, int64_t first, int64_t count, double* frames);
 }  // namespace e2vq_io
