@@ -159,6 +159,26 @@ def test_config2_sized_learn_pass_against_oracle(oracle):
     assert int(rows[:, 2 * (P + 1)].sum()) == T  # every frame counted exactly once
 
 
+def test_config2_full_ladder_cbook_bit_exact(oracle, tmp_path):
+    """configs[1] as BASELINE.json words it: vq learn on 1M frames, P = 36, up to M = 256 -- every level's pass count and
+    callback scalars, and the bytes of the final .cbook, equal the oracle's (whole ladder, ~30 s of CPU for the oracle)."""
+    T, M = 1_000_000, 256
+    frames = e.synth.synth_frames(20242, 20, P, 0, T)
+    rc, levels_o, cbs_o = oracle.learn(frames, 0.05, M, out_root=str(tmp_path / "o"))
+    assert rc == 0
+    cbs = []
+    os.environ["ECOZ2_VQ_QUIET"] = "1"
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        levels = s.learn(0.05, M, out_root=str(tmp_path / "g"), callback=lambda *a: cbs.append(a))
+    assert [(l.M, l.passes) for l in levels] == [(l["M"], l["passes"]) for l in levels_o] and cbs == cbs_o
+    for lv in levels_o:
+        name = os.path.join("data", "codebooks", "_", f"eps_0.05_M_{lv['M']:04d}.cbook")
+        assert open(tmp_path / "g" / name, "rb").read() == open(tmp_path / "o" / name, "rb").read()
+
+
 def test_config3_sized_quantize_properties(oracle):
     """configs[2] scale: 10M frames against M=1024.  Full oracle check on a 2M-frame slice; size-independent
     properties on all 10M: chunking invariance, dmin recomputed independently, every symbol < M."""
