@@ -79,8 +79,10 @@ int ecoz2_vq_classify(const char *const *cb_filenames, int num_codebooks,
 /* Knobs the reference has no argument for (environment):
  *   ECOZ2_VQ_MAX_CODEBOOK_SIZE  last codebook size trained (default 2048, notes.md:147)
  *   ECOZ2_VQ_DEVICE             HIP device ordinal (default 0)
- *   ECOZ2_VQ_GPUS               vq learn only: shard over this many in-process ranks / GPUs (default 1)
- *   ECOZ2_VQ_PREFILTER          0 = every pass on the FP64 sweep (default 1: prefiltered sweep for P = 36, M >= 256)
+ *   ECOZ2_VQ_GPUS               vq learn: shard the frames over this many in-process ranks / GPUs (default 1);
+ *                               vq quantize: deal the files to this many workers (no collective; same .seq files)
+ *   ECOZ2_VQ_PREFILTER          0 = every pass on the FP64 sweep (default 1: prefiltered sweep for P = 12, 16, ..., 40
+ *                               and 256 <= M <= 4096, M a multiple of 32)
  *   ECOZ2_VQ_PREFILTER_MIN_M    smallest codebook the prefiltered sweep serves (default 256, at least 64)
  *   ECOZ2_VQ_INCREMENTAL        0 = accumulate in full every pass; ECOZ2_VQ_PLAIN_FIRST 0 = no plain first pass
  *   ECOZ2_VQ_OUT_ROOT           prefix for data/... outputs (default ".")               */
