@@ -416,7 +416,14 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
     constexpr int HYB_CELLS = mfma_hyb_cells(NC);
     const int lds_cells = MODE == 5 ? HYB_CELLS : 0;
     i64* lacc = (i64*)smem;
-    int* img = (int*)(smem + (size_t)lds_cells * RS * 8) + wib * (16 * IMG);
+#ifdef E2VQ_PRE_DEFER
+    constexpr bool DEFER = MODE == 2 && DeferLayout<NC>::OK;  // deferred accumulate: the wave stages all 64 row images
+#else
+    constexpr bool DEFER = false;
+#endif
+    int* img = DEFER ? (int*)smem + wib * (DeferLayout<NC>::BYTES_PER_WAVE / 4)
+                     : (int*)(smem + (size_t)lds_cells * RS * 8) + wib * (16 * IMG);
+    bool pending = false;  // DEFER: the previous block's images wait in LDS for their atomics
     if constexpr (MODE == 5) {
         for (int i = threadIdx.x; i < lds_cells * RS; i += TPBM) lacc[i] = 0;
         __syncthreads();
@@ -539,6 +546,13 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 #undef E2VQ_PRE_JOB_ROLL
 #else
         for (int t = 0; t < MT; ++t) {
+            if constexpr (DEFER) {
+                // the 16 four-frame groups of the previous block, spread over this block's tiles
+                if (pending) {
+                    const int g0 = (16 * t) / MT, g1 = (16 * (t + 1)) / MT;
+                    for (int g = g0; g < g1; ++g) accum_drain_group<NC, true>(img, rows, g, incr != 0, lane);
+                }
+            }
             h8 A[PK::NSTEP];
 #pragma unroll
             for (int s = 0; s < PK::NSTEP; ++s) A[s] = cimg[(long)t * PK::TILE_E + s * 64 + lane];
@@ -650,7 +664,14 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
                 }
             }
         }
-        if constexpr (MODE != 0) {
+        if constexpr (DEFER) {
+            // (every group of the previous block went out during this block's tile loop: the LDS rows are free)
+            accum_stage_block<NC, true>(Bf, best, idx, img, sh_r, sh_d, sh_d2, b, T, lane, skip, incr != 0, oldidx);
+            pending = true;
+            const int is = q == 0 ? idx[0] : q == 1 ? idx[1] : q == 2 ? idx[2] : idx[3];
+            const bool sk = q == 0 ? skip[0] : q == 1 ? skip[1] : q == 2 ? skip[2] : skip[3];
+            if (prev_sym && b * 64 + lane < T && !sk) prev_sym[b * 64 + lane] = (unsigned short)is;
+        } else if constexpr (MODE != 0) {
             // (MODE 2 has no LDS table, lds_cells = 0; a null table pointer crashes the ROCm 7.2 optimizer: the LDS base)
             accumulate_block<NC, MODE, true, 4, MODE == 2>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2, b, T,
                                                            lane, skip, incr != 0, oldidx);
@@ -659,6 +680,10 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             const bool sk = q == 0 ? skip[0] : q == 1 ? skip[1] : q == 2 ? skip[2] : skip[3];
             if (prev_sym && b * 64 + lane < T && !sk) prev_sym[b * 64 + lane] = (unsigned short)is;
         }
+    }
+    if constexpr (DEFER) {  // the last block's images
+        if (pending)
+            for (int g = 0; g < 16; ++g) accum_drain_group<NC, true>(img, rows, g, incr != 0, lane);
     }
     if constexpr (MODE == 5) {
         __syncthreads();
@@ -798,7 +823,12 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
     } else if (accumulate) {
         (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 2, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
-        hipLaunchKernelGGL((k_pass_pre<NC, 2, TPBM>), dim3(grid), dim3(TPBM), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
+#ifdef E2VQ_PRE_DEFER
+        const size_t lds2 = DeferLayout<NC>::OK ? (size_t)(TPBM / 64) * DeferLayout<NC>::BYTES_PER_WAVE : lds;  // 160 KB at NC = 37
+#else
+        const size_t lds2 = lds;
+#endif
+        hipLaunchKernelGGL((k_pass_pre<NC, 2, TPBM>), dim3(grid), dim3(TPBM), lds2, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
                            dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0);
     } else {
