@@ -41,6 +41,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace e2vq {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -87,6 +89,20 @@ struct PrePack {
         }
     }
 };
+
+// calls fn(integral_constant<p>) for p = 2 it + half, it = 0, 1, ... (p < PAIRS): the pair index is a compile-time
+// constant inside fn although it depends on the runtime bit `half`
+template <int PAIRS, int IT = 0, typename Fn>
+__device__ __forceinline__ void pre_for_pairs(int half, Fn& fn)
+{
+    if constexpr (2 * IT < PAIRS) {
+        if (half == 0)
+            fn(std::integral_constant<int, 2 * IT>{});
+        else if constexpr (2 * IT + 1 < PAIRS)
+            fn(std::integral_constant<int, 2 * IT + 1>{});
+        pre_for_pairs<PAIRS, IT + 1>(half, fn);
+    }
+}
 
 // x in [-1, 1] -> the three integer limbs
 __device__ __forceinline__ void pre_split(double x, int (&L)[3])
@@ -202,78 +218,93 @@ __global__ void k_pre_ea_from_codebook(const double* __restrict__ cbq, int M, in
 }
 
 // row-major frames [t][NC] -> (a) the blocked FP64 MFMA layout of k_blockify_mfma, (b) the f16 limb image,
-// (c) the tolerance terms, one 64-frame block per workgroup, every global access coalesced through LDS
+// (c) the tolerance terms, one 64-frame block per workgroup, every global access coalesced through LDS.
+// Thread = (frame f = tid & 63, coefficient group tid >> 6): the four waves split the coefficients of every frame for
+// the exponent and limb passes, and all index arithmetic of the two output layouts is resolved at compile time per
+// k-step / granule pair (round 2: 0.57 -> 0.3 ms per 2^21 frames; the kernel was bound by its instruction count).
 template <int NC>
 __global__ __launch_bounds__(256) void k_pre_quant_prep(const double* __restrict__ aos, long T, long nblocks,
                                                         const int* __restrict__ ea, double* __restrict__ blk,
                                                         h8* __restrict__ fimg, float* __restrict__ fg)
 {
-    constexpr int NS = (NC + 3) / 4;
+    constexpr int NS = (NC + 3) / 4, REM = NC - 4 * (NS - 1);
     typedef PrePack<NC> PK;
     __shared__ double stage[64 * NC];
     __shared__ short X[3][64][PK::NCX];
     __shared__ int eAs[64];
+    __shared__ double gp[4][64];
     __shared__ int eas[NC];
-    for (int n = threadIdx.x; n < NC; n += 256) eas[n] = ea[n];
+    const int tid = threadIdx.x, f = tid & 63, grp = tid >> 6;
+    for (int n = tid; n < NC; n += 256) eas[n] = ea[n];
     for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
-        __syncthreads();
+        __syncthreads();  // the previous block's readers of stage / X / eAs are done
         const long base = b * 64 * NC, total = T * NC;
-        for (int i = threadIdx.x; i < 64 * NC; i += 256) stage[i] = base + i < total ? aos[base + i] : 0.0;
+        for (int i = tid; i < 64 * NC; i += 256) stage[i] = base + i < total ? aos[base + i] : 0.0;
+        if (tid < 64) eAs[tid] = -100000;
         __syncthreads();
-        // (a) blocked FP64 layout: element o of the block holds r[t][n] as k_blockify_mfma lays it out
-        for (int o = threadIdx.x; o < 64 * NC; o += 256) {
-            const int u = o / (NC * 32), x = o - u * (NC * 32);
-            int n, h, j;
-            if (x < (NS - 1) * 128) {
-                const int y = x & 127, l = y >> 1;
-                h = y & 1;
-                j = l & 15;
-                n = 4 * (x >> 7) + (l >> 4);
-            } else {
-                const int y = x - (NS - 1) * 128, z = y >> 1;
-                h = y & 1;
-                j = z & 15;
-                n = 4 * (NS - 1) + (z >> 4);
+        // (a) blocked FP64 layout (k_blockify_mfma): per 32-frame half u and k-step st, 64 lanes x 2 doubles with
+        //     value r[u*32 + 16 h + j][4 st + q], lane = 16 q + j.  Threads 0..127 serve u = 0, the others u = 1.
+        {
+            const int u = tid >> 7, y = tid & 127, l = y >> 1, h = y & 1, j = l & 15, q = l >> 4;
+            const double* src = stage + (u * 32 + h * 16 + j) * NC;
+            double* dst = blk + base + u * (NC * 32) + y;
+#pragma unroll
+            for (int st = 0; st < NS - 1; ++st) dst[st * 128] = src[4 * st + q];
+            if (y < REM * 32) {  // last k-step: REM coefficients, [q < REM][j][h]
+                const int z = y >> 1, jj = z & 15, qq = z >> 4;
+                blk[base + u * (NC * 32) + (NS - 1) * 128 + y] = stage[(u * 32 + (y & 1) * 16 + jj) * NC + 4 * (NS - 1) + qq];
             }
-            blk[base + o] = stage[(u * 32 + h * 16 + j) * NC + n];
         }
-        // frame scales and tolerance terms: one thread per frame (row stride NC is odd: conflict-free)
-        if (threadIdx.x < 64) {
-            const double* row = stage + threadIdx.x * NC;
+        // frame scale A_t = 2^eA: max over the coefficients, each wave its share, combined by an LDS integer max
+        {
             int eA = -100000;
-            for (int n = 0; n < NC; ++n)
-                if (row[n] != 0.0) {
-                    const int e = ilogb(row[n]) - eas[n] + 1;
+            for (int n = grp; n < NC; n += 4) {
+                const double x = stage[f * NC + n];
+                if (x != 0.0) {
+                    const int e = ilogb(x) - eas[n] + 1;
                     eA = e > eA ? e : eA;
                 }
-            if (eA == -100000) eA = 0;
-            eAs[threadIdx.x] = eA;
-            double g = 0.0;
-            for (int n = 0; n < NC; ++n) g += fabs(ldexp(row[n], -eas[n] - eA));
-            const long t = b * 64 + threadIdx.x;
-            if (t < T) fg[t] = (float)g * 1.000001f;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < 64 * PK::NCX; i += 256) {
-            const int f = i / PK::NCX, n = i - f * PK::NCX;
-            int L[3] = {0, 0, 0};
-            if (n < NC) pre_split(ldexp(stage[f * NC + n], -eas[n] - eAs[f]), L);
-            X[0][f][n] = (short)L[0];
-            X[1][f][n] = (short)L[1];
-            X[2][f][n] = (short)L[2];
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < 2 * PK::PAIRS * 64; i += 256) {
-            const int cb = i / (PK::PAIRS * 64), r = i - cb * (PK::PAIRS * 64), p = r >> 6, l = r & 63;
-            const int hh = l >> 5, f = 32 * cb + (l & 31);
-            h8 out;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                int fl, n;
-                PK::slot(p, hh, e, fl, n);
-                out[e] = n >= 0 ? (_Float16)(int)X[fl][f][n] : (_Float16)0;
             }
-            fimg[((b * 2 + cb) * PK::PAIRS + p) * 64 + l] = out;
+            if (eA != -100000) atomicMax(&eAs[f], eA);
+        }
+        __syncthreads();
+        {
+            int eA = eAs[f];
+            if (eA == -100000) eA = 0;
+            double g = 0.0;
+            for (int n = grp; n < PK::NCX; n += 4) {
+                int L[3] = {0, 0, 0};
+                if (n < NC) {
+                    const double xi = ldexp(stage[f * NC + n], -eas[n] - eA);
+                    g += fabs(xi);
+                    pre_split(xi, L);
+                }
+                X[0][f][n] = (short)L[0];
+                X[1][f][n] = (short)L[1];
+                X[2][f][n] = (short)L[2];
+            }
+            gp[grp][f] = g;
+        }
+        __syncthreads();
+        if (tid < 64) {  // tolerance term: sum |xi| (any order: it is rounded up)
+            const long t = b * 64 + tid;
+            if (t < T) fg[t] = (float)(((gp[0][tid] + gp[1][tid]) + gp[2][tid]) + gp[3][tid]) * 1.000001f;
+        }
+        // (b) limb image: granule (pair p, lane l = 32 h + col) of column block cb; two pairs per step, p compile-time
+        {
+            const int half = tid >> 7, cb = (tid >> 6) & 1, l = tid & 63, hh = l >> 5, fr = 32 * cb + (l & 31);
+            auto emit = [&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                h8 out;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    int fl, n;
+                    PK::slot(p, hh, e, fl, n);
+                    out[e] = n >= 0 ? (_Float16)(int)X[fl][fr][n] : (_Float16)0;
+                }
+                fimg[((b * 2 + cb) * PK::PAIRS + p) * 64 + l] = out;
+            };
+            pre_for_pairs<PK::PAIRS>(half, emit);
         }
     }
 }
