@@ -52,11 +52,11 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                             const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                             long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
-                            hipStream_t s);
+                            hipStream_t s, const double* rowmajor_frames = nullptr);
 int launch_pass_fallback(int NC, bool accumulate, const double* blk, const double* cbm, int M, const DevScalars* sc,
                          const unsigned long long* l1max_bits, unsigned short* sym, double* dmin, long long* rows,
                          const int* fb_list, const int* fb_count, unsigned short* prev_sym, bool incremental,
-                         hipStream_t s);
+                         hipStream_t s, bool rowmajor = false);
 void launch_zero_distortion_columns(long long* rows, int M, int NC, hipStream_t s);
 void launch_rows_stats(const long long* rows, int M, int NC, const DevScalars* sc, double* S, double* within,
                        long long* lstats, hipStream_t s);

@@ -205,7 +205,8 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                                                        i64* __restrict__ rows, int stagger,
                                                        const int* __restrict__ fb_list = nullptr,
                                                        const int* __restrict__ fb_count = nullptr,
-                                                       unsigned short* __restrict__ prev_sym = nullptr, int incr = 0)
+                                                       unsigned short* __restrict__ prev_sym = nullptr, int incr = 0,
+                                                       int list_rowmajor = 0)
 {
     constexpr bool AOS = SRC == 1;
     // frame tiles (of 16) per wave: the fallback list is short, so its waves take one tile each -- four times as
@@ -327,7 +328,8 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
 #pragma unroll
                 for (int st = 0; st < NS; ++st) {
                     const int n = st < NS - 1 ? 4 * st + q : (TAILV ? NC - 1 : (q < REM ? 4 * (NS - 1) + q : -1));
-                    Bf[ft][st] = (t >= 0 && n >= 0) ? blk[mfma_blk_offset(NC, t, n)] : 0.0;
+                    // (list_rowmajor: the listed frames are rows of the row-major .prd payload -- quantize)
+                    Bf[ft][st] = (t >= 0 && n >= 0) ? blk[list_rowmajor ? t * NC + n : mfma_blk_offset(NC, t, n)] : 0.0;
                 }
             }
         } else {
@@ -1102,7 +1104,7 @@ int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const
 // full FP64 sweep of the frames a prefiltered pass could not certify (vq_prefilter.hip): fb_list[0 .. *fb_count)
 int launch_pass_fallback(int NC, bool accumulate, const double* blk, const double* cbm, int M, const DevScalars* sc,
                          const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows, const int* fb_list,
-                         const int* fb_count, unsigned short* prev_sym, bool incremental, hipStream_t s)
+                         const int* fb_count, unsigned short* prev_sym, bool incremental, hipStream_t s, bool rowmajor)
 {
     const int MT = (M + 15) / 16;
     switch (NC) {
@@ -1112,10 +1114,12 @@ int launch_pass_fallback(int NC, bool accumulate, const double* blk, const doubl
         const size_t lds = (size_t)4 * 16 * (2 * N + 5 + IMG_STRIDE_PAD) * 4 + (size_t)2 * 4 * 64 * (8 + 4);          \
         if (accumulate)                                                                                                \
             hipLaunchKernelGGL((k_pass_mfma<N, 2, 256, 2>), dim3(1024), dim3(256), lds, s, blk, 0L, 0L, cbm, MT, M, sc, \
-                               l1max_bits, sym, dmin, rows, 0, fb_list, fb_count, prev_sym, incremental ? 1 : 0);     \
+                               l1max_bits, sym, dmin, rows, 0, fb_list, fb_count, prev_sym, incremental ? 1 : 0,      \
+                               rowmajor ? 1 : 0);                                                                      \
         else                                                                                                           \
             hipLaunchKernelGGL((k_pass_mfma<N, 0, 256, 2>), dim3(1024), dim3(256), lds, s, blk, 0L, 0L, cbm, MT, M, sc, \
-                               l1max_bits, sym, dmin, rows, 0, fb_list, fb_count);                                     \
+                               l1max_bits, sym, dmin, rows, 0, fb_list, fb_count, (unsigned short*)nullptr, 0,          \
+                               rowmajor ? 1 : 0);                                                                      \
         return 0;                                                                                                      \
     }
         E2VQ_PRE_NC_LIST(X)

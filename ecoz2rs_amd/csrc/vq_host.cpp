@@ -976,9 +976,9 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
     HIPCHK(hipSetDevice(s->device));
     const i64 nb = (T + s->FB - 1) / s->FB;
     if (s->pre_enabled && s->M >= s->pre_min_M && e2vq::prefilter_supports(s->NC, s->M)) {
-        // prefiltered sweep: one re-layout pass builds the blocked FP64 frames and their f16 limb image, then the
-        // assignment-only prefiltered kernel and the FP64 sweep of what it could not certify
-        if (ensure_qblk(s, T)) return 1;
+        // prefiltered sweep: one pass over the row-major payload builds the f16 limb image and the tolerance terms; the
+        // assignment-only prefiltered kernel and the FP64 sweep of what it could not certify then take the FP64 frames
+        // straight from the payload (no blocked copy: 592 B per frame less traffic)
         if (s->qpre_cap < nb) {
             for (void* p : {(void*)s->d_qfimg, (void*)s->d_qfg, (void*)s->d_qfblist})
                 if (p) HIPCHK(hipFree(p));
@@ -997,15 +997,16 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
             s->qcimg_cap = std::max(s->M, 2048);
             HIPCHK(hipMalloc(&s->d_qcimg, e2vq::prefilter_codebook_image_bytes(s->NC, s->qcimg_cap)));
         }
-        e2vq::launch_prefilter_quantize_prep((const double*)device_frames, T, nb, s->NC, s->d_cbq, s->M, s->d_ea_q,
-                                             s->d_qblk, s->d_qfimg, s->d_qfg, s->stream);
+        const double* aos = (const double*)device_frames;
+        e2vq::launch_prefilter_quantize_prep(aos, T, nb, s->NC, s->d_cbq, s->M, s->d_ea_q, nullptr, s->d_qfimg, s->d_qfg,
+                                             s->stream);
         e2vq::launch_prefilter_codebook(s->d_cbq, s->M, s->NC, s->d_ea_q, s->d_ps, s->d_qcimg, s->stream);
-        e2vq::launch_pass_prefiltered(s->NC, false, s->d_qblk, T, nb, s->d_qfimg, s->d_qfg, s->d_qcimg, s->d_ps, s->d_cbq,
+        e2vq::launch_pass_prefiltered(s->NC, false, nullptr, T, nb, s->d_qfimg, s->d_qfg, s->d_qcimg, s->d_ps, s->d_cbq,
                                       s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym, (double*)device_dmin, nullptr,
-                                      s->d_qfblist, nullptr, false, false, s->stream);
-        e2vq::launch_pass_fallback(s->NC, false, s->d_qblk, s->d_cbm, s->M, s->d_sc, s->d_l1max,
-                                   (unsigned short*)device_sym, (double*)device_dmin, nullptr, s->d_qfblist,
-                                   e2vq::prefilter_fallback_count(s->d_ps), nullptr, false, s->stream);
+                                      s->d_qfblist, nullptr, false, false, s->stream, aos);
+        e2vq::launch_pass_fallback(s->NC, false, aos, s->d_cbm, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
+                                   (double*)device_dmin, nullptr, s->d_qfblist, e2vq::prefilter_fallback_count(s->d_ps),
+                                   nullptr, false, s->stream, /*rowmajor=*/true);
         HIPCHK(hipGetLastError());
         return 0;
     }

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_pre_quant_prep(const double* __restrict
         __syncthreads();
         // (a) blocked FP64 layout (k_blockify_mfma): per 32-frame half u and k-step st, 64 lanes x 2 doubles with
         //     value r[u*32 + 16 h + j][4 st + q], lane = 16 q + j.  Threads 0..127 serve u = 0, the others u = 1.
-        {
+        if (blk) {  // (nullptr: the sweep reads the FP64 frames from the row-major payload itself)
             const int u = tid >> 7, y = tid & 127, l = y >> 1, h = y & 1, j = l & 15, q = l >> 4;
             const double* src = stage + (u * 32 + h * 16 + j) * NC;
             double* dst = blk + base + u * (NC * 32) + y;
@@ -431,7 +431,8 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
                                                   const DevScalars* __restrict__ sc, const u64* __restrict__ l1max_bits,
                                                   unsigned short* __restrict__ sym, double* __restrict__ dmin,
                                                   i64* __restrict__ rows, int* __restrict__ fb_list, int stagger,
-                                                  unsigned short* __restrict__ prev_sym, int incr)
+                                                  unsigned short* __restrict__ prev_sym, int incr,
+                                                  const double* __restrict__ aos)
 {
     typedef PrePack<NC> PK;
     constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2;
@@ -630,7 +631,10 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 
         // ---- FP64 frames (MFMA operand layout of k_pass_mfma), exact evaluation of the two candidates -----------
         double Bf[4][2 * NP];
-        load_block_frames<NC>(blk, b, lane, Bf);
+        if (MODE == 0 && aos)  // quantize: the FP64 frames come straight from the row-major payload
+            load_block_frames_rowmajor<NC>(aos, b, T, lane, Bf);
+        else
+            load_block_frames<NC>(blk, b, lane, Bf);
         double best[4];
         int idx[4];
         bool skip[4];
@@ -834,7 +838,7 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                                      const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                                      const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym,
                                      double* dmin, long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental,
-                                     bool hybrid_table, hipStream_t s)
+                                     bool hybrid_table, hipStream_t s, const double* aos)
 {
     constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
     constexpr int TPBM = 512;  // 8 waves = 2 per SIMD, one persistent workgroup per CU
@@ -850,7 +854,7 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                                   E2VQ_LDS_BYTES);
         hipLaunchKernelGGL((k_pass_pre<NC, 5, TPBM>), dim3(grid), dim3(TPBM), lds5, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
-                           dmin, rows, fb_list, stagger, prev_sym, 0);
+                           dmin, rows, fb_list, stagger, prev_sym, 0, (const double*)nullptr);
     } else if (accumulate) {
         (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 2, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
@@ -861,13 +865,13 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
 #endif
         hipLaunchKernelGGL((k_pass_pre<NC, 2, TPBM>), dim3(grid), dim3(TPBM), lds2, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
-                           dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0);
+                           dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0, (const double*)nullptr);
     } else {
         (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 0, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
         hipLaunchKernelGGL((k_pass_pre<NC, 0, TPBM>), dim3(grid), dim3(TPBM), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
-                           dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0);
+                           dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0, aos);
     }
     return 0;
 }
@@ -876,14 +880,14 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                             const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                             long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
-                            hipStream_t s)
+                            hipStream_t s, const double* rowmajor_frames)
 {
     if (!prefilter_supports(NC, M) || (hybrid_table && incremental)) return 1;
     switch (NC) {
 #define X(N)                                                                                                          \
     case N:                                                                                                           \
         return launch_pass_prefiltered_t<N>(accumulate, blk, T, nblocks, fimg, fg, cimg, ps, cbq, M, sc, l1max_bits, sym, \
-                                            dmin, rows, fb_list, prev_sym, incremental, hybrid_table, s);
+                                            dmin, rows, fb_list, prev_sym, incremental, hybrid_table, s, rowmajor_frames);
         E2VQ_PRE_NC_LIST(X)
 #undef X
         default: return 1;
