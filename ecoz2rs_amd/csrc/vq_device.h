@@ -5,6 +5,7 @@
 
 #define E2VQ_MAX_P 200          // CHANGELOG.md:183 of the reference: "increased maximum prediction order (200)"
 #define E2VQ_LDS_BYTES 163840   // 160 KiB per CU on gfx950
+#define E2VQ_PRE_EBIAS (1 << 20)  // bias of the codebook-scale exponent kept in the prefilter's scalars (0 = empty)
 
 namespace e2vq {
 
@@ -46,8 +47,12 @@ void launch_prefilter_frames(const double* blk, long T, long nblocks64, int NC, 
 // quantize: scales from the codebook; row-major frames -> blocked FP64 layout + limb image + tolerance terms
 void launch_prefilter_quantize_prep(const double* aos, long T, long nblocks64, int NC, const double* cbq, int M, int* ea,
                                     double* blk, void* fimg, float* fg, hipStream_t s);
-void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, void* ps, void* cimg, hipStream_t s);
+// scale_ready: the scalars were zeroed before and *prefilter_codebook_scale(ps) already holds the scale of this
+// codebook (k_cell_update computed it): only the image kernel runs
+void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, void* ps, void* cimg, hipStream_t s,
+                               bool scale_ready = false);
 const int* prefilter_fallback_count(const void* ps);
+int* prefilter_codebook_scale(void* ps);
 int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, long nblocks, const void* fimg,
                             const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
@@ -75,9 +80,37 @@ void launch_publish_stats(long long* lstats, const unsigned long long* l1max_bit
                           long long* h_l, unsigned long long* h_l1, double* h_within, unsigned long long* h_seq,
                           unsigned long long seq, hipStream_t s);
 bool has_cell_update(int NC);
+// What k_cell_update publishes when `flags` is set (two words per cell: [0, M) "statistics out", [M, 2 M) "recursion
+// done"; a cell's wave stores the low 32 bits of `seq` there, so nothing has to be reset; every pointer
+// device-visible, the h_* ones host-mapped).  One extra workgroup, the last of the grid, does the publishing: it polls
+// the first set of flags -- every cell raises its flag when its statistics are out, before the Levinson recursion,
+// and carries on --, copies the level statistics (64 slots of 8 words, zeroed again afterwards), the L1 max of the
+// codebook the pass ran on and the within-cell terms, then stores `seq` at *h_seq: the host spins on it, decides and
+// launches the next pass while the kernel is still updating the cells.  The count of failed recursions follows when
+// the second set of flags is up (*h_failed, then `seq` at *h_seq2).  Everything that crosses workgroups is a
+// memory-side atomic or an agent-scope atomic store / load: no agent-scope fence (= L2 write-back) anywhere.
+// (Measured alternatives: a ticket counter -- 256 returning atomics on one address -- costs ~25 us; __threadfence()
+// per wave ~20 us at M = 1024.)
+struct PublishArgs {
+    unsigned int* flags;
+    const unsigned long long* l1max_cur;
+    long long* h_l;
+    unsigned long long* h_l1;
+    double* h_within;
+    volatile unsigned long long* h_seq;
+    long long* h_failed;
+    volatile unsigned long long* h_seq2;
+    unsigned long long seq;
+};
 void launch_cell_update(const long long* rows, int M, int NC, const DevScalars* sc, const double* refl_in,
                         double* refl_out, double* cbq, double* cbm, unsigned long long* l1max_bits, double* within,
-                        long long* lstats, hipStream_t s);
+                        long long* lstats, hipStream_t s, bool zero_first = true, const int* ea = nullptr,
+                        int* eC_biased = nullptr, const PublishArgs* pub = nullptr);
+struct ZeroList {
+    void* p[3];
+    int words[3];  // 4-byte words
+};
+void launch_pass_prologue(long long* rows, int M, int NC, int what, const ZeroList& z, hipStream_t s);
 void launch_finish_q(const long long* stats, int NC, DevScalars* sc, hipStream_t s);
 void launch_init_codebook(const long long* stats, int NC, const DevScalars* sc, double* reflections, int* status,
                           hipStream_t s);

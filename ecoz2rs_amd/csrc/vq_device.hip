@@ -699,101 +699,181 @@ __global__ void k_centroids(const i64* __restrict__ rows, const double* __restri
 //   rows != nullptr : limbs -> S -> statistics -> Levinson (lpca_r) -> reflections -> codeword images
 //   rows == nullptr : reflections -> codeword images only (after set_codebook / grow)
 // Every sequential sum of the oracle (the Levinson inner product, sum S^2, raas, L1 norm) is still evaluated
-// term by term in the canonical order: the terms are produced by the lanes in parallel, parked in LDS, and
-// added by a lane-uniform loop of broadcast reads, so all lanes carry the same running value.
-// Element-wise updates (a[i] += akk*a[k-i]) are independent per i and run across lanes as they are.
+// term by term in the canonical order: the lanes produce the terms in parallel and a lane-uniform loop adds them,
+// each term broadcast from its lane with v_readlane (an SGPR operand of the add: no LDS round trip, the chain is
+// one v_add_f64 per term), so all lanes carry the same running value.  Element-wise updates
+// (a[i] += akk*a[k-i]) are independent per i and run across lanes as they are; the reversed operand a[k - lane]
+// is kept as a second per-lane array that follows the same recursion and moves up one lane per step (DPP
+// wave_shr:1).  The whole wave stays active throughout (DPP and readlane under a partial EXEC mask would read
+// stale lanes): `act` only selects values.
+// One extra workgroup publishes the level statistics to the host as soon as they are complete: see PublishArgs.
 // ------------------------------------------------------------------------------------------
 constexpr int CU_WAVES = 4;  // waves (cells) per workgroup of k_cell_update
+
+__device__ __forceinline__ double lane_bcast(double x, int l)  // l must be wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+// lane i takes the value of lane i - 1 (lane 0 reads 0) / of lane i + 1 (lane 63 reads 0)
+__device__ __forceinline__ double lane_shr1(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_shl1(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// ((0.0 + x[first]) + x[first+1]) + ... + x[last], the terms taken from lanes first..last (wave-uniform bounds)
+__device__ __forceinline__ double lane_ordered_sum(double x, int first, int last)
+{
+    double sum = 0.0;
+    int i = first;
+    for (; i + 3 <= last; i += 4) {
+        const double t0 = lane_bcast(x, i), t1 = lane_bcast(x, i + 1), t2 = lane_bcast(x, i + 2),
+                     t3 = lane_bcast(x, i + 3);
+        sum += t0;
+        sum += t1;
+        sum += t2;
+        sum += t3;
+    }
+    for (; i <= last; ++i) sum += lane_bcast(x, i);
+    return sum;
+}
+__device__ __forceinline__ bool wave_uniform(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
+
+// step-up of the predictor, one order: a[i] += akk * a[k-i] (0 < i < k), a[k] = akk; arev[i] = a[k - i] follows the
+// same recursion (arev[i] += akk * a[i], arev[0] = akk) and is then moved up one lane: arev[i] = a[(k+1) - i]
+__device__ __forceinline__ void step_up(int lane, int k, double akk, double& a, double& arev)
+{
+    const double an = a + akk * arev, rn = arev + akk * a;
+    const bool mid = lane >= 1 && lane < k;
+    a = lane == k ? akk : (mid ? an : a);
+    arev = lane == 0 ? akk : (mid ? rn : arev);
+    arev = lane_shr1(arev);
+}
 
 __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
     const i64* __restrict__ rows, int M, int NC, const DevScalars* __restrict__ sc, const double* refl_in,
     double* refl_out, double* __restrict__ cbq, double* __restrict__ cbm, int MT, u64* __restrict__ l1max_bits,
-    double* __restrict__ within, i64* __restrict__ lstats)
+    double* __restrict__ within, i64* __restrict__ lstats, const int* __restrict__ ea, int* __restrict__ eC_biased,
+    PublishArgs pub)
 {
-    __shared__ double lds[CU_WAVES][2][64];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int m = blockIdx.x * CU_WAVES + wib;
-    if (m >= M) return;
-    double* la = lds[wib][0];  // a[] / general staging
-    double* lp = lds[wib][1];  // products
     const int P = NC - 1, RS = (2 * NC + 5 + 7) & ~7, NPAD = (NC + 7) & ~7;
+    const int nb = (M + CU_WAVES - 1) / CU_WAVES;  // workgroups that own cells
+    if (pub.flags && (int)blockIdx.x == nb) {      // the publisher (dispatched last: every cell workgroup is under way)
+        // (every datum read below was written device-coherently -- memory-side atomics, agent-scope atomic stores -- and
+        // is read with agent-scope atomic loads: no cache write-back or invalidate is involved anywhere)
+        const unsigned int want = (unsigned int)pub.seq;
+        for (int i = threadIdx.x; i < M; i += blockDim.x)
+            while (__hip_atomic_load(&pub.flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want)
+                __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * 8; i += blockDim.x) {
+            if ((i & 7) == 5) continue;  // (failed recursions: counted in part 2, published at the end)
+            pub.h_l[i] = (i64)__hip_atomic_load((u64*)&lstats[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lstats[i] = 0;  // ready for the next pass
+        }
+        for (int i = threadIdx.x; i < M; i += blockDim.x)
+            pub.h_within[i] = __longlong_as_double(
+                (i64)__hip_atomic_load((const u64*)&within[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (threadIdx.x == 0) *pub.h_l1 = __hip_atomic_load(pub.l1max_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            *pub.h_seq = pub.seq;
+            __threadfence_system();
+        }
+#ifdef E2VQ_CU_NOLATE  // A/B (tools/probe/ab): no second publication
+        return;
+#endif
+        for (int i = threadIdx.x; i < M; i += blockDim.x)
+            while (__hip_atomic_load(&pub.flags[M + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want)
+                __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            i64 f = (i64)__hip_atomic_load((u64*)&lstats[threadIdx.x * 8 + 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lstats[threadIdx.x * 8 + 5] = 0;
+            for (int d = 32; d >= 1; d >>= 1) f += __shfl_xor(f, d, 64);
+            if (threadIdx.x == 0) {
+                *pub.h_failed = f;
+                __threadfence_system();
+                *pub.h_seq2 = pub.seq;
+                __threadfence_system();
+            }
+        }
+        return;
+    }
     const bool act = lane < NC;
-    const double* src = refl_in + (long)m * NC;
-    double a = 0.0;         // predictor coefficient a[lane]
-    double rcn = 0.0;       // reflection rc[lane]
-    bool have_a = false;    // a[] already holds the step-up of the final reflections
-    bool fresh = false;
+    const bool cell = m < M;  // wave-uniform
+    i64* ls = lstats + (blockIdx.x & 63) * 8;
 
-    if (rows) {
+    // ---- part 1: everything the host's convergence decision needs (level statistics, within-cell terms) ---------
+    double S = 0.0;
+    i64 cnt = 0;
+    if (cell && rows) {
         const i64* row = rows + (long)m * RS;
-        const i64 cnt = row[2 * NC];
+        cnt = row[2 * NC];
         // level statistics: 64 slots of 8 words (same-address atomics serialise at the memory side; the host
         // adds the slots -- integers, so still exact)
-        i64* ls = lstats + (blockIdx.x & 63) * 8;
-        if (lane == 0) {
-            atomicAdd((u64*)&ls[0], (u64)row[2 * NC + 1]);
-            atomicAdd((u64*)&ls[1], (u64)row[2 * NC + 2]);
-            atomicAdd((u64*)&ls[2], (u64)row[2 * NC + 3]);
-            atomicAdd((u64*)&ls[3], (u64)row[2 * NC + 4]);
-            if (cnt == 0) atomicAdd((u64*)&ls[4], 1ull);
-        }
+        if (lane < 4) atomicAdd((u64*)&ls[lane], (u64)row[2 * NC + 1 + lane]);
+        if (lane == 4 && cnt == 0) atomicAdd((u64*)&ls[4], 1ull);
+        double w = 0.0;
         if (cnt != 0) {  // wave-uniform
-            const double S = act ? unfix(row[2 * lane], row[2 * lane + 1], sc->sh_r) : 0.0;
+            S = act ? unfix(row[2 * lane], row[2 * lane + 1], sc->sh_r) : 0.0;
             // within-cell term: ss = sum_n S_n^2 (ascending n), / count
-            lp[lane] = S * S;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            double ss = 0.0;
-            for (int n0 = 0; n0 < NC; n0 += 8) {
-                double t[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = lp[(n0 + u) & 63];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (n0 + u < NC) ss += t[u];
-            }
-            if (lane == 0) within[m] = ss / (double)cnt;
+            w = lane_ordered_sum(S * S, 0, P) / (double)cnt;
+        }
+        if (lane == 0)
+            __hip_atomic_store((u64*)&within[m], (u64)__double_as_longlong(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pub.flags) {
+            // this cell's statistics are out: once the atomics and the store above have been performed (s_waitcnt; an
+            // agent-scope release fence would also write the whole L2 back, and a thousand of those queue up for tens
+            // of microseconds) the publisher may count the cell in
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0)
+                __hip_atomic_store(&pub.flags[m], (unsigned int)pub.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // ---- part 2: the new codeword of the cell and its images ------------------------------------------------------
+    if (cell) {
+        const double* src = refl_in + (long)m * NC;
+        double a = lane == 0 ? 1.0 : 0.0;     // predictor coefficient a[lane]
+        double arev = lane == 1 ? 1.0 : 0.0;  // a[k - lane] for the order k about to be computed (k = 1)
+        double rcn = 0.0;                     // reflection rc[lane]
+        bool have_a = false;                  // a[] already holds the step-up of the final reflections
+        bool fresh = false;
+
+#ifdef E2VQ_CU_NOLEV  // A/B: no recursion (every cell keeps its codeword)
+        if (false) {
+#else
+        if (rows && cnt != 0) {  // wave-uniform
+#endif
             // ---- lpca_r (src/lpc/lpca_r_rs.rs:8-43) on S ------------------------------------------------
-            const double r0 = __shfl(S, 0, 64);
+            const double r0 = lane_bcast(S, 0);
             int status = 0;
-            if (0.0 == r0) {
+            if (wave_uniform(0.0 == r0)) {
                 status = 1;
             } else {
                 double pe = r0;
-                a = lane == 0 ? 1.0 : 0.0;
                 for (int k = 1; k <= P; ++k) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    la[lane] = a;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const int rev = k - lane;
-                    const double ar = (rev >= 0 && rev < 64) ? la[rev] : 0.0;  // old a[k - lane]
-                    lp[lane] = ar * S;                                        // a[k-i] * r[i] at lane i
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    // sum -= lp[i], i = 1..k in order; reads are issued 8 at a time so their LDS latency overlaps
-                    double sum = 0.0;
-                    for (int i0 = 1; i0 <= k; i0 += 8) {
-                        double t[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) t[u] = lp[(i0 + u) & 63];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (i0 + u <= k) sum -= t[u];
-                    }
+                    // sum = ((0 - a[k-1] r[1]) - a[k-2] r[2]) - ... - a[0] r[k]   (x - y == x + (-y), exactly)
+                    const double sum = lane_ordered_sum(-(arev * S), 1, k);
                     const double akk = sum / pe;
-                    if (lane == k) {
-                        rcn = akk;
-                        a = akk;
-                    } else if (lane >= 1 && lane < k) {
-                        a = a + akk * ar;
-                    }
+                    if (lane == k) rcn = akk;
+                    step_up(lane, k, akk, a, arev);
                     pe *= 1.0 - akk * akk;
-                    if (pe <= 0.0) {
+                    if (wave_uniform(pe <= 0.0)) {
                         status = 2;
                         break;
                     }
@@ -805,85 +885,65 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
             } else if (lane == 0) {
                 atomicAdd((u64*)&ls[5], 1ull);
             }
-        } else if (lane == 0) {
-            within[m] = 0.0;
+        }
+#ifndef E2VQ_CU_NOLATE
+        if (pub.flags && rows) {  // whether this cell's recursion failed is known (and counted)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0)
+                __hip_atomic_store(&pub.flags[M + m], (unsigned int)pub.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#endif
+
+        if (!fresh) rcn = act ? src[lane] : 0.0;  // keep the codeword
+        if (lane == 0) rcn = 0.0;
+        if (refl_out && act && (fresh || refl_out != refl_in)) refl_out[(long)m * NC + lane] = rcn;
+
+        if (!have_a) {  // step-up from the reflections (same element-wise updates as inside lpca_r)
+            a = lane == 0 ? 1.0 : 0.0;
+            arev = lane == 1 ? 1.0 : 0.0;
+            for (int k = 1; k <= P; ++k) step_up(lane, k, lane_bcast(rcn, k), a, arev);
+        }
+        if (!act) a = 0.0;
+
+        // ---- raas: raa[n] = sum_{i=0}^{P-n} a[i]*a[i+n]  (ascending i) -> cq ------------------------------
+        double raa = 0.0, ash = a;  // ash = a[lane + i]
+        for (int i = 0; i <= P; ++i) {
+            const double t = raa + lane_bcast(a, i) * ash;
+            raa = i + lane <= P ? t : raa;
+            ash = lane_shl1(ash);
+        }
+        const double c = !act ? 0.0 : (lane == 0 ? raa : 2.0 * raa);
+        const double l1 = lane_ordered_sum(fabs(c), 0, P);
+        if (lane == 0) {  // monotone max: skip the atomic unless it can still raise the value
+            const u64 bits = (u64)__double_as_longlong(l1);
+            if (bits > __hip_atomic_load(l1max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(l1max_bits, bits);
+        }
+        if (eC_biased) {  // scale of the limb image of this codebook: max ilogb(c a) + 1 (k_pre_cmax)
+            int e = (act && c != 0.0) ? ilogb(c) + ea[lane] + 1 + E2VQ_PRE_EBIAS : 0;
+            for (int d = 32; d >= 1; d >>= 1) {
+                const int o = __shfl_xor(e, d, 64);
+                e = o > e ? o : e;
+            }
+            if (lane == 0 && e > __hip_atomic_load(eC_biased, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(eC_biased, e);
+        }
+        if (lane < NPAD) cbq[(long)m * NPAD + lane] = c;
+        if (cbm) {
+            const int NS = (NC + 3) >> 2, NP = (NS + 1) >> 1;
+            // this cell's slot, plus (cell 0 only) the padding slots of the last tile: copies of codeword 0
+            const int first = m, last = (m == 0) ? 16 * MT : m + 1;
+            for (int mm = first; mm < last; mm = (mm == first && m == 0) ? M : mm + 1) {
+                if (mm >= 16 * MT) break;
+                double* mt = cbm + (long)(mm >> 4) * NP * 128;
+                const int jm = mm & 15;
+                if (lane < 8 * NP)
+                    mt[(((lane >> 3) * 64) + ((lane & 3) * 16 + jm)) * 2 + ((lane >> 2) & 1)] = c;
+                if (lane == P) cbm[(long)MT * NP * 128 + (long)(mm >> 4) * 16 + (jm & 3) * 4 + (jm >> 2)] = c;
+            }
         }
     }
 
-    if (!fresh) rcn = act ? src[lane] : 0.0;  // keep the codeword
-    if (lane == 0) rcn = 0.0;
-    if (refl_out && act && (fresh || refl_out != refl_in)) refl_out[(long)m * NC + lane] = rcn;
-
-    if (!have_a) {  // step-up from the reflections (same element-wise updates as inside lpca_r)
-        a = lane == 0 ? 1.0 : 0.0;
-        for (int k = 1; k <= P; ++k) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            la[lane] = a;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int rev = k - lane;
-            const double ar = (rev >= 0 && rev < 64) ? la[rev] : 0.0;
-            const double akk = __shfl(rcn, k, 64);
-            if (lane == k)
-                a = akk;
-            else if (lane >= 1 && lane < k)
-                a = a + akk * ar;
-        }
-    }
-
-    // ---- raas: raa[n] = sum_{i=0}^{P-n} a[i]*a[i+n]  (ascending i) -> cq ------------------------------
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    la[lane] = act ? a : 0.0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double raa = 0.0;
-    for (int i0 = 0; i0 <= P; i0 += 8) {
-        double ai[8], aj[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            ai[u] = la[(i0 + u) & 63];
-            aj[u] = la[(i0 + u + lane) & 63];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (i0 + u + lane <= P) raa += ai[u] * aj[u];
-    }
-    const double c = lane == 0 ? raa : 2.0 * raa;
-    lp[lane] = act ? fabs(c) : 0.0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double l1 = 0.0;
-    for (int n0 = 0; n0 <= P; n0 += 8) {
-        double t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = lp[(n0 + u) & 63];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (n0 + u <= P) l1 += t[u];
-    }
-    if (lane == 0) {  // monotone max: skip the atomic unless it can still raise the value
-        const u64 bits = (u64)__double_as_longlong(l1);
-        if (bits > __hip_atomic_load(l1max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(l1max_bits, bits);
-    }
-    if (lane < NPAD) cbq[(long)m * NPAD + lane] = act ? c : 0.0;
-    if (cbm) {
-        const int NS = (NC + 3) >> 2, NP = (NS + 1) >> 1;
-        // this cell's slot, plus (cell 0 only) the padding slots of the last tile: copies of codeword 0
-        const int first = m, last = (m == 0) ? 16 * MT : m + 1;
-        for (int mm = first; mm < last; mm = (mm == first && m == 0) ? M : mm + 1) {
-            if (mm >= 16 * MT) break;
-            double* mt = cbm + (long)(mm >> 4) * NP * 128;
-            const int jm = mm & 15;
-            if (lane < 8 * NP)
-                mt[(((lane >> 3) * 64) + ((lane & 3) * 16 + jm)) * 2 + ((lane >> 2) & 1)] = act ? c : 0.0;
-            if (lane == P) cbm[(long)MT * NP * 128 + (long)(mm >> 4) * 16 + (jm & 3) * 4 + (jm >> 2)] = c;
-        }
-    }
 }
 
 // the M = 1 codeword from the global sums
@@ -1212,14 +1272,46 @@ void launch_reduce_slice_i64(const PeerBuffers& bufs, int n, long lo, long hi, i
 
 bool has_cell_update(int NC) { return NC <= 64; }
 
-// fused per-cell update (rows != nullptr) or codeword preparation only (rows == nullptr)
+// fused per-cell update (rows != nullptr) or codeword preparation only (rows == nullptr).  *l1max_bits (and
+// *eC_biased, if given) must be zero when the kernel starts: zero_first adds a memset for callers that have no
+// launch_pass_prologue in front.
 void launch_cell_update(const i64* rows, int M, int NC, const DevScalars* sc, const double* refl_in, double* refl_out,
-                        double* cbq, double* cbm, u64* l1max_bits, double* within, i64* lstats, hipStream_t s)
+                        double* cbq, double* cbm, u64* l1max_bits, double* within, i64* lstats, hipStream_t s,
+                        bool zero_first, const int* ea, int* eC_biased, const PublishArgs* pub)
 {
-    (void)hipMemsetAsync(l1max_bits, 0, sizeof(u64), s);
+    if (zero_first) (void)hipMemsetAsync(l1max_bits, 0, sizeof(u64), s);
     const int MT = (M + 15) / 16;
-    hipLaunchKernelGGL(k_cell_update, dim3((M + CU_WAVES - 1) / CU_WAVES), dim3(64 * CU_WAVES), 0, s, rows, M, NC, sc,
-                       refl_in, refl_out, cbq, cbm, MT, l1max_bits, within, lstats);
+    PublishArgs p{};
+    if (pub) p = *pub;
+    hipLaunchKernelGGL(k_cell_update, dim3((M + CU_WAVES - 1) / CU_WAVES + (p.flags ? 1 : 0)), dim3(64 * CU_WAVES), 0,
+                       s, rows, M, NC, sc, refl_in, refl_out, cbq, cbm, MT, l1max_bits, within, lstats, ea, eC_biased,
+                       p);
+}
+
+// One launch in front of a pass instead of up to four memsets: the rows (what = 1: every word, 2: the four
+// distortion columns of every row, 0: nothing) and up to three small blocks of 4-byte words.
+__global__ __launch_bounds__(256) void k_pass_prologue(i64* __restrict__ rows, int M, int NC, int RS, int what,
+                                                       ZeroList z)
+{
+    if (what == 1) {
+        const long n2 = (long)M * RS / 2;  // RS is a multiple of 8 words
+        ulonglong2* r2 = (ulonglong2*)rows;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256)
+            r2[i] = make_ulonglong2(0ull, 0ull);
+    } else if (what == 2) {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < 4L * M; i += (long)gridDim.x * 256)
+            rows[(i >> 2) * RS + 2 * NC + 1 + (i & 3)] = 0;
+    }
+    if (blockIdx.x == 0)
+        for (int k = 0; k < 3; ++k)
+            for (int j = threadIdx.x; j < z.words[k]; j += 256) ((unsigned int*)z.p[k])[j] = 0u;
+}
+
+void launch_pass_prologue(i64* rows, int M, int NC, int what, const ZeroList& z, hipStream_t s)
+{
+    const int RS = row_stride(NC);
+    const long items = what == 1 ? (long)M * RS / 2 : (what == 2 ? 4L * M : 1);
+    hipLaunchKernelGGL(k_pass_prologue, dim3(grid_for(items, 256, 1024)), dim3(256), 0, s, rows, M, NC, RS, what, z);
 }
 
 void launch_init_codebook(const i64* stats, int NC, const DevScalars* sc, double* reflections, int* status,

@@ -89,8 +89,11 @@ struct e2vq_session {
     double* d_cbm_spec = nullptr;
     u64* d_l1max_spec = nullptr;
     bool spec_valid = false;
+    bool spec_zeroed = false;  // the pass prologue zeroed d_l1max_spec and the shadow image's scalars
     hipEvent_t ev_stats = nullptr;
-    struct HostStats { i64 l[64 * 8]; u64 l1bits; volatile u64 seq; }* h_stats = nullptr;  // pinned, host-mapped
+    struct HostStats { i64 l[64 * 8]; u64 l1bits; volatile u64 seq; i64 failed; volatile u64 seq2; }* h_stats = nullptr;  // pinned, host-mapped
+    bool failed_pending = false;              // the failed-recursion count of stats_seq has not been read yet (seq2)
+    e2vq_level_stats* failed_patch = nullptr;  // e2vq_learn: the level record that still waits for that count
     u64 stats_seq = 0;
     double* h_within = nullptr;                                      // pinned, M_cap doubles
     // statistics
@@ -177,7 +180,9 @@ static int ensure_codebook_capacity(e2vq_session* s, int M)
         HIPCHK(hipMalloc(&cbm_spec, (size_t)e2vq::cbm_doubles(s->NC, cap) * 8));
     }
     HIPCHK(hipMalloc(&S, (size_t)cap * s->NC * 8));
-    HIPCHK(hipMalloc(&within, (size_t)cap * 8));
+    // (+ the flags k_cell_update's publishing workgroup polls: two per cell)
+    HIPCHK(hipMalloc(&within, (size_t)cap * 8 + (size_t)cap * 2 * sizeof(unsigned)));
+    HIPCHK(hipMemset(within + cap, 0, (size_t)cap * 2 * sizeof(unsigned)));
     HIPCHK(hipMalloc(&rows, (size_t)cap * s->RS * 8));
     if (s->M > 0) {
         HIPCHK(hipMemcpyAsync(refl, s->d_refl, (size_t)s->M * s->NC * 8, hipMemcpyDeviceToDevice, s->stream));
@@ -584,14 +589,30 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         rows = s->d_rows_local;
     }
     const bool incremental = keep && s->incr_valid && s->incr_M == s->M;
-    if (incremental)
-        e2vq::launch_zero_distortion_columns(rows, s->M, s->NC, s->stream);
-    else if (mode != 0)
-        HIPCHK(hipMemsetAsync(rows, 0, (size_t)s->M * s->RS * 8, s->stream));
     // The first pass of a level accumulates in full.  For the smallest prefiltered sizes that is cheaper on the plain
     // FP64 sweep with its workgroup-local LDS table (hybrid accumulate: 0.92 vs 1.5 ms at M = 256, where 2^21 frames
     // hammer 256 rows with global atomics); it records the cells for the incremental passes that follow.
     const bool plain_first = s->plain_first && keep && !incremental && mode == 5 && s->M <= 384;
+    if (s->last_prefiltered && !plain_first && ensure_codebook_image(s)) return 1;
+    {
+        // one prologue launch: the rows (all of them, or the distortion columns of an incremental pass), the fallback
+        // count of a codebook image that is already there, and what the speculative update after this pass
+        // accumulates into with atomicMax (the shadow codebook's L1 max and the scalars of its limb image)
+        e2vq::ZeroList z{};
+        int nz = 0;
+        if (s->last_prefiltered && !plain_first && s->img_valid[s->img_cur]) {
+            z.p[nz] = (void*)e2vq::prefilter_fallback_count(s->d_ps2[s->img_cur]);
+            z.words[nz++] = 1;
+        }
+        z.p[nz] = s->d_l1max_spec;
+        z.words[nz++] = 2;
+        if (s->d_ps2[1 - s->img_cur]) {
+            z.p[nz] = s->d_ps2[1 - s->img_cur];
+            z.words[nz++] = (int)(e2vq::prefilter_scalars_bytes() / 4);
+        }
+        e2vq::launch_pass_prologue(rows, s->M, s->NC, incremental ? 2 : (mode != 0 ? 1 : 0), z, s->stream);
+        s->spec_zeroed = true;
+    }
     if (plain_first) {
         unsigned short* sym_out = device_sym ? (unsigned short*)device_sym : s->d_prev_sym;
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
@@ -610,11 +631,9 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     } else if (s->last_prefiltered) {
         // f16 limb image of the current codebook, prefiltered sweep (exact evaluation of the certified top two),
         // then the full FP64 sweep of whatever it could not certify
-        if (ensure_codebook_image(s)) return 1;
         const int k = s->img_cur;
-        if (s->img_valid[k])  // built ahead by e2vq_pass_stats for the codebook committed since: only the count restarts
-            HIPCHK(hipMemsetAsync((void*)e2vq::prefilter_fallback_count(s->d_ps2[k]), 0, sizeof(int), s->stream));
-        else
+        if (!s->img_valid[k])  // (else: built ahead by e2vq_pass_stats for the codebook committed since; the prologue
+                               // restarted its fallback count)
             e2vq::launch_prefilter_codebook(s->d_cbq, s->M, s->NC, s->d_ea, s->d_ps2[k], s->d_cimg2[k], s->stream);
         s->img_valid[k] = true;
         s->img_last = k;
@@ -715,45 +734,94 @@ extern "C" int e2vq_last_pass_kernel_ms(e2vq_session* s, float* ms)
     return 0;
 }
 
-extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
+// the count of failed recursions of the last fused update arrives at the kernel's end (PublishArgs::h_seq2)
+static int resolve_failed_cells(e2vq_session* s)
+{
+    if (!s->failed_pending) return 0;
+    for (unsigned long spins = 0; s->h_stats->seq2 != s->stats_seq; ++spins) {
+        if ((spins & 0xfff) == 0xfff) {
+            const hipError_t q = hipEventQuery(s->ev_stats);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return e2vq_set_error("update kernel failed: %s", hipGetErrorString(q));
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    if (s->h_stats->seq2 != s->stats_seq) HIPCHK(hipStreamSynchronize(s->stream));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    s->last.failed_cells = s->h_stats->failed;
+    if (s->failed_patch) s->failed_patch->failed_cells = s->h_stats->failed;
+    s->failed_patch = nullptr;
+    s->failed_pending = false;
+    return 0;
+}
+
+// wait_failed = false (e2vq_learn): return as soon as the statistics the convergence rule needs are there;
+// failed_cells of *out is then filled in by resolve_failed_cells later
+static int pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_failed)
 {
     HIPCHK(hipSetDevice(s->device));
     if (s->stats_valid) {
+        if (wait_failed && resolve_failed_cells(s)) return 1;
         if (out) *out = s->last;
         return 0;
     }
+    if (resolve_failed_cells(s)) return 1;  // (of the pass before: long there)
     // (d_lstats is zero here -- zeroed at session start and by every publish kernel -- unless a separate centroid
     // kernel counted failed cells into it afterwards)
     if (s->lstats_dirty) HIPCHK(hipMemsetAsync(s->d_lstats, 0, 64 * 8 * 8, s->stream));
     s->lstats_dirty = false;
     const bool fused = e2vq::has_cell_update(s->NC);
-    if (fused)  // statistics + speculative update into the shadow codebook in ONE wave-per-cell kernel
+    void *dl = nullptr, *dw = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dl, s->h_stats, 0));
+    HIPCHK(hipHostGetDevicePointer(&dw, s->h_within, 0));
+    auto* dstats = (e2vq_session::HostStats*)dl;
+    if (fused) {
+        // statistics + speculative update into the shadow codebook in ONE wave-per-cell kernel; its last workgroup
+        // writes the statistics into host-mapped memory and then a sequence number.  The next pass will most likely
+        // run on the shadow codebook: if that pass is going to be a prefiltered one, the kernel also finds the scale of
+        // the shadow's limb image, and the image itself is built right behind it -- after the statistics went out,
+        // i.e. during the host's round trip.
+        const int k = 1 - s->img_cur;
+        const bool image = s->d_cimg2[k] && use_prefilter(s, pass_mode(s)) && s->M <= s->cimg_cap;
+        if (!s->spec_zeroed) {  // (no e2vq_pass in front: a repeated e2vq_pass_stats after an update)
+            HIPCHK(hipMemsetAsync(s->d_l1max_spec, 0, sizeof(u64), s->stream));
+            if (s->d_ps2[k]) HIPCHK(hipMemsetAsync(s->d_ps2[k], 0, e2vq::prefilter_scalars_bytes(), s->stream));
+        }
+        s->spec_zeroed = false;
+        e2vq::PublishArgs pub{};
+        pub.flags = (unsigned int*)(s->d_within + s->M_cap);
+        pub.l1max_cur = s->d_l1max;
+        pub.h_l = dstats->l;
+        pub.h_l1 = &dstats->l1bits;
+        pub.h_within = (double*)dw;
+        pub.h_seq = (volatile u64*)&dstats->seq;
+        pub.h_failed = &dstats->failed;
+        pub.h_seq2 = (volatile u64*)&dstats->seq2;
+        pub.seq = ++s->stats_seq;
         e2vq::launch_cell_update(s->d_rows, s->M, s->NC, s->d_sc, s->d_refl, s->d_refl_spec, s->d_cbq_spec,
-                                 s->d_cbm_spec, s->d_l1max_spec, s->d_within, s->d_lstats, s->stream);
-    else
+                                 s->d_cbm_spec, s->d_l1max_spec, s->d_within, s->d_lstats, s->stream,
+                                 /*zero_first=*/false, image ? s->d_ea : nullptr,
+                                 image ? e2vq::prefilter_codebook_scale(s->d_ps2[k]) : nullptr, &pub);
+        s->failed_pending = true;
+        HIPCHK(hipEventRecord(s->ev_stats, s->stream));
+        if (image) {
+            e2vq::launch_prefilter_codebook(s->d_cbq_spec, s->M, s->NC, s->d_ea, s->d_ps2[k], s->d_cimg2[k], s->stream,
+                                            /*scale_ready=*/true);
+            s->img_valid[k] = true;
+        }
+    } else {
+        // thread-per-cell path (P > 63): statistics, a one-block publish kernel, then the speculative centroid update
+        // (keeps the GPU busy while the host decides)
         e2vq::launch_rows_stats(s->d_rows, s->M, s->NC, s->d_sc, s->d_S, s->d_within, s->d_lstats, s->stream);
-    // publish: one small kernel writes the statistics into host-mapped memory and then a sequence number
-    {
-        void *dl = nullptr, *dw = nullptr;
-        HIPCHK(hipHostGetDevicePointer(&dl, s->h_stats, 0));
-        HIPCHK(hipHostGetDevicePointer(&dw, s->h_within, 0));
-        auto* dstats = (e2vq_session::HostStats*)dl;
         e2vq::launch_publish_stats(s->d_lstats, s->d_l1max, s->d_within, s->M, dstats->l, &dstats->l1bits, (double*)dw,
                                    (u64*)&dstats->seq, ++s->stats_seq, s->stream);
-    }
-    HIPCHK(hipEventRecord(s->ev_stats, s->stream));
-    if (!fused) {  // speculative centroid update: keeps the GPU busy while the host decides
+        HIPCHK(hipEventRecord(s->ev_stats, s->stream));
         e2vq::launch_centroids(s->d_rows, s->d_S, s->M, s->NC, s->d_refl, s->d_refl_spec, s->d_lstats, s->stream);
         s->lstats_dirty = true;
         e2vq::launch_codebook_prepare(s->d_refl_spec, s->M, s->NC, s->d_cbq_spec, s->d_l1max_spec, s->d_cbm_spec,
                                       s->stream);
-    }
-    // the next pass will most likely run on the shadow codebook: its limb image is built now -- after the statistics
-    // went out, i.e. during the host's round trip -- if that pass is going to be a prefiltered one
-    if (fused && s->d_cimg2[1 - s->img_cur] && use_prefilter(s, pass_mode(s)) && s->M <= s->cimg_cap) {
-        const int k = 1 - s->img_cur;
-        e2vq::launch_prefilter_codebook(s->d_cbq_spec, s->M, s->NC, s->d_ea, s->d_ps2[k], s->d_cimg2[k], s->stream);
-        s->img_valid[k] = true;
     }
     HIPCHK(hipGetLastError());
     s->spec_valid = true;
@@ -792,8 +860,10 @@ extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
     s->last.sigma = sqrt(v);
     s->last.inertia = s->h_sc.Q - w;
     s->last.empty_cells = l[4];
-    s->last.failed_cells = l[5];  // fused kernel: counted before the publish
-    if (!fused) {
+    s->last.failed_cells = 0;
+    if (fused) {
+        if (wait_failed && resolve_failed_cells(s)) return 1;
+    } else {
         // thread-per-cell path (P > 63): k_centroids counted the failed recursions after the slots were published
         i64 slots[64 * 8];
         HIPCHK(hipMemcpyAsync(slots, s->d_lstats, sizeof slots, hipMemcpyDeviceToHost, s->stream));
@@ -806,6 +876,8 @@ extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out)
     if (out) *out = s->last;
     return 0;
 }
+
+extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out) { return pass_stats_impl(s, out, true); }
 
 extern "C" int e2vq_update(e2vq_session* s)
 {
@@ -877,6 +949,10 @@ extern "C" int e2vq_learn(e2vq_session* s, double epsilon, int max_M, const char
         FILE* f = nullptr;
         ~FileCloser() { if (f) fclose(f); }
     } rpt_guard;
+    struct PatchGuard {  // no pointer into the caller's level records outlives the call
+        e2vq_session* s;
+        ~PatchGuard() { s->failed_patch = nullptr; }
+    } patch_guard{s};
     FILE*& rpt = rpt_guard.f;
     char path[4096];
     if (write_files) {
@@ -901,7 +977,7 @@ extern "C" int e2vq_learn(e2vq_session* s, double epsilon, int max_M, const char
         int pass = 0;
         for (;; ++pass) {
             if (e2vq_pass(s, nullptr, nullptr)) return 1;
-            if (e2vq_pass_stats(s, &ls)) return 1;
+            if (pass_stats_impl(s, &ls, /*wait_failed=*/false)) return 1;
             const double DD = ls.DD;
             const double ratio = (s->DDprv - DD) / DD;
             if (verbose) {
@@ -926,10 +1002,14 @@ extern "C" int e2vq_learn(e2vq_session* s, double epsilon, int max_M, const char
                 fprintf(rpt, "%d %d %.17g %.17g %.17g %.17g %lld\n", s->M, ls.passes, ls.DD, ls.avg_distortion,
                         ls.sigma, ls.inertia, (long long)ls.empty_cells);
         }
-        if (levels && nlev < max_levels) levels[nlev] = ls;
+        if (levels && nlev < max_levels) {
+            levels[nlev] = ls;
+            if (s->failed_pending) s->failed_patch = &levels[nlev];  // (filled in before the next statistics / on return)
+        }
         ++nlev;
         if (callback && s->rank == 0) callback(target, s->M, ls.avg_distortion, ls.sigma, ls.inertia);
     }
+    if (resolve_failed_cells(s)) return 1;
     if (num_levels) *num_levels = nlev;
     return 0;
 }

@@ -315,7 +315,7 @@ struct PreScalars {
     int ymax_bits;  // max_m sum_n |eta[m][n]| as float bits (positive -> ordered like ints)
     int fb_count;   // frames handed to the fallback sweep
 };
-constexpr int PRE_EBIAS = 1 << 20;
+constexpr int PRE_EBIAS = E2VQ_PRE_EBIAS;
 
 // ---- codebook scale: eC = max ilogb(c a) + 1 over the codebook -------------------------------------------
 __global__ void k_pre_cmax(const double* __restrict__ cbq, int M, int NC, int NPAD, const int* __restrict__ ea,
@@ -808,14 +808,18 @@ void launch_prefilter_quantize_prep(const double* aos, long T, long nblocks64, i
 }
 
 const int* prefilter_fallback_count(const void* ps) { return &((const PreScalars*)ps)->fb_count; }
+int* prefilter_codebook_scale(void* ps) { return &((PreScalars*)ps)->eC_biased; }
 
 // zeroes the per-pass scalars (fallback count included) and builds the limb image of the current codebook
-void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, void* ps, void* cimg, hipStream_t s)
+void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, void* ps, void* cimg, hipStream_t s,
+                               bool scale_ready)
 {
     const int NPAD = (NC + 7) & ~7;
-    (void)hipMemsetAsync(ps, 0, sizeof(PreScalars), s);
-    hipLaunchKernelGGL(k_pre_cmax, dim3(pre_grid((long)M * NC, 1024, 32)), dim3(256), 0, s, cbq, M, NC, NPAD, ea,
-                       (PreScalars*)ps);
+    if (!scale_ready) {
+        (void)hipMemsetAsync(ps, 0, sizeof(PreScalars), s);
+        hipLaunchKernelGGL(k_pre_cmax, dim3(pre_grid((long)M * NC, 1024, 32)), dim3(256), 0, s, cbq, M, NC, NPAD, ea,
+                           (PreScalars*)ps);
+    }
     switch (NC) {
 #define X(N)                                                                                                        \
     case N:                                                                                                         \
