@@ -80,6 +80,24 @@ __device__ __forceinline__ void load_block_frames_rowmajor(const double* __restr
     }
 }
 
+// the same operands from a wave's 64 row-major frames staged in LDS (fused quantize; frames >= T were staged as zeros)
+template <int NC>
+__device__ __forceinline__ void load_block_frames_stage(const double* stage, int lane,
+                                                        double (&Bf)[4][2 * ((((NC + 3) / 4) + 1) / 2)])
+{
+    constexpr int NS = (NC + 3) / 4, REM = NC - 4 * (NS - 1);
+    const int q = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+        const double* row = stage + (16 * ft + j) * NC;
+#pragma unroll
+        for (int st = 0; st < NS - 1; ++st) Bf[ft][st] = row[4 * st + q];
+        Bf[ft][NS - 1] = REM == 1 ? row[NC - 1] : (q < REM ? row[4 * (NS - 1) + q] : 0.0);
+#pragma unroll
+        for (int st = NS; st < 2 * ((NS + 1) / 2); ++st) Bf[ft][st] = 0.0;
+    }
+}
+
 // Bf[ft][st]: lane (q, j) holds r[frame 16 ft + j][4 st + q] (with NC = 4k+1 every q lane holds r[NC-1] in the
 // last slot); best / idx: min distortion and cell of frame 16 ft + j, in all four q lanes.  img: this wave's 16 row
 // images in LDS.  MODE 1: all cells in the LDS table lacc; 5: cells < lds_cells there; 2: global atomics; 3: none.

@@ -44,9 +44,10 @@ size_t prefilter_codebook_image_bytes(int NC, int M);
 size_t prefilter_scalars_bytes();
 void launch_prefilter_frames(const double* blk, long T, long nblocks64, int NC, unsigned long long* colmax_bits, int* ea,
                              void* fimg, float* fg, hipStream_t s);
-// quantize: scales from the codebook; row-major frames -> blocked FP64 layout + limb image + tolerance terms
-void launch_prefilter_quantize_prep(const double* aos, long T, long nblocks64, int NC, const double* cbq, int M, int* ea,
-                                    double* blk, void* fimg, float* fg, hipStream_t s);
+// quantize, unfused (P = 40): row-major frames -> (optional) blocked FP64 layout + limb image + tolerance terms, with the
+// scales of launch_prefilter_quantize_scales
+void launch_prefilter_quantize_prep(const double* aos, long T, long nblocks64, int NC, const int* ea, double* blk,
+                                    void* fimg, float* fg, hipStream_t s);
 // scale_ready: the scalars were zeroed before and *prefilter_codebook_scale(ps) already holds the scale of this
 // codebook (k_cell_update computed it): only the image kernel runs
 void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, void* ps, void* cimg, hipStream_t s,
@@ -57,7 +58,11 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                             const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                             long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
-                            hipStream_t s, const double* rowmajor_frames = nullptr);
+                            hipStream_t s, const double* rowmajor_frames = nullptr, const int* ea_fused = nullptr);
+// fused quantize (ea_fused != nullptr, assignment only): no frame image at all -- the sweep builds the limb images of
+// its frames from rowmajor_frames with the per-coefficient scales ea_fused (launch_prefilter_quantize_scales)
+bool prefilter_fused_quantize(int NC);
+void launch_prefilter_quantize_scales(const double* cbq, int M, int NC, int* ea, hipStream_t s);
 int launch_pass_fallback(int NC, bool accumulate, const double* blk, const double* cbm, int M, const DevScalars* sc,
                          const unsigned long long* l1max_bits, unsigned short* sym, double* dmin, long long* rows,
                          const int* fb_list, const int* fb_count, unsigned short* prev_sym, bool incremental,

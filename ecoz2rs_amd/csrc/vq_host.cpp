@@ -147,6 +147,9 @@ struct e2vq_session {
     int* d_qfblist = nullptr;
     void* d_qcimg = nullptr;
     i64 qpre_cap = 0;
+    i64 qfb_cap = 0;
+    u64 cb_version = 1;    // bumped whenever the codebook in d_cbq changes
+    u64 qimg_version = 0;  // codebook version d_qcimg / d_ea_q / d_ps were built for
     int qcimg_cap = 0;
     // incremental accumulation (prefiltered passes): the rank's own rows and every frame's cell persist between
     // passes of one codebook size; a pass then moves only the frames whose cell changed (vq_accum.h)
@@ -455,6 +458,7 @@ static int codebook_prepare(e2vq_session* s, bool redefined = true)
 {
     if (redefined) s->incr_valid = false;
     s->img_valid[0] = s->img_valid[1] = false;  // the codebook in d_cbq is a new one
+    s->cb_version++;
     if (e2vq::has_cell_update(s->NC))
         e2vq::launch_cell_update(nullptr, s->M, s->NC, s->d_sc, s->d_refl, nullptr, s->d_cbq, s->d_cbm, s->d_l1max,
                                  nullptr, nullptr, s->stream);
@@ -885,6 +889,7 @@ extern "C" int e2vq_update(e2vq_session* s)
         if (e2vq_pass_stats(s, nullptr)) return 1;
     }
     HIPCHK(hipSetDevice(s->device));
+    s->cb_version++;
     if (s->spec_valid) {  // commit the speculative update: no launch, just swap the codebook sets
         std::swap(s->d_refl, s->d_refl_spec);
         std::swap(s->d_cbq, s->d_cbq_spec);
@@ -1056,18 +1061,24 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
     HIPCHK(hipSetDevice(s->device));
     const i64 nb = (T + s->FB - 1) / s->FB;
     if (s->pre_enabled && s->M >= s->pre_min_M && e2vq::prefilter_supports(s->NC, s->M)) {
-        // prefiltered sweep: one pass over the row-major payload builds the f16 limb image and the tolerance terms; the
-        // assignment-only prefiltered kernel and the FP64 sweep of what it could not certify then take the FP64 frames
-        // straight from the payload (no blocked copy: 592 B per frame less traffic)
-        if (s->qpre_cap < nb) {
-            for (void* p : {(void*)s->d_qfimg, (void*)s->d_qfg, (void*)s->d_qfblist})
+        // prefiltered sweep.  Fused (P <= 38): the assignment-only kernel builds the f16 limb images of its frames from the
+        // row-major payload itself and keeps the FP64 frames in LDS for the exact evaluation -- every frame is read once.
+        // Otherwise one preparation pass over the payload writes the limb image and the tolerance terms first.  Either
+        // way the FP64 sweep of whatever could not be certified reads the payload too (no blocked copy).
+        const bool fused = e2vq::prefilter_fused_quantize(s->NC);
+        if (s->qfb_cap < nb) {
+            if (s->d_qfblist) HIPCHK(hipFree(s->d_qfblist));
+            s->d_qfblist = nullptr;
+            HIPCHK(hipMalloc(&s->d_qfblist, (size_t)nb * 64 * sizeof(int)));
+            s->qfb_cap = nb;
+        }
+        if (!fused && s->qpre_cap < nb) {
+            for (void* p : {(void*)s->d_qfimg, (void*)s->d_qfg})
                 if (p) HIPCHK(hipFree(p));
             s->d_qfimg = nullptr;
             s->d_qfg = nullptr;
-            s->d_qfblist = nullptr;
             HIPCHK(hipMalloc(&s->d_qfimg, e2vq::prefilter_frame_image_bytes(s->NC, nb)));
             HIPCHK(hipMalloc(&s->d_qfg, (size_t)nb * 64 * sizeof(float)));
-            HIPCHK(hipMalloc(&s->d_qfblist, (size_t)nb * 64 * sizeof(int)));
             s->qpre_cap = nb;
         }
         if (!s->d_ea_q) HIPCHK(hipMalloc(&s->d_ea_q, (size_t)s->NC * sizeof(int)));
@@ -1076,14 +1087,27 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
             s->d_qcimg = nullptr;
             s->qcimg_cap = std::max(s->M, 2048);
             HIPCHK(hipMalloc(&s->d_qcimg, e2vq::prefilter_codebook_image_bytes(s->NC, s->qcimg_cap)));
+            s->qimg_version = 0;
         }
         const double* aos = (const double*)device_frames;
-        e2vq::launch_prefilter_quantize_prep(aos, T, nb, s->NC, s->d_cbq, s->M, s->d_ea_q, nullptr, s->d_qfimg, s->d_qfg,
-                                             s->stream);
-        e2vq::launch_prefilter_codebook(s->d_cbq, s->M, s->NC, s->d_ea_q, s->d_ps, s->d_qcimg, s->stream);
-        e2vq::launch_pass_prefiltered(s->NC, false, nullptr, T, nb, s->d_qfimg, s->d_qfg, s->d_qcimg, s->d_ps, s->d_cbq,
-                                      s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym, (double*)device_dmin, nullptr,
-                                      s->d_qfblist, nullptr, false, false, s->stream, aos);
+        if (s->qimg_version != s->cb_version) {
+            // scales and limb image of the codebook: once per codebook, not per call (a corpus is many short files)
+            e2vq::launch_prefilter_quantize_scales(s->d_cbq, s->M, s->NC, s->d_ea_q, s->stream);
+            e2vq::launch_prefilter_codebook(s->d_cbq, s->M, s->NC, s->d_ea_q, s->d_ps, s->d_qcimg, s->stream);
+            s->qimg_version = s->cb_version;
+        } else {
+            HIPCHK(hipMemsetAsync((void*)e2vq::prefilter_fallback_count(s->d_ps), 0, sizeof(int), s->stream));
+        }
+        if (fused) {
+            e2vq::launch_pass_prefiltered(s->NC, false, nullptr, T, nb, nullptr, nullptr, s->d_qcimg, s->d_ps, s->d_cbq,
+                                          s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym, (double*)device_dmin,
+                                          nullptr, s->d_qfblist, nullptr, false, false, s->stream, aos, s->d_ea_q);
+        } else {
+            e2vq::launch_prefilter_quantize_prep(aos, T, nb, s->NC, s->d_ea_q, nullptr, s->d_qfimg, s->d_qfg, s->stream);
+            e2vq::launch_pass_prefiltered(s->NC, false, nullptr, T, nb, s->d_qfimg, s->d_qfg, s->d_qcimg, s->d_ps, s->d_cbq,
+                                          s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym, (double*)device_dmin,
+                                          nullptr, s->d_qfblist, nullptr, false, false, s->stream, aos);
+        }
         e2vq::launch_pass_fallback(s->NC, false, aos, s->d_cbm, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                                    (double*)device_dmin, nullptr, s->d_qfblist, e2vq::prefilter_fallback_count(s->d_ps),
                                    nullptr, false, s->stream, /*rowmajor=*/true);

@@ -419,6 +419,103 @@ __device__ __forceinline__ double pre_exact(const double (&Bft)[2 * ((((NC + 3) 
     return __shfl(v, 16 * (j & 3) + j, 64);  // the lane with q = j & 3 holds the diagonal element of frame j
 }
 
+// ---- quantize, fused (MODE 6 of k_pass_pre): the wave builds the limb images of its 64 frames itself ---------------
+// The 64 row-major frames of block b go to the wave's LDS stage (coalesced 8-byte loads; frames >= T read as zero) and
+// stay there for the exact evaluation after the sweep, so the sweep kernel reads every frame exactly once and no limb
+// image ever travels through HBM (the separate preparation pass wrote and the sweep re-read 228 B per frame).
+// Lane (col = lane & 31, h = lane >> 5) owns the B granules of frames col (column block 0) and 32 + col (column block 1)
+// for lane half h: of the full pairs those are the coefficients n = 16 g + 8 h + e, e = 0..7, with all three limbs --
+// the two halves split the coefficients between them; the R tail coefficients are split by both.  Same scales and the
+// same pre_split as k_pre_quant_prep: identical images.  gq[cb] = sum_n |xi_n| of the frame, rounded up.
+template <int NC>
+__device__ __forceinline__ void pre_build_block(const double* __restrict__ aos, long b, long T, int lane,
+                                                double* __restrict__ stage, const int* __restrict__ eas,
+                                                h8 (&B)[2][PrePack<NC>::PAIRS], float (&gq)[2])
+{
+    typedef PrePack<NC> PK;
+    constexpr int G = PK::G, R = PK::R, NL = PK::NL;
+    const long base = b * 64 * NC, total = T * NC;
+    if ((b + 1) * 64 <= T) {  // (wave-uniform) a full block: LDS-DMA, 1 KB per instruction, no registers involved
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        constexpr int BYTES = 64 * NC * 8, K16 = BYTES / 1024, K4 = (BYTES - K16 * 1024) / 256;
+        static_assert(K16 * 1024 + K4 * 256 == BYTES, "a block of frames is a whole number of 256-byte pieces");
+        const char* g16 = (const char*)(aos + base) + lane * 16;
+        const char* g4 = (const char*)(aos + base) + K16 * 1024 + lane * 4;
+        char* l = (char*)stage;
+#pragma unroll
+        for (int k = 0; k < K16; ++k)
+            __builtin_amdgcn_global_load_lds((gptr_t)(g16 + k * 1024), (lptr_t)(l + k * 1024), 16, 0, 0);
+#pragma unroll
+        for (int k = 0; k < K4; ++k)
+            __builtin_amdgcn_global_load_lds((gptr_t)(g4 + k * 256), (lptr_t)(l + K16 * 1024 + k * 256), 4, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {  // the last, partial block: element by element, frames >= T as zeros
+        for (int i = lane; i < 64 * NC; i += 64) stage[i] = base + i < total ? aos[base + i] : 0.0;
+    }
+    const int col = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        __builtin_amdgcn_sched_barrier(0);  // one frame after the other: interleaved, the two spill ~80 registers
+        const double* row = stage + (32 * cb + col) * NC;
+        constexpr int NV = 8 * G + R;  // the lane's values of this frame: its half of the full pairs, then the tail
+        double x[NV];
+        int sh[NV];                    // -ea[n], then -ea[n] - eA
+        int eA = -100000;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int n = i < 8 * G ? 16 * (i >> 3) + 8 * h + (i & 7) : 16 * G + (i - 8 * G);
+            x[i] = row[n];
+            sh[i] = -eas[n];
+            // ilogb(x) + 1 - ea[n] for x != 0 (v_frexp_exp_i32_f64: denormals included)
+            const int ex = x[i] != 0.0 ? __builtin_amdgcn_frexp_exp(x[i]) + sh[i] : -100000;
+            eA = ex > eA ? ex : eA;
+        }
+        {
+            const int o = __shfl_xor(eA, 32, 64);
+            eA = o > eA ? o : eA;
+        }
+        if (eA == -100000) eA = 0;  // an all-zero frame
+        double gsum = 0.0;
+        _Float16 lim[NL][NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const double xi = ldexp(x[i], sh[i] - eA);
+            if (i < 8 * G || h == 0) gsum += fabs(xi);  // (both halves hold the tail: counted once)
+            const double s1 = xi * 512.0, l1 = __builtin_rint(s1);  // (pre_split, kept in FP64 up to the f16 conversion)
+            const double s2 = (s1 - l1) * 512.0, l2 = __builtin_rint(s2);
+            const double s3 = (s2 - l2) * 512.0, l3 = __builtin_rint(s3);
+            lim[0][i] = (_Float16)(float)l1;
+            lim[1][i] = (_Float16)(float)l2;
+            lim[2][i] = (_Float16)(float)l3;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int fl = 0; fl < NL; ++fl)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) B[cb][fl * G + g][e] = lim[fl][8 * g + e];
+        if constexpr (R > 0) {
+#pragma unroll
+            for (int tp = 0; tp < PK::TAILP; ++tp) {
+                h8 o0 = {0, 0, 0, 0, 0, 0, 0, 0}, o1 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    int fl, n;
+                    PK::slot(NL * G + tp, 0, e, fl, n);
+                    if (n >= 0) o0[e] = lim[fl][8 * G + n - 16 * G];
+                    PK::slot(NL * G + tp, 1, e, fl, n);
+                    if (n >= 0) o1[e] = lim[fl][8 * G + n - 16 * G];
+                }
+                B[cb][NL * G + tp] = h == 0 ? o0 : o1;
+            }
+        }
+        gsum += __shfl_xor(gsum, 32, 64);
+        gq[cb] = (float)gsum * 1.000001f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // One wave = 64 frames, independent of every other wave (no LDS sharing, no barriers): the codeword tile images come
 // straight from L2 (512 KB at M = 1024; 16 B per lane and k-step) -- measured as fast as a workgroup-shared LDS ring
 // (tools/probe/pre_sweep.hip -DDIRECT_L2), and it lets the two waves of a SIMD drift apart so that one sweeps (matrix
@@ -432,9 +529,13 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
                                                   unsigned short* __restrict__ sym, double* __restrict__ dmin,
                                                   i64* __restrict__ rows, int* __restrict__ fb_list, int stagger,
                                                   unsigned short* __restrict__ prev_sym, int incr,
-                                                  const double* __restrict__ aos)
+                                                  const double* __restrict__ aos, const int* __restrict__ ea)
 {
+    // MODE 0: assignment only (limb image from fimg; FP64 frames from blk, or from the row-major payload aos);
+    // MODE 6: assignment only, fused quantize -- limb image AND FP64 frames from the row-major payload aos, through the
+    //         wave's LDS stage (pre_build_block); MODE 2 / 5: accumulate (global atomics / + workgroup LDS table)
     typedef PrePack<NC> PK;
+    constexpr bool QF = MODE == 6, ACC = MODE != 0 && MODE != 6;
     constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2;
     constexpr int NE = 2 * NC + 5, IMG = NE + IMG_STRIDE_PAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -456,13 +557,19 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
     int* img = DEFER ? (int*)smem + wib * (DeferLayout<NC>::BYTES_PER_WAVE / 4)
                      : (int*)(smem + (size_t)lds_cells * RS * 8) + wib * (16 * IMG);
     bool pending = false;  // DEFER: the previous block's images wait in LDS for their atomics
+    double* stage = (double*)smem + wib * (64 * NC);                       // QF: the wave's 64 row-major FP64 frames
+    int* eas = (int*)((double*)smem + (TPBM >> 6) * (64 * NC));            // QF: per-coefficient scale exponents
+    if constexpr (QF) {
+        for (int n = threadIdx.x; n < NC; n += TPBM) eas[n] = ea[n];
+        __syncthreads();
+    }
     if constexpr (MODE == 5) {
         for (int i = threadIdx.x; i < lds_cells * RS; i += TPBM) lacc[i] = 0;
         __syncthreads();
     }
 
     int sh_r = 0, sh_d = 0, sh_d2 = 0;
-    if constexpr (MODE != 0) {
+    if constexpr (ACC) {
         sh_r = sc->sh_r;
         const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
         sh_d = 30 - Ed;
@@ -483,10 +590,15 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
     for (long b = wave; b < nblocks; b += nwaves) {
         // ---- f16 limb images of the wave's 64 frames: B operands, resident for the sweep ----------
         h8 B[2][PK::PAIRS];
+        float gq[2] = {0.f, 0.f};
+        if constexpr (QF) {
+            pre_build_block<NC>(aos, b, T, lane, stage, eas, B, gq);
+        } else {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+            for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int p = 0; p < PK::PAIRS; ++p) B[cb][p] = fimg[((b * 2 + cb) * PK::PAIRS + p) * 64 + lane];
+                for (int p = 0; p < PK::PAIRS; ++p) B[cb][p] = fimg[((b * 2 + cb) * PK::PAIRS + p) * 64 + lane];
+        }
         float k1[2], k2[2], k3[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) k1[cb] = k2[cb] = k3[cb] = __int_as_float(0x7f7fffff);
@@ -611,7 +723,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             const float w3 = med3f(u2, u3, b3);
             // t1 <= u2 <= w3: the three smallest keys of frame 32 cb + (lane & 31)
             const long t = b * 64 + 32 * cb + (lane & 31);
-            const float g = t < T ? fg[t] : 0.f;
+            const float g = QF ? gq[cb] : (t < T ? fg[t] : 0.f);
             const float tau = 1.27f * (512.f * (g + ymax1 + (NC + 4.0f)) + relk * t1);
             cert[cb] = t1 >= 1.0e-30f && t1 < 1.0e37f && w3 > t1 + tau;
             amb[cb] = !(u2 > t1 + tau);  // the runner-up is within reach: it needs the exact evaluation too
@@ -621,7 +733,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 
         // cells of the previous pass (incremental accumulation): loaded here, with the frames, not after the evaluation
         int oldidx[4] = {0, 0, 0, 0};
-        if (MODE != 0 && incr) {
+        if (ACC && incr) {
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft) {
                 const long t = b * 64 + 16 * ft + j;
@@ -631,7 +743,9 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 
         // ---- FP64 frames (MFMA operand layout of k_pass_mfma), exact evaluation of the two candidates -----------
         double Bf[4][2 * NP];
-        if (MODE == 0 && aos)  // quantize: the FP64 frames come straight from the row-major payload
+        if constexpr (QF)  // fused quantize: the frames are still in the wave's LDS stage
+            load_block_frames_stage<NC>(stage, lane, Bf);
+        else if (MODE == 0 && aos)  // quantize: the FP64 frames come straight from the row-major payload
             load_block_frames_rowmajor<NC>(aos, b, T, lane, Bf);
         else
             load_block_frames<NC>(blk, b, lane, Bf);
@@ -706,7 +820,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             const int is = q == 0 ? idx[0] : q == 1 ? idx[1] : q == 2 ? idx[2] : idx[3];
             const bool sk = q == 0 ? skip[0] : q == 1 ? skip[1] : q == 2 ? skip[2] : skip[3];
             if (prev_sym && b * 64 + lane < T && !sk) prev_sym[b * 64 + lane] = (unsigned short)is;
-        } else if constexpr (MODE != 0) {
+        } else if constexpr (ACC) {
             // (MODE 2 has no LDS table, lds_cells = 0; a null table pointer crashes the ROCm 7.2 optimizer: the LDS base)
             accumulate_block<NC, MODE, true, 4, MODE == 2>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2, b, T,
                                                            lane, skip, incr != 0, oldidx);
@@ -790,21 +904,25 @@ void launch_prefilter_frames(const double* blk, long T, long nblocks64, int NC, 
     }
 }
 
-void launch_prefilter_quantize_prep(const double* aos, long T, long nblocks64, int NC, const double* cbq, int M, int* ea,
-                                    double* blk, void* fimg, float* fg, hipStream_t s)
+void launch_prefilter_quantize_prep(const double* aos, long T, long nblocks64, int NC, const int* ea, double* blk,
+                                    void* fimg, float* fg, hipStream_t s)
 {
-    const int NPAD = (NC + 7) & ~7;
-    hipLaunchKernelGGL(k_pre_ea_from_codebook, dim3(1), dim3(1024), 0, s, cbq, M, NC, NPAD, ea);
     switch (NC) {
 #define X(N)                                                                                                        \
     case N:                                                                                                         \
         hipLaunchKernelGGL((k_pre_quant_prep<N>), dim3(pre_grid(nblocks64, 1, 4096)), dim3(256), 0, s, aos, T,      \
-                           nblocks64, (const int*)ea, blk, (h8*)fimg, fg);                                          \
+                           nblocks64, ea, blk, (h8*)fimg, fg);                                          \
         break;
         E2VQ_PRE_NC_LIST(X)
 #undef X
         default: break;
     }
+}
+
+// the per-coefficient scales of quantize alone (fused quantize needs no preparation pass over the frames)
+void launch_prefilter_quantize_scales(const double* cbq, int M, int NC, int* ea, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pre_ea_from_codebook, dim3(1), dim3(1024), 0, s, cbq, M, NC, (NC + 7) & ~7, ea);
 }
 
 const int* prefilter_fallback_count(const void* ps) { return &((const PreScalars*)ps)->fb_count; }
@@ -832,6 +950,10 @@ void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, 
     }
 }
 
+// fused quantize keeps 8 waves x 64 row-major FP64 frames in LDS: P <= 38 (NC = 41 takes the separate preparation pass)
+__host__ __device__ constexpr bool fused_quantize_fits(int NC) { return 8 * 64 * NC * 8 + NC * 4 <= E2VQ_LDS_BYTES; }
+bool prefilter_fused_quantize(int NC) { return pre_has_nc(NC) && fused_quantize_fits(NC) && !getenv("ECOZ2_VQ_QUANTIZE_UNFUSED"); }
+
 // hybrid_table (full accumulation only): cells < mfma_hybrid_cells(NC) accumulate in the workgroup's LDS table.
 // accumulate = false: assignment only.  prev_sym (optional): the cell of every frame is recorded there; with
 // `incremental` the rows must be those of the previous pass over the same frames (distortion elements zeroed) and
@@ -842,7 +964,7 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                                      const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                                      const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym,
                                      double* dmin, long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental,
-                                     bool hybrid_table, hipStream_t s, const double* aos)
+                                     bool hybrid_table, hipStream_t s, const double* aos, const int* ea_fused)
 {
     constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
     constexpr int TPBM = 512;  // 8 waves = 2 per SIMD, one persistent workgroup per CU
@@ -858,7 +980,7 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                                   E2VQ_LDS_BYTES);
         hipLaunchKernelGGL((k_pass_pre<NC, 5, TPBM>), dim3(grid), dim3(TPBM), lds5, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
-                           dmin, rows, fb_list, stagger, prev_sym, 0, (const double*)nullptr);
+                           dmin, rows, fb_list, stagger, prev_sym, 0, (const double*)nullptr, (const int*)nullptr);
     } else if (accumulate) {
         (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 2, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
@@ -869,13 +991,26 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
 #endif
         hipLaunchKernelGGL((k_pass_pre<NC, 2, TPBM>), dim3(grid), dim3(TPBM), lds2, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
-                           dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0, (const double*)nullptr);
+                           dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0, (const double*)nullptr,
+                           (const int*)nullptr);
+    } else if (ea_fused) {  // fused quantize: limb images built in the kernel from the row-major payload
+        if constexpr (fused_quantize_fits(NC)) {
+            const size_t lds6 = (size_t)(TPBM / 64) * 64 * NC * 8 + (size_t)NC * sizeof(int);
+            (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 6, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      E2VQ_LDS_BYTES);
+            hipLaunchKernelGGL((k_pass_pre<NC, 6, TPBM>), dim3(grid), dim3(TPBM), lds6, s, (const double*)nullptr, T, nblocks,
+                               (const h8*)nullptr, (const float*)nullptr, (const h8*)cimg, (PreScalars*)ps, cbq, M / 32,
+                               idxmask, sc, (const u64*)l1max_bits, sym, dmin, rows, fb_list, stagger, prev_sym, 0, aos,
+                               ea_fused);
+        } else {
+            return 1;
+        }
     } else {
         (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 0, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
         hipLaunchKernelGGL((k_pass_pre<NC, 0, TPBM>), dim3(grid), dim3(TPBM), lds, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
-                           dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0, aos);
+                           dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0, aos, (const int*)nullptr);
     }
     return 0;
 }
@@ -884,14 +1019,16 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                             const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                             long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
-                            hipStream_t s, const double* rowmajor_frames)
+                            hipStream_t s, const double* rowmajor_frames, const int* ea_fused)
 {
     if (!prefilter_supports(NC, M) || (hybrid_table && incremental)) return 1;
+    if (ea_fused && (accumulate || !rowmajor_frames || !prefilter_fused_quantize(NC))) return 1;
     switch (NC) {
 #define X(N)                                                                                                          \
     case N:                                                                                                           \
         return launch_pass_prefiltered_t<N>(accumulate, blk, T, nblocks, fimg, fg, cimg, ps, cbq, M, sc, l1max_bits, sym, \
-                                            dmin, rows, fb_list, prev_sym, incremental, hybrid_table, s, rowmajor_frames);
+                                            dmin, rows, fb_list, prev_sym, incremental, hybrid_table, s, rowmajor_frames, \
+                                            ea_fused);
         E2VQ_PRE_NC_LIST(X)
 #undef X
         default: return 1;
