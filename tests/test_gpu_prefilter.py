@@ -295,3 +295,29 @@ def test_prefilter_for_other_prediction_orders(oracle, monkeypatch, Pn):
     _s, _d, rows_o = oracle.run_pass(cq, bad, sh_r, oracle.dist_exponent(cq, st.maxabs))
     assert pre_bad and fb_bad > 0, (pre_bad, fb_bad)
     assert np.array_equal(rows_bad, rows_o), np.argwhere(rows_bad != rows_o)[:10]
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("first,T", [(1, 4097), (3, 64), (5, 63), (2, 1), (7, 12345)])
+def test_device_resident_quantize_at_unaligned_offsets(oracle, monkeypatch, fused, first, T):
+    """e2vq_quantize_device on a slice of a larger device buffer: the slice starts at an odd frame (37 doubles per frame:
+    only 8-byte aligned), sizes ragged around the 64-frame blocks.  The fused kernel stages whole blocks with 16-byte
+    LDS-DMA loads and the last, partial block element by element; both must give the oracle's symbols and distortions."""
+    if not fused:
+        monkeypatch.setenv("ECOZ2_VQ_QUANTIZE_UNFUSED", "1")
+    frames = _frames(20260, first + T + 3)
+    refl = _codebook(oracle, frames[: max(2000, T)] if T > 2000 else _frames(20261, 4000), 256, seed=9)
+    buf = _DeviceBuffer(frames.nbytes)
+    buf.from_host(frames)
+    sym, dmin = _DeviceBuffer(2 * T + 2), _DeviceBuffer(8 * T)
+    with e.VqSession(P) as s:
+        s.set_frames(_frames(20262, 3000))  # (any training set: the session only needs its scale for the prefilter)
+        s.prepare()
+        s.set_codebook(refl)
+        s.quantize_device(buf.ptr.value + first * (P + 1) * 8, T, sym.ptr.value, dmin.ptr.value)
+        s.synchronize()
+    sym_o, dmin_o = oracle.quantize(oracle.reflections_to_cq(refl), frames[first : first + T])
+    assert np.array_equal(sym.to_host(np.uint16)[:T], sym_o)
+    assert np.array_equal(dmin.to_host(np.float64).view(np.uint64), dmin_o.view(np.uint64))
+    for b in (buf, sym, dmin):
+        b.free()
