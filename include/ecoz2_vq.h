@@ -85,6 +85,8 @@ int ecoz2_vq_classify(const char *const *cb_filenames, int num_codebooks,
  *                               and 256 <= M <= 4096, M a multiple of 32)
  *   ECOZ2_VQ_PREFILTER_MIN_M    smallest codebook the prefiltered sweep serves (default 256, at least 64)
  *   ECOZ2_VQ_INCREMENTAL        0 = accumulate in full every pass; ECOZ2_VQ_PLAIN_FIRST 0 = no plain first pass
+ *   ECOZ2_VQ_QUANTIZE_UNFUSED   1 = quantize with a separate preparation pass (limb image through HBM) instead of the
+ *                               fused kernel that builds the limb images of its frames itself (default for P <= 38)
  *   ECOZ2_VQ_OUT_ROOT           prefix for data/... outputs (default ".")               */
 
 /* ========================================================================================
