@@ -742,13 +742,25 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
         }
 
         // ---- FP64 frames (MFMA operand layout of k_pass_mfma), exact evaluation of the two candidates -----------
+#ifdef E2VQ_PRE_ABLATE_BF
+        const float t1seed = k1[0];
+#endif
         double Bf[4][2 * NP];
         if constexpr (QF)  // fused quantize: the frames are still in the wave's LDS stage
             load_block_frames_stage<NC>(stage, lane, Bf);
         else if (MODE == 0 && aos)  // quantize: the FP64 frames come straight from the row-major payload
             load_block_frames_rowmajor<NC>(aos, b, T, lane, Bf);
         else
+#ifdef E2VQ_PRE_ABLATE_BF  // diagnostics only (wrong results): what does the FP64 frame load cost?
+        {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+                for (int st = 0; st < 2 * NP; ++st) Bf[ft][st] = (double)(lane + st) * 1e-3 + (double)t1seed;
+        }
+#else
             load_block_frames<NC>(blk, b, lane, Bf);
+#endif
         double best[4];
         int idx[4];
         bool skip[4];
@@ -775,7 +787,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 #endif
                 idx[ft] = ca[ft];
             }
-#ifndef E2VQ_PRE_ABLATE_VERIFY
+#if !defined(E2VQ_PRE_ABLATE_VERIFY) && !defined(E2VQ_PRE_ABLATE_ROUND2)
             if (two[0] || two[1] || two[2] || two[3]) {
 #pragma unroll
                 for (int ft = 0; ft < 4; ++ft)
