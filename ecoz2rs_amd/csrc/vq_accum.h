@@ -107,7 +107,11 @@ __device__ __forceinline__ void load_block_frames_stage(const double* stage, int
 // is set, a frame whose cell did not change (oldidx == idx) adds only its distortion elements (those are rebuilt
 // every pass); a frame that moved is subtracted from its old cell and added to the new one.  64-bit integer sums
 // are exactly invertible, so the rows equal those of a full accumulation bit for bit -- at a fraction of the atomics.
-template <int NC, int MODE, bool SKIP = false, int NFT = 4, bool INCR = false>
+// DSEP (prefiltered sweep): the four distortion elements of a frame are NOT part of its row image -- the caller sums
+// them per wave in registers and adds them to the distortion columns once at the end (only the column totals of
+// those elements are ever used: the level statistics); a tile of an incremental pass in which no frame moved then has
+// nothing to add at all.
+template <int NC, int MODE, bool SKIP = false, int NFT = 4, bool INCR = false, bool DSEP = false>
 __device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((NC + 3) / 4) + 1) / 2)],
                                                  const double (&best)[4], const int (&idx)[4], int* __restrict__ img,
                                                  i64* __restrict__ lacc, i64* __restrict__ rows, int lds_cells, int sh_r,
@@ -117,8 +121,8 @@ __device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((N
     static_assert(!INCR || MODE == 2, "incremental accumulation goes through global atomics");
     constexpr int NS = (NC + 3) / 4, REM = NC - 4 * (NS - 1);
     constexpr int RS = (2 * NC + 5 + 7) & ~7;
-    constexpr int NE = 2 * NC + 5;
-    constexpr int IMG = NE + IMG_STRIDE_PAD;
+    constexpr int NE = DSEP ? 2 * NC + 1 : 2 * NC + 5;  // elements of a row image that are added
+    constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
     constexpr int HYB_CELLS = mfma_hyb_cells(NC);
     const int q = lane >> 4, j = lane & 15;
 #pragma unroll
@@ -126,6 +130,7 @@ __device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((N
         int* my = img + j * IMG;
         // incremental pass: the limbs are needed only if a frame of this tile changed cell (wave-uniform test)
         const bool limbs = !INCR || !incr || __ballot(oldidx[ft] != idx[ft]) != 0;
+        if (DSEP && !limbs) continue;  // (wave-uniform) nothing moves, and the distortions are the caller's business
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
             if (limbs && (st < NS - 1 || q < REM)) {  // with TAILV only q = 0 writes r[NC-1] (all q lanes hold it)
@@ -135,7 +140,8 @@ __device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((N
                 *(int2*)&my[2 * (4 * st + q)] = make_int2(hi, lo);
             }
         }
-        if (q == 0) {
+        if (q == 0 && DSEP) my[2 * NC] = (SKIP && skip[ft]) ? 0 : 1;
+        if (q == 0 && !DSEP) {
             const double e = (SKIP && skip[ft]) ? 0.0 : best[ft] - 1.0;
             int hi, lo;
             my[2 * NC] = (SKIP && skip[ft]) ? 0 : 1;

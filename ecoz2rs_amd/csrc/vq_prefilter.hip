@@ -536,6 +536,15 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
     //         wave's LDS stage (pre_build_block); MODE 2 / 5: accumulate (global atomics / + workgroup LDS table)
     typedef PrePack<NC> PK;
     constexpr bool QF = MODE == 6, ACC = MODE != 0 && MODE != 6;
+    // the distortion elements of the frames (e, e^2 as limb pairs) are summed per wave in registers and added to the
+    // distortion columns of one row at the end: only the column totals are ever used (level statistics), and per-frame
+    // atomics on those four words were 2^23 per pass, the only ones left for a frame that keeps its cell
+#if defined(E2VQ_PRE_DEFER) || defined(E2VQ_PRE_NO_DSEP)  // (A/B: per-frame atomics on the distortion elements, as in round 1)
+    constexpr bool DSEP = false;
+#else
+    constexpr bool DSEP = ACC;
+#endif
+    i64 dacc[4] = {0, 0, 0, 0};
     constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2;
     constexpr int NE = 2 * NC + 5, IMG = NE + IMG_STRIDE_PAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -833,9 +842,25 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             const bool sk = q == 0 ? skip[0] : q == 1 ? skip[1] : q == 2 ? skip[2] : skip[3];
             if (prev_sym && b * 64 + lane < T && !sk) prev_sym[b * 64 + lane] = (unsigned short)is;
         } else if constexpr (ACC) {
+            if constexpr (DSEP) {
+                if (q == 0) {
+#pragma unroll
+                    for (int ft = 0; ft < 4; ++ft)
+                        if (!skip[ft] && b * 64 + 16 * ft + j < T) {
+                            const double e = best[ft] - 1.0;
+                            int hi, lo;
+                            fix2(e, sh_d, hi, lo);
+                            dacc[0] += hi;
+                            dacc[1] += lo;
+                            fix2(e * e, sh_d2, hi, lo);
+                            dacc[2] += hi;
+                            dacc[3] += lo;
+                        }
+                }
+            }
             // (MODE 2 has no LDS table, lds_cells = 0; a null table pointer crashes the ROCm 7.2 optimizer: the LDS base)
-            accumulate_block<NC, MODE, true, 4, MODE == 2>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2, b, T,
-                                                           lane, skip, incr != 0, oldidx);
+            accumulate_block<NC, MODE, true, 4, MODE == 2, DSEP>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2,
+                                                                 b, T, lane, skip, incr != 0, oldidx);
             // (after the accumulate, which consumed the old cells: the owner lane records the new one)
             const int is = q == 0 ? idx[0] : q == 1 ? idx[1] : q == 2 ? idx[2] : idx[3];
             const bool sk = q == 0 ? skip[0] : q == 1 ? skip[1] : q == 2 ? skip[2] : skip[3];
@@ -845,6 +870,15 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
     if constexpr (DEFER) {  // the last block's images
         if (pending)
             for (int g = 0; g < 16; ++g) accum_drain_group<NC, true>(img, rows, g, incr != 0, lane);
+    }
+    if constexpr (DSEP) {  // the wave's distortion sums -> the distortion columns of one row (any row: totals only)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            i64 v = dacc[k];
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane == 0 && v != 0)
+                atomicAdd((u64*)&rows[(long)(wave % (32 * MT)) * RS + 2 * NC + 1 + k], (u64)v);
+        }
     }
     if constexpr (MODE == 5) {
         __syncthreads();

@@ -153,7 +153,10 @@ int e2vq_sweep_launch_counts(e2vq_session *s, int64_t *prefiltered, int64_t *pla
 int e2vq_update(e2vq_session *s);
 /* one whole LBG iteration in a single call: e2vq_pass + e2vq_pass_stats + e2vq_update */
 int e2vq_iterate(e2vq_session *s, void *device_sym, void *device_dmin, e2vq_level_stats *out);
-/* the reduced accumulator rows of the last pass (M x row_stride int64) copied to the host */
+/* the reduced accumulator rows of the last pass (M x row_stride int64) copied to the host.  Row of a cell: [0, 2 NC) the
+ * limb pairs of its coefficient sums, [2 NC] its frame count, [2 NC + 1, 2 NC + 5) distortion sums (e and e^2 as limb
+ * pairs).  Only the COLUMN TOTALS of the four distortion elements are defined (the level statistics read nothing else):
+ * the prefiltered sweep adds a wave's distortion sums to one row, not frame by frame to the frame's cell. */
 int e2vq_row_stride(int prediction_order);
 int e2vq_get_rows(e2vq_session *s, int64_t *rows);
 

@@ -297,3 +297,15 @@ class HmmOracle:
 
 def load_hmm():
     return HmmOracle()
+
+
+def rows_match(rows, rows_o, P):
+    """GPU cell sums vs the oracle's: the limb sums and the count of every cell word for word; the four distortion
+    elements (sum of e and of e^2 as limb pairs) by their COLUMN TOTALS -- the level statistics are all that ever reads
+    them, and the prefiltered sweep adds each wave's distortion sums to the distortion columns of one row instead of four
+    atomics per frame.  The oracle keeps them per cell; both give the same totals, exactly (integers)."""
+    import numpy as np
+    a, b = np.asarray(rows), np.asarray(rows_o)
+    n = 2 * (P + 1) + 1
+    return (a.shape == b.shape and np.array_equal(a[:, :n], b[:, :n])
+            and np.array_equal(a[:, n:n + 4].sum(axis=0), b[:, n:n + 4].sum(axis=0)))

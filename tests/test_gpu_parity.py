@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 import ecoz2rs_amd as e
+from tests import oracle_lib
 
 pytestmark = pytest.mark.gpu
 
@@ -61,7 +62,7 @@ def test_pass_rows_bit_exact(oracle, T, M):
         ls = s.pass_stats()
         s.update()
         refl_g = s.get_codebook()
-    assert np.array_equal(rows, rows_o)
+    assert oracle_lib.rows_match(rows, rows_o, P)
     assert ls.DD == ls_o.DD and ls.avg_distortion == ls_o.avg and ls.sigma == ls_o.sigma
     assert ls.inertia == ls_o.inertia and ls.empty_cells == ls_o.empty_cells
     assert np.array_equal(refl_g.view(np.uint64), refl_o.view(np.uint64))
@@ -124,7 +125,7 @@ def test_failed_cells_are_counted_like_the_oracle(oracle, Pn):
         s.prepare()
         s.set_codebook(refl)
         s.run_pass()
-        assert np.array_equal(s.get_rows(), rows_o)
+        assert oracle_lib.rows_match(s.get_rows(), rows_o, Pn)
         ls = s.pass_stats()
         s.update()
         refl_g = s.get_codebook()
