@@ -108,6 +108,7 @@ struct e2vq_session {
     i64* d_lstats = nullptr;  // [64 slots][8]: dist, dist2 limbs, empty, failed (slots are summed on the host)
     bool lstats_dirty = false;  // a centroid kernel added to the slots after they were published
     bool stats_valid = false;
+    bool rows_fresh = false;  // d_rows hold the sums of a pass over the codebook that is still the current one
     e2vq_level_stats last{};
     double DDprv = DBL_MAX / 1e5;  // "e+303" in notes.md:128
     // quantize scratch
@@ -349,6 +350,7 @@ extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames
     // whatever happens below, the previous training set is gone: nothing may sweep a stale or null buffer
     s->prepared = false;
     s->stats_valid = false;
+    s->rows_fresh = false;
     s->spec_valid = false;
     s->incr_valid = false;
     s->maxabs_scanned = false;
@@ -466,6 +468,7 @@ static int codebook_prepare(e2vq_session* s, bool redefined = true)
         e2vq::launch_codebook_prepare(s->d_refl, s->M, s->NC, s->d_cbq, s->d_l1max, s->d_cbm, s->stream);
     HIPCHK(hipGetLastError());
     s->stats_valid = false;
+    s->rows_fresh = false;
     s->spec_valid = false;
     return 0;
 }
@@ -678,6 +681,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     HIPCHK(hipGetLastError());
     if (reduce(s, s->d_rows, (i64)s->M * s->RS, 0)) return 1;
     s->stats_valid = false;
+    s->rows_fresh = true;
     s->spec_valid = false;
     s->img_valid[1 - s->img_cur] = false;
     return 0;
@@ -771,6 +775,9 @@ static int pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_fai
         if (out) *out = s->last;
         return 0;
     }
+    // (the distortion sums in the rows are fixed-point numbers scaled for the codebook the pass ran on: after an update
+    // they cannot be read any more)
+    if (!s->rows_fresh) return e2vq_set_error("no statistics: e2vq_pass has not run on the current codebook");
     if (resolve_failed_cells(s)) return 1;  // (of the pass before: long there)
     // (d_lstats is zero here -- zeroed at session start and by every publish kernel -- unless a separate centroid
     // kernel counted failed cells into it afterwards)
@@ -890,6 +897,7 @@ extern "C" int e2vq_update(e2vq_session* s)
     }
     HIPCHK(hipSetDevice(s->device));
     s->cb_version++;
+    s->rows_fresh = false;
     if (s->spec_valid) {  // commit the speculative update: no launch, just swap the codebook sets
         std::swap(s->d_refl, s->d_refl_spec);
         std::swap(s->d_cbq, s->d_cbq_spec);

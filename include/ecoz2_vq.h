@@ -135,7 +135,10 @@ int e2vq_init_codebook(e2vq_session *s); /* M = 1 centroid of the whole set */
 int e2vq_grow(e2vq_session *s);          /* M -> 2M split                   */
 
 /* one LBG iteration, in pieces: assignment+accumulation (+ all-reduce), statistics, update.
- * device_sym / device_dmin: optional device buffers of T uint16 / T doubles (NULL to skip). */
+ * device_sym / device_dmin: optional device buffers of T uint16 / T doubles (NULL to skip).
+ * e2vq_pass_stats and e2vq_update work from the rows of the last e2vq_pass over the CURRENT codebook: once an update (or
+ * e2vq_set_codebook / e2vq_grow) has changed the codebook they fail until the next pass (the distortion sums in the rows
+ * are fixed-point numbers scaled for the codebook the pass ran on). */
 int e2vq_pass(e2vq_session *s, void *device_sym, void *device_dmin);
 int e2vq_pass_stats(e2vq_session *s, e2vq_level_stats *out);
 /* HIP events around the sweep kernel of e2vq_pass, on the session's stream */

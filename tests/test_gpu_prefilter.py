@@ -323,3 +323,33 @@ def test_device_resident_quantize_at_unaligned_offsets(oracle, monkeypatch, fuse
     assert np.array_equal(dmin.to_host(np.float64).view(np.uint64), dmin_o.view(np.uint64))
     for b in (buf, sym, dmin):
         b.free()
+
+
+@pytest.mark.parametrize("M", [64, 256])
+def test_statistics_need_a_pass_on_the_current_codebook(oracle, monkeypatch, M):
+    """The distortion sums in the rows are fixed-point numbers scaled for the codebook the pass ran on: once e2vq_update
+    has committed a new codebook, e2vq_pass_stats / e2vq_update must refuse to work from the stale rows (they used to
+    recompute statistics with the wrong scale), and the next pass must give the oracle's rows again."""
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
+    frames = _frames(20264, 9000)
+    refl = _codebook(oracle, frames, M, seed=12)
+    rc, st = oracle.data_stats(frames)
+    sh_r, sh_q = oracle.shifts(st.maxabs)
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.set_codebook(refl)
+        with pytest.raises(RuntimeError, match="has not run"):
+            s.pass_stats()  # nothing has run yet
+        s.run_pass()
+        ls1 = s.pass_stats()
+        assert s.pass_stats().DD == ls1.DD  # (cached)
+        s.update()
+        with pytest.raises(RuntimeError, match="has not run"):
+            s.pass_stats()
+        with pytest.raises(RuntimeError, match="has not run"):
+            s.update()
+        cq = oracle.reflections_to_cq(oracle.update(_oracle_pass(oracle, frames, refl)[2], P, sh_r, refl)[0])
+        _sym, _dmin, rows_o = oracle.run_pass(cq, frames, sh_r, oracle.dist_exponent(cq, st.maxabs))
+        s.run_pass()
+        assert oracle_lib.rows_match(s.get_rows(), rows_o, P)
