@@ -836,10 +836,12 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
         if (lane == 0)
             __hip_atomic_store((u64*)&within[m], (u64)__double_as_longlong(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (pub.flags) {
-            // this cell's statistics are out: once the atomics and the store above have been performed (s_waitcnt; an
-            // agent-scope release fence would also write the whole L2 back, and a thousand of those queue up for tens
-            // of microseconds) the publisher may count the cell in
+            // this cell's statistics are out: once the atomics and the store above have been performed the publisher may
+            // count the cell in.  The wait is spelled out: a workgroup-scope release fence emits none (stores of one wave
+            // to different addresses may land in any order at the memory side), and an agent-scope one would also write
+            // the whole L2 back -- a thousand of those queue up for tens of microseconds
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0)
                 __hip_atomic_store(&pub.flags[m], (unsigned int)pub.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -889,6 +891,7 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
 #ifndef E2VQ_CU_NOLATE
         if (pub.flags && rows) {  // whether this cell's recursion failed is known (and counted)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0)
                 __hip_atomic_store(&pub.flags[M + m], (unsigned int)pub.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
