@@ -1342,7 +1342,9 @@ static int upload_predictors(e2vq_session* s, const PrdSet& ps, i64 lo, i64 hi)
             while (ps.first[(size_t)file + 1] <= t0 + got) ++file;
             const i64 in_file = t0 + got - ps.first[(size_t)file];
             const i64 take = std::min(n - got, ps.first[(size_t)file + 1] - (t0 + got));
-            if (e2vq_io::prd_read_range(ps.files[file], ps.P, in_file, take, r.h[k] + (size_t)got * NC)) return 1;
+            if (e2vq_io::prd_read_range_mt(ps.files[file], ps.P, in_file, take, r.h[k] + (size_t)got * NC,
+                                           e2vq_io::io_threads()))
+                return 1;
             got += take;
         }
         HIPCHK(hipMemcpyAsync(r.d + (size_t)(t0 - lo) * NC, r.h[k], (size_t)n * NC * 8, hipMemcpyHostToDevice, r.st));
@@ -1587,9 +1589,10 @@ int quantize_worker(int device, int w, int W, int P, int M, const double* refl, 
         }
         rc = q.ensure(T, NC);
         if (rc) break;
-        rc = e2vq_prd_read(files[i], q.h_frames, T);
+        bool finite = true;
+        rc = e2vq_io::prd_read_range_mt(files[i], P, 0, T, q.h_frames, e2vq_io::io_threads(), &finite);
         if (rc) break;
-        if (!all_finite(q.h_frames, (size_t)T * NC)) {
+        if (!finite) {
             rc = e2vq_set_error("%s: contains NaN or infinite values", files[i]);
             break;
         }

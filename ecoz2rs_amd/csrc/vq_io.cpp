@@ -18,9 +18,11 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <cmath>
 #include <fstream>
 #include <sstream>
 #include <thread>
+#include <vector>
 
 namespace e2vq_io {
 
@@ -246,6 +248,57 @@ int e2vq_io::prd_read_range(const char* path, int P, int64_t first, int64_t coun
     if (!rc && fread(frames, row, (size_t)count, f) != (size_t)count) rc = e2vq_set_error("%s: truncated payload", path);
     fclose(f);
     return rc;
+}
+
+// the same range read by up to `threads` threads (page-cache reads run at ~10 GB/s per thread, PCIe at ~50 GB/s: one
+// reader thread per GPU starves the upload).  finite (optional): set to false if any value read is NaN / infinite.
+int e2vq_io::prd_read_range_mt(const char* path, int P, int64_t first, int64_t count, double* frames, int threads,
+                               bool* finite)
+{
+    const size_t row = (size_t)(P + 1) * sizeof(double);
+    const int64_t min_rows = std::max<int64_t>(1, (int64_t)((8u << 20) / row));  // at least 8 MB per thread
+    int n = (int)std::min<int64_t>(std::max(1, threads), (count + min_rows - 1) / min_rows);
+    if (n < 1) n = 1;
+    std::vector<int> rcs((size_t)n, 0);
+    std::vector<char> fin((size_t)n, 1);
+    std::vector<std::string> errs((size_t)n);
+    auto piece = [&](int k) {
+        const int64_t a = count * k / n, b = count * (k + 1) / n;
+        if (b <= a) return;
+        rcs[(size_t)k] = prd_read_range(path, P, first + a, b - a, frames + (size_t)a * (P + 1));
+        if (rcs[(size_t)k]) {
+            errs[(size_t)k] = e2vq_last_error();  // (thread-local: handed to the calling thread below)
+            return;
+        }
+        if (finite) {
+            const double* v = frames + (size_t)a * (P + 1);
+            const size_t m = (size_t)(b - a) * (P + 1);
+            bool ok = true;
+            for (size_t i = 0; i < m; ++i) ok &= std::isfinite(v[i]);
+            fin[(size_t)k] = ok;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < n; ++k) th.emplace_back(piece, k);
+    piece(0);
+    for (auto& t : th) t.join();
+    for (int k = 0; k < n; ++k)
+        if (rcs[(size_t)k]) return e2vq_set_error("%s", errs[(size_t)k].empty() ? "read failed" : errs[(size_t)k].c_str());
+    if (finite) {
+        *finite = true;
+        for (int k = 0; k < n; ++k) *finite = *finite && fin[(size_t)k];
+    }
+    return 0;
+}
+
+int e2vq_io::io_threads()
+{
+    static const int n = [] {
+        const char* e = getenv("ECOZ2_VQ_IO_THREADS");
+        const int v = e ? atoi(e) : 4;
+        return v < 1 ? 1 : (v > 64 ? 64 : v);
+    }();
+    return n;
 }
 
 extern "C" int e2vq_prd_write(const char* path, const char* class_name, int P, const double* frames, int64_t T)

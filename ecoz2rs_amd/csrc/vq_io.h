@@ -19,4 +19,8 @@ int files_from_csv(const std::string& csv, const std::string& tt, const std::str
                    std::vector<std::string>& out);
 // frames [first, first + count) of a .prd file whose header has been validated by e2vq_prd_info
 int prd_read_range(const char* path, int P, int64_t first, int64_t count, double* frames);
+// ... by up to `threads` reader threads; *finite (optional) = no NaN / infinite value among them
+int prd_read_range_mt(const char* path, int P, int64_t first, int64_t count, double* frames, int threads,
+                      bool* finite = nullptr);
+int io_threads();  // ECOZ2_VQ_IO_THREADS (default 4): reader threads per rank / worker
 }  // namespace e2vq_io
