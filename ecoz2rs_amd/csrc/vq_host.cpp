@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -1326,6 +1327,15 @@ static int upload_predictors(e2vq_session* s, const PrdSet& ps, i64 lo, i64 hi)
             if (st) (void)hipStreamDestroy(st);
         }
     } r;
+    static const bool timing = getenv("ECOZ2_VQ_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tl = now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const double t1 = now();
+        fprintf(stderr, "[ecoz2 vq learn]   upload: %-22s %8.1f ms\n", what, (t1 - tl) * 1e3);
+        tl = t1;
+    };
     const i64 CH = std::min<i64>(T, 1 << 18);  // 78 MB of predictor vectors per chunk at P = 36
     HIPCHK(hipMalloc(&r.d, (size_t)T * NC * 8));
     HIPCHK(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
@@ -1333,6 +1343,7 @@ static int upload_predictors(e2vq_session* s, const PrdSet& ps, i64 lo, i64 hi)
         HIPCHK(hipHostMalloc(&r.h[k], (size_t)CH * NC * 8, hipHostMallocDefault));
         HIPCHK(hipEventCreateWithFlags(&r.ev[k], hipEventDisableTiming));
     }
+    lap("allocations");
     int file = (int)(std::upper_bound(ps.first.begin(), ps.first.end(), lo) - ps.first.begin()) - 1;
     int k = 0;
     for (i64 t0 = lo; t0 < hi; t0 += CH, k ^= 1) {
@@ -1351,7 +1362,10 @@ static int upload_predictors(e2vq_session* s, const PrdSet& ps, i64 lo, i64 hi)
         HIPCHK(hipEventRecord(r.ev[k], r.st));
     }
     HIPCHK(hipStreamSynchronize(r.st));
-    return e2vq_set_frames_device(s, r.d, T);  // (synchronises: the row-major copy can go)
+    lap("read + H2D");
+    const int rc = e2vq_set_frames_device(s, r.d, T);  // (synchronises: the row-major copy can go)
+    lap("re-layout + images");
+    return rc;
 }
 
 // one rank of a learn: session on `device`, frames [lo, hi) of the training set.
@@ -1360,15 +1374,29 @@ static int learn_rank(int device, double eps, const char* class_name, const doub
                       const PrdSet& ps, i64 lo, i64 hi, LocalRank* lr, int world, void* target,
                       ecoz2_vq_learn_callback_t cb)
 {
+    // ECOZ2_VQ_TIMING=1: wall time of the stages of a rank on stderr (diagnostics)
+    static const bool timing = getenv("ECOZ2_VQ_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const double t1 = now();
+        fprintf(stderr, "[ecoz2 vq learn, rank %d] %-28s %8.1f ms\n", lr ? lr->rank : 0, what, (t1 - t0) * 1e3);
+        t0 = t1;
+    };
     e2vq_session* s = nullptr;
     int rc = e2vq_session_create(device, ps.P, &s);
     if (!rc && lr) rc = e2vq_set_allreduce(s, local_allreduce, lr, lr->rank, world);
+    lap("session");
     if (!rc) rc = upload_predictors(s, ps, lo, hi);
+    lap("read + upload + re-layout");
     if (!rc) rc = e2vq_prepare(s);
     if (!rc) rc = base_refl ? e2vq_set_codebook(s, base_refl, base_M) : e2vq_init_codebook(s);
+    lap("statistics, first codebook");
     if (!rc)
         rc = e2vq_learn(s, eps, env_int("ECOZ2_VQ_MAX_CODEBOOK_SIZE", 2048), class_name,
                         env_str("ECOZ2_VQ_OUT_ROOT", "."), target, cb, nullptr, 0, nullptr);
+    lap("LBG ladder (+ files)");
     if (rc && lr) lr->g->fail();
     if (s) e2vq_session_destroy(s);
     return rc;

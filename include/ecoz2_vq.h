@@ -88,6 +88,7 @@ int ecoz2_vq_classify(const char *const *cb_filenames, int num_codebooks,
  *   ECOZ2_VQ_QUANTIZE_UNFUSED   1 = quantize with a separate preparation pass (limb image through HBM) instead of the
  *                               fused kernel that builds the limb images of its frames itself (default for P <= 38)
  *   ECOZ2_VQ_IO_THREADS         reader threads per rank / worker for the .prd payloads (default 4)
+ *   ECOZ2_VQ_TIMING             wall time of the stages of ecoz2_vq_learn on stderr (diagnostics)
  *   ECOZ2_VQ_OUT_ROOT           prefix for data/... outputs (default ".")               */
 
 /* ========================================================================================
