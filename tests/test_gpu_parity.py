@@ -131,3 +131,37 @@ def test_failed_cells_are_counted_like_the_oracle(oracle, Pn):
         refl_g = s.get_codebook()
     assert ls.failed_cells == failed_o
     assert np.array_equal(refl_g.view(np.uint64), refl_o.view(np.uint64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,T", [(8192, 30000), (65536, 20000)])
+def test_large_codebooks_statistics_and_update(oracle, M, T):
+    """Codebooks far beyond the ladder's usual sizes (the API takes M <= 65536): k_cell_update then runs more workgroups
+    than the chip holds at once (M / 4 + 1, the last one publishing the statistics once every cell has raised its flag),
+    most cells are empty and keep their codeword.  Rows, statistics and the updated codebook against the oracle."""
+    frames = e.synth.synth_frames(777, 20, P, 0, T)
+    rng = np.random.default_rng(M)
+    rc, st = oracle.data_stats(frames)
+    sh_r, sh_q = oracle.shifts(st.maxabs)
+    rc, levels, _cb = oracle.learn(frames[:6000], 0.05, 64)
+    refl = np.tile(levels[-1]["reflections"], (M // 64, 1)) * (1.0 + 1e-3 * rng.standard_normal((M, 1)))
+    refl[:, 0] = 0.0
+    refl = np.clip(refl, -0.999, 0.999)
+    cq = oracle.reflections_to_cq(refl)
+    Ed = oracle.dist_exponent(cq, st.maxabs)
+    _sym, _dmin, rows_o = oracle.run_pass(cq, frames, sh_r, Ed)
+    ls_o = oracle.rows_stats(rows_o, P, T, sh_r, Ed, oracle.unfix(st.q_hi, st.q_lo, sh_q))
+    refl_o, failed_o = oracle.update(rows_o, P, sh_r, refl)
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.set_codebook(refl)
+        s.run_pass()
+        rows = s.get_rows()
+        ls = s.pass_stats()
+        s.update()
+        cb = s.get_codebook()
+    assert oracle_lib.rows_match(rows, rows_o, P)
+    assert (ls.DD, ls.sigma, ls.inertia, ls.empty_cells, ls.failed_cells) == (ls_o.DD, ls_o.sigma, ls_o.inertia, ls_o.empty_cells, failed_o)
+    assert ls.empty_cells > M // 2
+    assert np.array_equal(cb.view(np.uint64), refl_o.view(np.uint64))
