@@ -13,6 +13,8 @@ resident in HBM before the timed region.  Weak scaling: S = 2^21 frames per GPU 
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...       (no launcher: the parent starts the N ranks itself as fresh child processes,
+                                        before it has made any GPU call, and relays rank 0's JSON line)
 """
 import argparse
 import json
@@ -115,6 +117,32 @@ def cpu_baseline(e, np):
     }
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (never an exec; this
+    parent has made no GPU call), one per GPU -- LOCAL_RANK modulo the device count inside the child, so that a
+    1-GPU box can rehearse N ranks with --backend gloo --, wait for all of them, relay rank 0's stdout (the JSON line)
+    and exit non-zero if any rank did."""
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit(f"bench.py: rank(s) failed: {bad}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +156,8 @@ def main():
                     "gloo lets several ranks share one GPU when rehearsing the N > 1 path)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     if args.no_prefilter:
         os.environ["ECOZ2_VQ_PREFILTER"] = "0"
     import numpy as np
@@ -158,8 +188,17 @@ def main():
 
     sess = e.VqSession(P, device=local)
     parallel.bind_torch_stream(sess, local)  # session kernels + RCCL collectives on one torch stream
+    ar_calls = {"n": 0, "bytes": 0, "max_bytes": 0}
     if world > 1:
-        sess.set_allreduce(parallel.make_allreduce(local), rank, world)
+        inner = parallel.make_allreduce(local)
+
+        def counted(ptr, count, op, stream):
+            ar_calls["n"] += 1
+            ar_calls["bytes"] += 8 * count
+            ar_calls["max_bytes"] = max(ar_calls["max_bytes"], 8 * count)
+            inner(ptr, count, op, stream)
+
+        sess.set_allreduce(counted, rank, world)
     sess.set_frames(frames)  # H2D + blocked re-layout; resident from here on
     del frames
     sess.prepare()
@@ -211,6 +250,7 @@ def main():
     sess.enable_timing(True)  # HIP events around the sweep kernel of every pass, summed inside the library
     fence()
     launches_before = sess.sweep_launch_counts()
+    ar_before = dict(ar_calls)
     t0 = time.perf_counter()
     steps_left = args.steps
     while steps_left >= L:
@@ -221,13 +261,36 @@ def main():
         st = leading_passes(steps_left)
     fence()
     dt = time.perf_counter() - t0
+    ar_timed = {k: ar_calls[k] - ar_before[k] for k in ("n", "bytes")}
     kernel_ms_total, kernel_passes = sess.timing_total()
     assert kernel_passes == args.steps, (kernel_passes, args.steps)
     prefiltered, fallback_frames = sess.last_pass_info()
+    collective = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        if args.backend != "nccl":
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        devs = [None] * world
+        dist.all_gather_object(devs, local)
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version()) if args.backend == "nccl" else None
+        except Exception:
+            rccl = None
+        collective = {
+            "backend": args.backend + (" (RCCL over xGMI)" if args.backend == "nccl" else " (host-staged rehearsal)"),
+            "world_size": world,
+            "devices_per_rank": 1,
+            "device_of_rank": devs,
+            "distinct_devices": len(set(devs)),
+            "allreduce_calls": ar_timed["n"],
+            "allreduce_calls_per_step": ar_timed["n"] / max(1, args.steps),
+            "bytes_per_call": ar_calls["max_bytes"],
+            "bytes_timed_region": ar_timed["bytes"],
+            "dtype": "int64 sum (exact: any rank count gives the same bits)",
+            "rccl_version": rccl,
+        }
 
     # ---- steady state (informational): back-to-back iterations on the converged M = 1024 codebook, where the
     # incremental accumulate has almost nothing left to move -- round 1's headline regime, kept as an extra key
@@ -356,6 +419,7 @@ def main():
                 "prediction_order": P,
                 "passes_per_level": L,
                 "parallelism": f"frames sharded over {world} rank(s); int64 all-reduce of cell sums per iteration",
+                "collective": collective,
                 "sweep": "prefiltered (exact f16-limb prefilter + FP64 verification; bit-identical to the plain sweep)"
                          if prefiltered else "plain FP64 MFMA sweep",
                 "ladder_seconds_untimed": round(t_ladder, 3),

@@ -52,6 +52,7 @@ _sig("ecoz2_vq_learn_using_base_codebook", C.c_int, C.c_char_p, C.c_double, c_ch
      LEARN_CALLBACK)
 _sig("ecoz2_vq_quantize", C.c_int, C.c_char_p, c_char_pp, C.c_int, C.c_int)
 _sig("ecoz2_vq_show", C.c_int, C.c_char_p, C.c_int, C.c_int)
+_sig("ecoz2_prd_show_file", C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int)
 _sig("ecoz2_vq_classify", C.c_int, c_char_pp, C.c_int, c_char_pp, C.c_int, C.c_int)
 
 # Part 2: session API

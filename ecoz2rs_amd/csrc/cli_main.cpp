@@ -32,7 +32,7 @@ static int usage()
             "  ecoz2 vq classify [-r] --codebooks <files|dirs>... --tt <TRAIN|TEST> --predictors <files|dirs|tt.csv>...\n"
             "  ecoz2 vq show [-f <from>] [-t <to>] <codebook>\n"
             "  ecoz2 seq show [-c] [-L] [--full] [--pickle out.pkl -M <M> --tt <TRAIN|TEST> [--class-name c]] <file.seq|tt.csv>...\n"
-            "  ecoz2 prd show [--from a] [--to b] <file.prd>\n"
+            "  ecoz2 prd show [-k] [--from a] [--to b] <file.prd>\n"
             "  ecoz2 {nb|mm} learn -M <M> [--class-name <class>] <file.seq|dirs|tt.csv>...\n"
             "  ecoz2 {nb|mm} classify -M <M> [-r] --tt <TRAIN|TEST> --models <files|dirs>... --sequences <files|dirs|tt.csv>...\n"
             "  ecoz2 {nb|mm} show --model <file>\n"
@@ -295,33 +295,22 @@ static int seq_show(int argc, char** argv)
     return 0;
 }
 
-// `ecoz2 prd show [--from a] [--to b] <file>`: header line + coefficient range, as in notes.md:77-85
+// `ecoz2 prd show [-k|--reflections] [-f|--from a] [-t|--to b] <file>` (options: src/prd/mod.rs:30-62; from defaults to 1,
+// to = 0 means P) -> ecoz2_prd_show_file, the symbol the reference binds (src/ecoz2_lib/mod.rs:89-94, src/prd/mod.rs:99)
 static int prd_show(int argc, char** argv)
 {
-    int from = 0, to = -1;
+    int from = 1, to = 0, refl = 0;
     std::string file;
     for (int i = 0; i < argc; ++i) {
         const std::string a = argv[i];
-        if (a == "--from" && i + 1 < argc) from = atoi(argv[++i]);
-        else if (a == "--to" && i + 1 < argc) to = atoi(argv[++i]);
+        if ((a == "--from" || a == "-f") && i + 1 < argc) from = atoi(argv[++i]);
+        else if ((a == "--to" || a == "-t") && i + 1 < argc) to = atoi(argv[++i]);
+        else if (a == "-k" || a == "--reflections") refl = 1;
         else if (!is_flag(argv[i])) file = a;
         else return usage();
     }
     if (file.empty()) return usage();
-    char cls[96];
-    int P;
-    int64_t T;
-    if (e2vq_prd_info(file.c_str(), cls, &P, &T)) return 0;
-    std::vector<double> fr((size_t)T * (P + 1));
-    if (e2vq_prd_read(file.c_str(), fr.data(), T)) return 0;
-    if (to < 0 || to > P) to = P;
-    printf("# %s:\n# className='%s', T=%lld, P=%d\n", file.c_str(), cls, (long long)T, P);
-    for (int n = from; n <= to; ++n) printf("%sr%d", n == from ? "" : ",", n);
-    printf("\n");
-    for (int64_t t = 0; t < T; ++t) {
-        for (int n = from; n <= to; ++n) printf("%s%.5f", n == from ? "" : ",", fr[(size_t)t * (P + 1) + n]);
-        printf("\n");
-    }
+    ecoz2_prd_show_file(file.c_str(), refl, from, to);
     return 0;
 }
 

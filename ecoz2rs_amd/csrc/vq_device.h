@@ -58,7 +58,12 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                             const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                             long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
-                            hipStream_t s, const double* rowmajor_frames = nullptr, const int* ea_fused = nullptr);
+                            hipStream_t s, const double* rowmajor_frames = nullptr, const int* ea_fused = nullptr,
+                            const double* resident_rowmajor = nullptr);
+// resident_rowmajor (accumulating passes): a row-major copy of the training frames padded with zero rows to whole
+// 64-frame blocks; with it (and prefilter_lds_stage(NC)) the pass runs k_pass_pre_lds; prev_sym must then be padded
+// by 128 bytes
+bool prefilter_lds_stage(int NC);
 // fused quantize (ea_fused != nullptr, assignment only): no frame image at all -- the sweep builds the limb images of
 // its frames from rowmajor_frames with the per-coefficient scales ea_fused (launch_prefilter_quantize_scales)
 bool prefilter_fused_quantize(int NC);

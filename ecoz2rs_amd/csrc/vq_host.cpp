@@ -73,6 +73,7 @@ struct e2vq_session {
     hipStream_t own_stream = nullptr, stream = nullptr;
     // training set (blocked layout)
     double* d_blk = nullptr;
+    double* d_aos = nullptr;  // row-major copy padded with zero rows to whole blocks (k_pass_pre_lds stages it in LDS)
     i64 T = 0, nblocks = 0, T_total = 0;
     bool prepared = false;
     bool maxabs_scanned = false;  // d_maxabs / d_flags hold this rank's scan from the re-layout kernel
@@ -293,7 +294,7 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* ptrs[] = {s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
+    void* ptrs[] = {s->d_aos, s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
                     s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg2[0], s->d_cimg2[1], s->d_ps2[0], s->d_ps2[1], s->d_ps, s->d_fblist, s->d_prev_sym, s->d_rows_local,
                     s->d_ea_q, s->d_qfimg, s->d_qfg, s->d_qfblist, s->d_qcimg};
@@ -374,23 +375,39 @@ extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames
         if (s->d_fg) HIPCHK(hipFree(s->d_fg));
         if (s->d_fblist) HIPCHK(hipFree(s->d_fblist));
         if (s->d_prev_sym) HIPCHK(hipFree(s->d_prev_sym));
+        if (s->d_aos) HIPCHK(hipFree(s->d_aos));
+        s->d_aos = nullptr;
         s->d_prev_sym = nullptr;
         s->d_fimg = nullptr;
         s->d_fg = nullptr;
         s->d_fblist = nullptr;
         // 234 B per frame beside the 296 B of the blocked frames.  If the device cannot hold them, the session
         // simply keeps to the plain FP64 sweep (same results): use_prefilter() looks at d_fimg.
+        // (prev_sym: + 256 B, k_pass_pre_lds fetches the 64 cells of a block as 64 dwords)
         const bool fits = hipMalloc(&s->d_fimg, e2vq::prefilter_frame_image_bytes(s->NC, s->nblocks)) == hipSuccess &&
                           hipMalloc(&s->d_fg, (size_t)s->nblocks * 64 * sizeof(float)) == hipSuccess &&
                           hipMalloc(&s->d_fblist, (size_t)s->nblocks * 64 * sizeof(int)) == hipSuccess &&
-                          hipMalloc(&s->d_prev_sym, (size_t)s->nblocks * 64 * sizeof(unsigned short)) == hipSuccess;
+                          hipMalloc(&s->d_prev_sym, (size_t)s->nblocks * 64 * sizeof(unsigned short) + 256) == hipSuccess;
+        // the accumulating prefiltered pass stages the FP64 frames of a block in LDS from a row-major copy (another 296 B
+        // per frame; without it the pass keeps to the round-2 kernel, which reads the blocked layout)
+        if (fits && e2vq::prefilter_lds_stage(s->NC)) {
+            const size_t rows = (size_t)s->nblocks * 64, have = (size_t)T;
+            if (hipMalloc(&s->d_aos, rows * s->NC * 8) == hipSuccess) {
+                HIPCHK(hipMemcpyAsync(s->d_aos, device_frames, have * s->NC * 8, hipMemcpyDeviceToDevice, s->stream));
+                if (rows > have) HIPCHK(hipMemsetAsync(s->d_aos + have * s->NC, 0, (rows - have) * s->NC * 8, s->stream));
+                HIPCHK(hipMemsetAsync(s->d_fg, 0, (size_t)s->nblocks * 64 * sizeof(float), s->stream));
+            } else {
+                (void)hipGetLastError();
+                s->d_aos = nullptr;
+            }
+        }
         if (fits) {
             e2vq::launch_prefilter_frames(s->d_blk, T, s->nblocks, s->NC, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg,
                                           s->stream);
             HIPCHK(hipGetLastError());
         } else {
             (void)hipGetLastError();  // clear the out-of-memory status
-            for (void** p : {(void**)&s->d_fimg, (void**)&s->d_fg, (void**)&s->d_fblist, (void**)&s->d_prev_sym}) {
+            for (void** p : {(void**)&s->d_fimg, (void**)&s->d_fg, (void**)&s->d_fblist, (void**)&s->d_prev_sym, (void**)&s->d_aos}) {
                 if (*p) (void)hipFree(*p);
                 *p = nullptr;
             }
@@ -652,7 +669,8 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, d_cimg, d_ps,
                                       s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                                       (double*)device_dmin, rows, s->d_fblist, keep ? s->d_prev_sym : nullptr,
-                                      incremental, /*hybrid_table=*/mode == 5 && !incremental, s->stream);
+                                      incremental, /*hybrid_table=*/mode == 5 && !incremental, s->stream, nullptr, nullptr,
+                                      s->d_aos);
         if (s->timing) {
             HIPCHK(hipEventRecord(s->ev1, s->stream));
             s->timed = true;

@@ -391,6 +391,69 @@ extern "C" int e2vq_seq_write(const char* path, const char* class_name, int M, c
 // step-up k -> a, inverse Levinson with r0 = 1, then divide by E_P (src/lpc/lpc_rs.rs:125-131).
 // Counter based: frame t depends only on (seed, n_classes, P, t).
 // ------------------------------------------------------------------------------------------
+// ---- prd show ---------------------------------------------------------------------------------------------------
+// replaces `fn ecoz2_prd_show_file(prd_filename, show_reflections, from, to)` (src/ecoz2_lib/mod.rs:89-94; caller
+// src/prd/mod.rs:99, options :30-62: from defaults to 1, to = 0 means "up to P").  Output as in notes.md:77-85: a
+// `# <file>:` line, `# className='..', T=.., P=..`, the column names r<from>..r<to> (k<..> for reflections), then one
+// line of %.5f values per vector.  Reflections come from the Levinson recursion on the vector's autocorrelation,
+// restated from src/lpc/lpca_r_rs.rs:8-43 (status 1: r0 == 0, 2: prediction error <= 0; such rows print zeros).
+static int host_lpca_r(int P, const double* r, double* rc, double* a)
+{
+    const double r0 = r[0];
+    if (0.0 == r0) return 1;
+    double pe = r0;
+    a[0] = 1.0;
+    for (int k = 1; k <= P; ++k) {
+        double sum = 0.0;
+        for (int i = 1; i <= k; ++i) sum -= a[k - i] * r[i];
+        const double akk = sum / pe;
+        rc[k] = akk;
+        a[k] = akk;
+        for (int i = 1; i <= (k >> 1); ++i) {
+            const double ai = a[i], aj = a[k - i];
+            a[i] = ai + akk * aj;
+            a[k - i] = aj + akk * ai;
+        }
+        pe *= 1.0 - akk * akk;
+        if (pe <= 0.0) return 2;
+    }
+    return 0;
+}
+
+extern "C" int ecoz2_prd_show_file(const char* prd_filename, int show_reflections, int from, int to)
+{
+    if (!prd_filename) return e2vq_set_error("ecoz2_prd_show_file: bad arguments");
+    char cls[96];
+    int P;
+    int64_t T;
+    if (e2vq_prd_info(prd_filename, cls, &P, &T)) return 1;
+    if (to <= 0 || to > P) to = P;
+    if (from < 0) from = 0;
+    printf("# %s:\n# className='%s', T=%lld, P=%d\n", prd_filename, cls, (long long)T, P);
+    const char* name = show_reflections ? "k" : "r";
+    for (int n = from; n <= to; ++n) printf("%s%s%d", n == from ? "" : ",", name, n);
+    printf("\n");
+    const int NC = P + 1;
+    const int64_t CH = 4096;  // vectors per read
+    std::vector<double> fr((size_t)std::min<int64_t>(CH, std::max<int64_t>(T, 1)) * NC), rc((size_t)NC), a((size_t)NC);
+    for (int64_t t0 = 0; t0 < T; t0 += CH) {
+        const int64_t n = std::min(CH, T - t0);
+        if (e2vq_io::prd_read_range(prd_filename, P, t0, n, fr.data())) return 1;
+        for (int64_t t = 0; t < n; ++t) {
+            const double* v = fr.data() + (size_t)t * NC;
+            if (show_reflections) {
+                std::fill(rc.begin(), rc.end(), 0.0);
+                if (host_lpca_r(P, v, rc.data(), a.data()) != 0) std::fill(rc.begin(), rc.end(), 0.0);
+                v = rc.data();
+            }
+            for (int k = from; k <= to; ++k) printf("%s%.5f", k == from ? "" : ",", v[k]);
+            printf("\n");
+        }
+    }
+    fflush(stdout);
+    return 0;
+}
+
 namespace {
 
 inline uint64_t splitmix64(uint64_t x)

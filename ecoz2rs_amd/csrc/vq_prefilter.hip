@@ -516,6 +516,82 @@ __device__ __forceinline__ void pre_build_block(const double* __restrict__ aos, 
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- diagnostics (-DE2VQ_PRE_STAMP, tools/probe/pre_stamps.py): where a wave's cycles go, phase by phase ----------
+// s_memtime deltas summed per wave in scalar registers, added to a global table at the end; the stamped build also
+// drains the vector-memory counter at the phase ends, so that a phase pays for the loads it waits on.  Never defined
+// in the product build.
+#ifdef E2VQ_PRE_STAMP
+__device__ unsigned long long g_pre_stamps[32];
+#define E2VQ_STAMP_DECL unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_n = 0;
+#define E2VQ_STAMP_START st_t = __builtin_amdgcn_s_memtime();
+#define E2VQ_STAMP(i)                                                    \
+    {                                                                    \
+        const unsigned long long st_now = __builtin_amdgcn_s_memtime();  \
+        st_acc[i] += st_now - st_t;                                      \
+        st_t = st_now;                                                   \
+    }
+#define E2VQ_STAMP_DRAIN(i)                                              \
+    {                                                                    \
+        if (E2VQ_PRE_STAMP == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* (2: stamps without drains) */ \
+        E2VQ_STAMP(i)                                                    \
+    }
+#else
+#define E2VQ_STAMP_DECL
+#define E2VQ_STAMP_START
+#define E2VQ_STAMP(i)
+#define E2VQ_STAMP_DRAIN(i)
+#endif
+
+// ---- the tile loop's building blocks (shared by k_pass_pre and k_pass_pre_lds; they use the kernels' local names
+// PK, A, lane, maskv, ninf, k1, k2, k3) ------------------------------------------------------------------------------
+// one job = the NSTEP MFMAs of (tile, column block) interleaved with the key epilogue of the previous job
+// (96 VALU ops: two fmas, and_or, three med3 per value), pinned by sched_group_barrier; NC = 37: 15 MFMAs,
+// 1 MFMA (32 cycles, 8 of them blocking issue) : 6 VALU ops
+#ifdef E2VQ_PRE_VPM  // A/B knob (tools/probe/ab): VALU ops pinned behind each MFMA of a job
+#define E2VQ_PRE_VALU_PER_MFMA E2VQ_PRE_VPM
+#else
+#define E2VQ_PRE_VALU_PER_MFMA (96 / PK::NSTEP)
+#endif
+#define E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
+    {                                                                                                             \
+        const int sidx = __builtin_amdgcn_readfirstlane((PTILE) * 32 + 8 * (r >> 2) + (r & 3));                   \
+        const float v = __builtin_fmaf(PREV[0][r], 262144.f, __builtin_fmaf(PREV[1][r], 512.f, PREV[2][r]));     \
+        const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);                                     \
+        k3[PCB] = med3f(k2[PCB], k3[PCB], key);                                                                   \
+        k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                                   \
+        k1[PCB] = med3f(k1[PCB], key, ninf);                                                                      \
+    }
+#if defined(E2VQ_PRE_NOSCHED)  // A/B: leave the interleave to the compiler
+#define E2VQ_PRE_PIN
+#elif defined(E2VQ_PRE_PAIRSCHED)  // A/B: two MFMAs, then twice the VALU ops
+#define E2VQ_PRE_PIN                                                                                              \
+    _Pragma("unroll") for (int s = 0; s < (PK::NSTEP + 1) / 2; ++s)                                               \
+    {                                                                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2 * E2VQ_PRE_VALU_PER_MFMA, 0);                                        \
+    }
+#else
+#define E2VQ_PRE_PIN                                                                                              \
+    _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                         \
+    {                                                                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, E2VQ_PRE_VALU_PER_MFMA, 0);                                            \
+    }
+#endif
+#define E2VQ_PRE_JOB(ACC, BC, PREV, PTILE, PCB)                                                                   \
+    {                                                                                                             \
+        const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
+        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
+        {                                                                                                         \
+            const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \
+            const bool first = s == PK::level_first(lv);                                                         \
+            ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
+        }                                                                                                         \
+        E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
+        E2VQ_PRE_PIN                                                                                              \
+    }
+
 // One wave = 64 frames, independent of every other wave (no LDS sharing, no barriers): the codeword tile images come
 // straight from L2 (512 KB at M = 1024; 16 B per lane and k-step) -- measured as fast as a workgroup-shared LDS ring
 // (tools/probe/pre_sweep.hip -DDIRECT_L2), and it lets the two waves of a SIMD drift apart so that one sweeps (matrix
@@ -545,6 +621,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
     constexpr bool DSEP = ACC;
 #endif
     i64 dacc[4] = {0, 0, 0, 0};
+    E2VQ_STAMP_DECL
     constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2;
     constexpr int NE = 2 * NC + 5, IMG = NE + IMG_STRIDE_PAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -597,6 +674,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
         for (int i = 0; i < stagger * MT / 8; ++i) __builtin_amdgcn_s_sleep(127);  // ~8k cycles each; a tile ~2k
 
     for (long b = wave; b < nblocks; b += nwaves) {
+        E2VQ_STAMP_START
         // ---- f16 limb images of the wave's 64 frames: B operands, resident for the sweep ----------
         h8 B[2][PK::PAIRS];
         float gq[2] = {0.f, 0.f};
@@ -608,6 +686,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 #pragma unroll
                 for (int p = 0; p < PK::PAIRS; ++p) B[cb][p] = fimg[((b * 2 + cb) * PK::PAIRS + p) * 64 + lane];
         }
+        E2VQ_STAMP_DRAIN(0)  // limb images (or the fused build of them) are there
         float k1[2], k2[2], k3[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) k1[cb] = k2[cb] = k3[cb] = __int_as_float(0x7f7fffff);
@@ -618,53 +697,6 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[l][r] = l == 2 ? 3.0e38f : 0.f;
 
-        // one job = the NSTEP MFMAs of (tile, column block) interleaved with the key epilogue of the previous job
-        // (96 VALU ops: two fmas, and_or, three med3 per value), pinned by sched_group_barrier; NC = 37: 15 MFMAs,
-        // 1 MFMA (32 cycles, 8 of them blocking issue) : 6 VALU ops
-#ifdef E2VQ_PRE_VPM  // A/B knob (tools/probe/ab): VALU ops pinned behind each MFMA of a job
-        constexpr int VALU_PER_MFMA = E2VQ_PRE_VPM;
-#else
-        constexpr int VALU_PER_MFMA = 96 / PK::NSTEP;
-#endif
-#define E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
-    {                                                                                                             \
-        const int sidx = __builtin_amdgcn_readfirstlane((PTILE) * 32 + 8 * (r >> 2) + (r & 3));                   \
-        const float v = __builtin_fmaf(PREV[0][r], 262144.f, __builtin_fmaf(PREV[1][r], 512.f, PREV[2][r]));     \
-        const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);                                     \
-        k3[PCB] = med3f(k2[PCB], k3[PCB], key);                                                                   \
-        k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                                   \
-        k1[PCB] = med3f(k1[PCB], key, ninf);                                                                      \
-    }
-#if defined(E2VQ_PRE_NOSCHED)  // A/B: leave the interleave to the compiler
-#define E2VQ_PRE_PIN
-#elif defined(E2VQ_PRE_PAIRSCHED)  // A/B: two MFMAs, then twice the VALU ops
-#define E2VQ_PRE_PIN                                                                                              \
-    _Pragma("unroll") for (int s = 0; s < (PK::NSTEP + 1) / 2; ++s)                                               \
-    {                                                                                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                        \
-        __builtin_amdgcn_sched_group_barrier(0x002, 2 * VALU_PER_MFMA, 0);                                        \
-    }
-#else
-#define E2VQ_PRE_PIN                                                                                              \
-    _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                         \
-    {                                                                                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                        \
-        __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);                                            \
-    }
-#endif
-#define E2VQ_PRE_JOB(ACC, BC, PREV, PTILE, PCB)                                                                   \
-    {                                                                                                             \
-        const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
-        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
-        {                                                                                                         \
-            const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \
-            const bool first = s == PK::level_first(lv);                                                         \
-            ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
-        }                                                                                                         \
-        E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
-        E2VQ_PRE_PIN                                                                                              \
-    }
 #ifdef E2VQ_PRE_ROLL
         // A/B knob (off: 4-7 % SLOWER on MI355X as the compiler schedules it -- the 15 loads end up bunched late in the
         // second job and the loop head still waits for vmcnt(0), with 17 more spilled registers).  Rolling operand
@@ -685,7 +717,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
         {                                                                                                         \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                    \
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                    \
-            __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x002, E2VQ_PRE_VALU_PER_MFMA, 0);                               \
         }                                                                                                         \
     }
         h8 A[PK::NSTEP];
@@ -714,10 +746,8 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
         }
 #endif
         E2VQ_PRE_EPILOGUE(acc1, MT - 1, 1)
-#undef E2VQ_PRE_JOB
-#undef E2VQ_PRE_PIN
-#undef E2VQ_PRE_EPILOGUE
 
+        E2VQ_STAMP(1)  // tile loop
         // ---- per frame: merge the two lane halves (rows 4h..4h+3 of every 8), certify the top two -------------
         int c1[2], c2[2];
         bool cert[2], amb[2];
@@ -750,6 +780,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             }
         }
 
+        E2VQ_STAMP_DRAIN(2)  // certification, cells of the previous pass
         // ---- FP64 frames (MFMA operand layout of k_pass_mfma), exact evaluation of the two candidates -----------
 #ifdef E2VQ_PRE_ABLATE_BF
         const float t1seed = k1[0];
@@ -770,6 +801,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 #else
             load_block_frames<NC>(blk, b, lane, Bf);
 #endif
+        E2VQ_STAMP_DRAIN(3)  // FP64 frames
         double best[4];
         int idx[4];
         bool skip[4];
@@ -787,6 +819,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
                 two[ft] = __ballot(__shfl((int)amb[ft >> 1], src, 64) != 0) != 0;  // wave-uniform
                 g[ft] = pre_gather<NC>(ca[ft], cbq, q);
             }
+            E2VQ_STAMP_DRAIN(4)  // gathers of the first candidates
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft) {
 #ifdef E2VQ_PRE_ABLATE_VERIFY  // diagnostics only (tools/probe): wrong results, shows what the exact evaluation costs
@@ -796,6 +829,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 #endif
                 idx[ft] = ca[ft];
             }
+            E2VQ_STAMP(5)  // exact chains of the first candidates
 #if !defined(E2VQ_PRE_ABLATE_VERIFY) && !defined(E2VQ_PRE_ABLATE_ROUND2)
             if (two[0] || two[1] || two[2] || two[3]) {
 #pragma unroll
@@ -813,6 +847,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 #endif
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft) idx[ft] = skip[ft] ? 0 : idx[ft];
+            E2VQ_STAMP(6)  // the runners-up
         }
 
         // (frames left to the fallback change nothing here: their old cell is taken as their new one, 0)
@@ -834,6 +869,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
                 }
             }
         }
+        E2VQ_STAMP(7)  // outputs
         if constexpr (DEFER) {
             // (every group of the previous block went out during this block's tile loop: the LDS rows are free)
             accum_stage_block<NC, true>(Bf, best, idx, img, sh_r, sh_d, sh_d2, b, T, lane, skip, incr != 0, oldidx);
@@ -866,6 +902,10 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             const bool sk = q == 0 ? skip[0] : q == 1 ? skip[1] : q == 2 ? skip[2] : skip[3];
             if (prev_sym && b * 64 + lane < T && !sk) prev_sym[b * 64 + lane] = (unsigned short)is;
         }
+        E2VQ_STAMP(8)  // accumulate (issue side: the atomics drain later)
+#ifdef E2VQ_PRE_STAMP
+        st_n += 1;
+#endif
     }
     if constexpr (DEFER) {  // the last block's images
         if (pending)
@@ -887,9 +927,438 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             if (v != 0) atomicAdd((u64*)&rows[i], (u64)v);
         }
     }
+#ifdef E2VQ_PRE_STAMP
+    {
+        E2VQ_STAMP_START
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        E2VQ_STAMP(9)  // drain at the wave's end
+        if (lane == 0) {
+            for (int k = 0; k < 12; ++k) atomicAdd(&g_pre_stamps[k], st_acc[k]);
+            atomicAdd(&g_pre_stamps[12], st_n);
+            atomicAdd(&g_pre_stamps[13], 1ull);
+        }
+    }
+#endif
+}
+
+// ---- k_pass_pre_lds (round 3): the accumulating prefiltered pass with the FP64 frames of a block staged in LDS ------
+// Same sweep, same keys, same certification, same bits as k_pass_pre.  What changed is everything around the tile loop,
+// because stamps (tools/probe/pre_stamps.py) showed a wave spending 40 k of its 145 k cycles per block there at M = 1024
+// -- and as much again at M = 256, where the tile loop is four times shorter:
+//   * A wave's vector-memory operations retire in order, so every load issued after the block's atomics -- a register
+//     reload from scratch, the FP64 frames of the next tile, the next block's limb images -- waits until those atomics
+//     have been performed at the memory side (thousands of cycles with every CU adding).  Here all of a block's atomics
+//     go out in ONE burst at the very end of the block, behind the loads of the next block's limb images and first
+//     codeword tile; what follows them in the queue (the LDS-DMA of the next block's FP64 frames) is not needed before
+//     the next tile loop is over.
+//   * The FP64 frames arrive by LDS-DMA (global_load_lds_dwordx4 from a row-major resident copy: no registers, issued a
+//     whole tile loop ahead), with the tolerance terms and the cells of the previous pass behind them.
+//   * Exact evaluation: lane = frame.  Each lane runs the canonical chain acc = fma(r[n], cq[n], acc), n ascending from
+//     +0.0 -- the oracle's definition itself, which the FP64 MFMA reproduces (tools/probe/mfma64.hip) -- for both of its
+//     candidates, r from its LDS row, cq rows gathered from L2: no 16x16 FP64 MFMA tiles computed for their diagonals,
+//     no second round, no cross-lane traffic.
+//   * Accumulate in place: a frame that contributes converts its own LDS row to the (hi, lo) limb pairs where the
+//     doubles were (8 bytes either way), then the wave adds the rows of those frames to their cells, four frames per
+//     step (four 64-lane adds + one carrying the four row tails and the count).  Only frames that moved are touched.
+template <int NC>
+struct PreLds {
+    static constexpr int STAGE_BYTES = 64 * NC * 8;  // the block's frames, row-major
+    static constexpr int AUX_BYTES = 256 + 256;      // tolerance terms (64 floats); cells of the previous pass (64 u16, read as 64 dwords)
+    static constexpr int WAVE_BYTES = STAGE_BYTES + AUX_BYTES;
+    static constexpr int NE = 2 * NC + 1;            // elements of a frame's contribution: limb pairs + count
+    static constexpr bool OK = 8 * WAVE_BYTES <= E2VQ_LDS_BYTES && NE <= 80;
+};
+
+// requests block b of the row-major frames (padded with zero rows to whole blocks), its tolerance terms and the cells
+// of the previous pass into the wave's LDS region: LDS-DMA, 1 KB / 256 B per instruction, no registers
+template <int NC>
+__device__ __forceinline__ void pre_lds_request(const double* __restrict__ aos, const float* __restrict__ fg,
+                                                const unsigned short* __restrict__ prev_sym, long b, int lane,
+                                                unsigned char* wbase)
+{
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int BYTES = 64 * NC * 8, K16 = BYTES / 1024, K4 = (BYTES - K16 * 1024) / 256;
+    static_assert(K16 * 1024 + K4 * 256 == BYTES, "a block of frames is a whole number of 256-byte pieces");
+    const char* g = (const char*)(aos + b * (long)(64 * NC));
+#pragma unroll
+    for (int k = 0; k < K16; ++k)
+        __builtin_amdgcn_global_load_lds((gptr_t)(g + k * 1024 + lane * 16), (lptr_t)(wbase + k * 1024), 16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < K4; ++k)
+        __builtin_amdgcn_global_load_lds((gptr_t)(g + K16 * 1024 + k * 256 + lane * 4),
+                                         (lptr_t)(wbase + K16 * 1024 + k * 256), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)((const char*)(fg + b * 64) + lane * 4), (lptr_t)(wbase + BYTES), 4, 0, 0);
+    if (prev_sym)  // (64 dwords: the block's 64 cells and 128 bytes beyond them, which the array is padded for)
+        __builtin_amdgcn_global_load_lds((gptr_t)((const char*)(prev_sym + b * 64) + lane * 4),
+                                         (lptr_t)(wbase + BYTES + 256), 4, 0, 0);
+}
+
+// s_waitcnt vmcnt(0) that the N granules loaded by inline asm depend on (so that nothing consuming them moves above it)
+template <int N>
+__device__ __forceinline__ void pre_wait_loaded(h8 (&A)[N])
+{
+    static_assert(N >= 6 && N <= 18, "k-steps per tile");
+    if constexpr (N == 6)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5])::"memory");
+    else if constexpr (N == 9)
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), "+v"(A[8])::"memory");
+    else if constexpr (N == 11)
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), "+v"(A[8]),
+                       "+v"(A[9]), "+v"(A[10])::"memory");
+    else if constexpr (N == 12)
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), "+v"(A[8]),
+                       "+v"(A[9]), "+v"(A[10]), "+v"(A[11])::"memory");
+    else if constexpr (N == 15)
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), "+v"(A[8]),
+                       "+v"(A[9]), "+v"(A[10]), "+v"(A[11]), "+v"(A[12]), "+v"(A[13]), "+v"(A[14])::"memory");
+    else {  // other packings: one wait per granule (cheap: the counter is already zero after the first)
+#pragma unroll
+        for (int s = 0; s < N; ++s) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[s])::"memory");
+    }
+}
+
+// the lane index straight from the hardware, in a form the compiler can neither hoist nor share between uses
+__device__ __forceinline__ int pre_fresh_lane()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)::"memory");
+    return l;
+}
+
+template <int NC>
+__global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restrict__ aos, long T, long nblocks,
+                                                         const h8* __restrict__ fimg, const float* __restrict__ fg,
+                                                         const h8* __restrict__ cimg, PreScalars* __restrict__ ps,
+                                                         const double* __restrict__ cbq, int MT, int idxmask,
+                                                         const DevScalars* __restrict__ sc,
+                                                         const u64* __restrict__ l1max_bits,
+                                                         unsigned short* __restrict__ sym, double* __restrict__ dmin,
+                                                         i64* __restrict__ rows, int* __restrict__ fb_list, int stagger,
+                                                         unsigned short* __restrict__ prev_sym, int incr)
+{
+    typedef PrePack<NC> PK;
+    typedef PreLds<NC> PL;
+    constexpr int TPBM = 512;
+    constexpr int RS = (2 * NC + 5 + 7) & ~7, NPAD = (NC + 7) & ~7;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // (the wave's index as a scalar: everything derived from it -- block numbers, the LDS region -- stays in SGPRs)
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long wave = (long)blockIdx.x * (TPBM >> 6) + wib;
+    const long nwaves = (long)gridDim.x * (TPBM >> 6);
+    unsigned char* wbase = smem + (size_t)wib * PL::WAVE_BYTES;
+    double* stage = (double*)wbase;
+    int* stagei = (int*)wbase;
+    const float* fgs = (const float*)(wbase + PL::STAGE_BYTES);
+    const unsigned short* prevs = (const unsigned short*)(wbase + PL::STAGE_BYTES + 256);
+    E2VQ_STAMP_DECL
+
+    const int sh_r = sc->sh_r;
+    const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
+    const int sh_d = 30 - Ed, sh_d2 = 30 - 2 * Ed;
+    const float ymax1 = __int_as_float(ps->ymax_bits);
+    const float relk = 2.0f / (float)(1u << (22 - __builtin_popcount(~idxmask)));  // 2 rho, rho = 2^-(22-idxbits)
+
+    // (partner waves w and w + 4 of a SIMD: half a block period apart, as in k_pass_pre)
+    if (stagger && nblocks >= 2 * nwaves && wib >= 4)
+        for (int i = 0; i < stagger * MT / 8; ++i) __builtin_amdgcn_s_sleep(127);
+
+    // limb images of the block and the first codeword tile: loop-carried, requested for the NEXT block before the
+    // current block's atomics go out
+    // (addresses as uniform base + 32-bit lane offset: the compiler keeps no 64-bit per-lane pointers alive -- and
+    // spilled -- across the phases; a reload from scratch behind the atomics would wait for them)
+    h8 B[2][PK::PAIRS];
+    h8 A[PK::NSTEP];
+    constexpr unsigned BLOCK_IMG = 2u * PK::PAIRS * 64u * 16u;  // bytes of a block's limb image
+    constexpr unsigned TILE_IMG = (unsigned)PK::TILE_E * 16u;   // bytes of a codeword tile's limb image
+#define E2VQ_LDS_LOAD_B(BLK, LN)                                                                              \
+    {                                                                                                         \
+        const char* fb_ = (const char*)fimg + (size_t)(BLK) * BLOCK_IMG;                                      \
+        const unsigned lo_ = (unsigned)(LN) * 16u;                                                            \
+        _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int p = 0; p < PK::PAIRS; ++p) \
+            B[cb][p] = *(const h8*)(fb_ + (lo_ + (unsigned)((cb * PK::PAIRS + p) * 1024)));                   \
+    }
+#define E2VQ_LDS_LOAD_A(TILE, LN)                                                                             \
+    {                                                                                                         \
+        const char* cb_ = (const char*)cimg + (size_t)(TILE) * TILE_IMG;                                      \
+        const unsigned lo_ = (unsigned)(LN) * 16u;                                                            \
+        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s) A[s] = *(const h8*)(cb_ + (lo_ + (unsigned)(s * 1024))); \
+    }
+    if (wave < nblocks) {
+        E2VQ_LDS_LOAD_B(wave, lane)
+        E2VQ_LDS_LOAD_A(0, lane)
+        pre_lds_request<NC>(aos, fg, incr ? prev_sym : nullptr, wave, lane, wbase);
+    }
+    // (as before every block's atomics: both ways into the block loop arrive with no register load pending, so the
+    // compiler puts no counter wait in front of tile 0)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+
+    for (long b = wave; b < nblocks; b += nwaves) {
+        E2VQ_STAMP_START
+        // per-lane constants of the tile loop are made afresh for every block (from scalars, the lane index from the
+        // hardware): kept alive across the blocks they would be spilled during the evaluate phase and reloaded here --
+        // behind the previous block's atomics
+        int maskv;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(maskv) : "s"(idxmask));  // (scalar source: nothing to keep in a VGPR)
+        float ninf = -__builtin_inff();
+        asm volatile("" : "+v"(ninf));
+        const int lane_t = pre_fresh_lane();
+        float k1[2], k2[2], k3[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) k1[cb] = k2[cb] = k3[cb] = __int_as_float(0x7f7fffff);
+        f16v acc0[3], acc1[3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[l][r] = l == 2 ? 3.0e38f : 0.f;
+        // Tile 0 came with the block's limb images, complete before the previous block's atomics went out: it runs
+        // without a counter wait while those atomics drain; the loads of tile 1 queue behind them.  The in-loop loads
+        // are inline asm with a hand-placed wait: any load the compiler can see in this loop makes it insert counter
+        // waits that, at t = 0, would wait for the atomics (the counter is in-order and the number of atomics unknown).
+        for (int t = 0; t < MT; ++t) {
+            if (t > 0) {
+                const char* cb_ = (const char*)cimg + (size_t)t * TILE_IMG;
+                const unsigned lo_ = (unsigned)lane_t * 16u;
+#pragma unroll
+                for (int s = 0; s < PK::NSTEP; ++s)
+                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                                 : "=&v"(A[s])
+                                 : "v"(lo_ + (unsigned)((s >> 2) * 4096)), "s"(cb_), "n"((s & 3) * 1024)
+                                 : "memory");
+                static_assert(PK::NSTEP <= 18, "operand list of the wait below");
+                pre_wait_loaded<PK::NSTEP>(A);
+            }
+            E2VQ_PRE_JOB(acc0, B[0], acc1, (t - 1) & 0xffff, 1)  // (t = 0: the "previous" accumulators hold 3e38)
+            E2VQ_PRE_JOB(acc1, B[1], acc0, t, 0)
+        }
+        E2VQ_PRE_EPILOGUE(acc1, MT - 1, 1)
+        E2VQ_STAMP(1)  // tile loop
+
+        // Everything below recomputes its addresses from an opaque copy of the lane index: hoisted out of the block loop
+        // they would live across the tile loop, be spilled there, and their reloads would queue behind the atomics.
+        const int ln = pre_fresh_lane();
+        const long bn = b + nwaves;
+
+        // ---- ln = frame b*64 + ln = (column block ln >> 5, column ln & 31): the ln's half of that frame's
+        // keys is its own k*[ln >> 5]; the other half sits in the partner ln (ln ^ 32) as ITS k*[ln >> 5] --
+        const int half = ln >> 5;
+        const int hb = half << 2;
+        float a1, a2, a3, s1, s2, s3;
+        {
+            const float o1 = __int_as_float(__float_as_int(k1[0]) | hb), o2 = __int_as_float(__float_as_int(k2[0]) | hb),
+                        o3 = __int_as_float(__float_as_int(k3[0]) | hb);
+            const float p1 = __int_as_float(__float_as_int(k1[1]) | hb), p2 = __int_as_float(__float_as_int(k2[1]) | hb),
+                        p3 = __int_as_float(__float_as_int(k3[1]) | hb);
+            a1 = half ? p1 : o1, a2 = half ? p2 : o2, a3 = half ? p3 : o3;  // own frame's keys
+            s1 = half ? o1 : p1, s2 = half ? o2 : p2, s3 = half ? o3 : p3;  // the partner's frame's keys
+        }
+        const float b1 = __shfl_xor(s1, 32, 64), b2 = __shfl_xor(s2, 32, 64), b3 = __shfl_xor(s3, 32, 64);
+        const float t3 = med3f(a2, a3, b1), t2 = med3f(a1, a2, b1), t1 = med3f(a1, b1, ninf);
+        const float u3 = med3f(t2, t3, b2), u2 = med3f(t1, t2, b2);
+        const float w3 = med3f(u2, u3, b3);
+        // t1 <= u2 <= w3: the three smallest keys of the ln's frame (the merge is symmetric in the two halves)
+        // The block's LDS-DMA has landed: it was requested before the tile loop, and the loads of the last codeword tile --
+        // younger, completed in order -- have been consumed.  (No counter wait here: it would also wait for the limb
+        // images just requested.)  The fence keeps the compiler from reading the LDS rows any earlier.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        asm volatile("" ::: "memory");
+        const long t = b * 64 + ln;
+        const bool live = t < T;
+        const float g = live ? fgs[ln] : 0.f;
+        const float tau = 1.27f * (512.f * (g + ymax1 + (NC + 4.0f)) + relk * t1);
+        const bool cert = t1 >= 1.0e-30f && t1 < 1.0e37f && w3 > t1 + tau;
+        const int c1 = __float_as_int(t1) & ~idxmask, c2 = __float_as_int(u2) & ~idxmask;
+        const int old = incr ? (int)prevs[ln] : 0;
+        E2VQ_STAMP(2)  // merge, certification
+
+        // ---- exact evaluation of both candidates: the canonical chain, one frame per ln ---------------------------
+        double best;
+        int idx;
+        {
+            // both codeword rows are requested at once (one exposed L2 latency); the frame's coefficients come from
+            // its LDS row eight at a time, fenced, so that the compiler does not hoist all 37 reads above the chains
+            // (the next block's limb images are in flight in 56 registers: with everything hoisted they get spilled,
+            // which first has to wait for them)
+            constexpr int NH = (NC + 1) / 2;
+            const double2* r1 = (const double2*)(cbq + (long)c1 * NPAD);
+            const double2* r2 = (const double2*)(cbq + (long)c2 * NPAD);
+            double2 x[NH], y[NH];
+#pragma unroll
+            for (int n2 = 0; n2 < NH; ++n2) {  // (rows are padded to a multiple of 8 doubles)
+                x[n2] = r1[n2];
+                y[n2] = r2[n2];
+            }
+            const double* fr = stage + ln * NC;
+            double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int n2 = 0; n2 < NH; ++n2) {
+                if ((n2 & 3) == 0) asm volatile("" ::: "memory");
+                const double f0 = fr[2 * n2];
+                d1 = __builtin_fma(f0, x[n2].x, d1);
+                d2 = __builtin_fma(f0, y[n2].x, d2);
+                if (2 * n2 + 1 < NC) {
+                    const double f1 = fr[2 * n2 + 1];
+                    d1 = __builtin_fma(f1, x[n2].y, d1);
+                    d2 = __builtin_fma(f1, y[n2].y, d2);
+                }
+            }
+            // (a runner-up whose key is out of reach cannot win: comparing it anyway changes nothing)
+            const bool take_b = d2 < d1 || (d2 == d1 && c2 < c1);
+            best = take_b ? d2 : d1;
+            idx = take_b ? c2 : c1;
+        }
+        const bool skip = !cert;
+        idx = skip ? 0 : idx;
+        E2VQ_STAMP(3)  // exact evaluation
+
+        // ---- outputs; uncertified frames go to the fallback list -----------------------------------------------------
+        if (live) {
+            if (skip) {
+                fb_list[atomicAdd(&ps->fb_count, 1)] = (int)t;
+            } else {
+                if (sym) sym[t] = (unsigned short)idx;
+                if (dmin) dmin[t] = best;
+            }
+        }
+        // the block's distortion sums (e and e^2 of every certified frame as limb pairs): only their column totals are
+        // ever used, so the wave adds them up and one lane per element adds them to the distortion columns of some row
+        // with the block's other atomics (no per-lane running sums to keep across the tile loops)
+        i64 dsum;
+        {
+            int h0 = 0, l0 = 0, h1 = 0, l1 = 0;
+            if (live && !skip) {
+                const double e = best - 1.0;
+                fix2(e, sh_d, h0, l0);
+                fix2(e * e, sh_d2, h1, l1);
+            }
+            i64 d0 = h0, d1 = l0, d2 = h1, d3 = l1;
+            for (int d = 32; d >= 1; d >>= 1) {
+                d0 += __shfl_xor(d0, d, 64);
+                d1 += __shfl_xor(d1, d, 64);
+                d2 += __shfl_xor(d2, d, 64);
+                d3 += __shfl_xor(d3, d, 64);
+            }
+            dsum = ln == 0 ? d0 : ln == 1 ? d1 : ln == 2 ? d2 : d3;
+        }
+        E2VQ_STAMP(4)  // outputs
+
+        // ---- the next block's limb images and first codeword tile: requested now -- behind the register-hungry chains,
+        // ahead of the limb conversion, which covers most of their latency -- and complete before the atomics go out
+        if (bn < nblocks) {
+            E2VQ_LDS_LOAD_B(bn, ln)
+            E2VQ_LDS_LOAD_A(0, ln)
+        }
+
+
+        // ---- frames that contribute (all of a full pass, the movers of an incremental one): rows -> limb pairs, in place
+        const bool mov = live && !skip && (!incr || old != idx);
+        if (mov) {
+            double* fr = stage + ln * NC;
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                int hi, lo;
+                fix2(fr[n], sh_r, hi, lo);
+                *(int2*)&fr[n] = make_int2(hi, lo);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        E2VQ_STAMP(5)  // limb conversion
+
+        // ---- the block's atomics, four frames per step ------------------------------------------------------------------
+        // Every load of this block -- and of the next block's limb images -- has to be complete before the first atomic:
+        // nothing may wait on the vector-memory counter from here to the next tile loop.  The builtin (not inline asm) so
+        // that the compiler's own counter bookkeeping sees it and inserts no later wait for those registers.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        {
+            u64 mm = __ballot(mov);
+            const int tq = ln >> 4, te = ln & 15;
+            constexpr int NE = PL::NE;            // limb pairs + count
+            constexpr bool TAIL = NE > 64;        // rows longer than a wave: one more add carries four row tails
+            constexpr int NT = TAIL ? NE - 64 : 0;  // tail elements, the count last
+            while (mm != 0) {
+                int f[4], cell[4], oldc[4], v[4];
+                bool on[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    on[k] = mm != 0;  // wave-uniform
+                    f[k] = on[k] ? (int)__builtin_ctzll(mm) : 0;
+                    mm = on[k] ? (mm & (mm - 1)) : mm;
+                    cell[k] = __builtin_amdgcn_readlane(idx, f[k]);
+                    oldc[k] = __builtin_amdgcn_readlane(old, f[k]);
+                    const int e = ln;  // element handled in the full-width add
+                    v[k] = e < 2 * NC ? stagei[f[k] * (2 * NC) + e] : 1;  // (e == 2 NC, short rows only: the count)
+                }
+                int tv = 0, tcell = 0, told = 0;
+                bool ton = false;
+                if constexpr (TAIL) {
+                    const int tf = tq == 0 ? f[0] : tq == 1 ? f[1] : tq == 2 ? f[2] : f[3];
+                    ton = tq == 0 ? on[0] : tq == 1 ? on[1] : tq == 2 ? on[2] : on[3];
+                    tcell = tq == 0 ? cell[0] : tq == 1 ? cell[1] : tq == 2 ? cell[2] : cell[3];
+                    told = tq == 0 ? oldc[0] : tq == 1 ? oldc[1] : tq == 2 ? oldc[2] : oldc[3];
+                    tv = te < NT - 1 ? stagei[tf * (2 * NC) + 64 + te] : 1;
+                    ton = ton && te < NT;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!on[k]) continue;  // wave-uniform
+                    if (TAIL || ln < NE) {
+                        atomicAdd((u64*)&rows[(long)cell[k] * RS + ln], (u64)(i64)v[k]);
+                        if (incr) atomicAdd((u64*)&rows[(long)oldc[k] * RS + ln], (u64)(-(i64)v[k]));
+                    }
+                }
+                if (TAIL && ton) {
+                    atomicAdd((u64*)&rows[(long)tcell * RS + 64 + te], (u64)(i64)tv);
+                    if (incr) atomicAdd((u64*)&rows[(long)told * RS + 64 + te], (u64)(-(i64)tv));
+                }
+            }
+        }
+        if (ln < 4 && dsum != 0) atomicAdd((u64*)&rows[(long)(b % (32 * MT)) * RS + 2 * NC + 1 + ln], (u64)dsum);
+        if (prev_sym && live && !skip) prev_sym[t] = (unsigned short)idx;
+        E2VQ_STAMP(6)  // atomics (issue)
+
+        // ---- the next block's frames: the LDS rows are free once this block's reads are done ---------------------------
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (bn < nblocks) pre_lds_request<NC>(aos, fg, incr ? prev_sym : nullptr, bn, ln, wbase);
+        E2VQ_STAMP(7)
+#ifdef E2VQ_PRE_STAMP
+        st_n += 1;
+#endif
+    }
+#ifdef E2VQ_PRE_STAMP
+    {
+        E2VQ_STAMP_START
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        E2VQ_STAMP(9)  // drain at the wave's end
+        if (lane == 0) {
+            for (int k = 0; k < 12; ++k) atomicAdd(&g_pre_stamps[16 + k], st_acc[k]);
+            atomicAdd(&g_pre_stamps[12 + 16], st_n);
+            atomicAdd(&g_pre_stamps[13 + 16], 1ull);
+        }
+    }
+#endif
 }
 
 // ---- launch wrappers ---------------------------------------------------------------------------------------
+#ifdef E2VQ_PRE_STAMP
+}  // namespace e2vq
+extern "C" int e2vq_debug_pre_stamps(unsigned long long* out32, int reset)
+{
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(e2vq::g_pre_stamps), 32 * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(e2vq::g_pre_stamps), z, 32 * 8) != hipSuccess) return 1;
+    }
+    return 0;
+}
+namespace e2vq {
+#endif
 static inline int pre_grid(long items, int per_block, int cap)
 {
     long g = (items + per_block - 1) / per_block;
@@ -1000,6 +1469,21 @@ void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, 
 __host__ __device__ constexpr bool fused_quantize_fits(int NC) { return 8 * 64 * NC * 8 + NC * 4 <= E2VQ_LDS_BYTES; }
 bool prefilter_fused_quantize(int NC) { return pre_has_nc(NC) && fused_quantize_fits(NC) && !getenv("ECOZ2_VQ_QUANTIZE_UNFUSED"); }
 
+// the accumulating pass with LDS-staged frames (k_pass_pre_lds) needs 8 waves x (64 frames + 512 B) of LDS: P <= 38;
+// ECOZ2_VQ_PRE_LDS=0 keeps the round-2 kernel (A/B)
+template <int NC> static constexpr bool lds_stage_ok_t() { return PreLds<NC>::OK; }
+bool prefilter_lds_stage(int NC)
+{
+    static const bool off = getenv("ECOZ2_VQ_PRE_LDS") && atoi(getenv("ECOZ2_VQ_PRE_LDS")) == 0;
+    if (off) return false;
+    switch (NC) {
+#define X(N) case N: return lds_stage_ok_t<N>();
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        default: return false;
+    }
+}
+
 // hybrid_table (full accumulation only): cells < mfma_hybrid_cells(NC) accumulate in the workgroup's LDS table.
 // accumulate = false: assignment only.  prev_sym (optional): the cell of every frame is recorded there; with
 // `incremental` the rows must be those of the previous pass over the same frames (distortion elements zeroed) and
@@ -1010,7 +1494,8 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                                      const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                                      const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym,
                                      double* dmin, long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental,
-                                     bool hybrid_table, hipStream_t s, const double* aos, const int* ea_fused)
+                                     bool hybrid_table, hipStream_t s, const double* aos, const int* ea_fused,
+                                     const double* aos_resident)
 {
     constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
     constexpr int TPBM = 512;  // 8 waves = 2 per SIMD, one persistent workgroup per CU
@@ -1027,6 +1512,16 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
         hipLaunchKernelGGL((k_pass_pre<NC, 5, TPBM>), dim3(grid), dim3(TPBM), lds5, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
                            dmin, rows, fb_list, stagger, prev_sym, 0, (const double*)nullptr, (const int*)nullptr);
+    } else if (accumulate && aos_resident && prefilter_lds_stage(NC)) {
+        // round 3: FP64 frames staged in LDS, lane-per-frame exact evaluation, one burst of atomics per block
+        if constexpr (PreLds<NC>::OK) {
+            (void)hipFuncSetAttribute((const void*)k_pass_pre_lds<NC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      E2VQ_LDS_BYTES);
+            hipLaunchKernelGGL((k_pass_pre_lds<NC>), dim3(grid), dim3(TPBM), (size_t)8 * PreLds<NC>::WAVE_BYTES, s,
+                               aos_resident, T, nblocks, (const h8*)fimg, fg, (const h8*)cimg, (PreScalars*)ps, cbq, M / 32,
+                               idxmask, sc, (const u64*)l1max_bits, sym, dmin, rows, fb_list, stagger, prev_sym,
+                               incremental ? 1 : 0);
+        }
     } else if (accumulate) {
         (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 2, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
@@ -1065,7 +1560,7 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                             const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                             long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
-                            hipStream_t s, const double* rowmajor_frames, const int* ea_fused)
+                            hipStream_t s, const double* rowmajor_frames, const int* ea_fused, const double* resident_rowmajor)
 {
     if (!prefilter_supports(NC, M) || (hybrid_table && incremental)) return 1;
     if (ea_fused && (accumulate || !rowmajor_frames || !prefilter_fused_quantize(NC))) return 1;
@@ -1074,7 +1569,7 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
     case N:                                                                                                           \
         return launch_pass_prefiltered_t<N>(accumulate, blk, T, nblocks, fimg, fg, cimg, ps, cbq, M, sc, l1max_bits, sym, \
                                             dmin, rows, fb_list, prev_sym, incremental, hybrid_table, s, rowmajor_frames, \
-                                            ea_fused);
+                                            ea_fused, resident_rowmajor);
         E2VQ_PRE_NC_LIST(X)
 #undef X
         default: return 1;

@@ -70,6 +70,11 @@ def vq_show(codebook_filename, from_=-1, to=-1):
     check(lib.ecoz2_vq_show(str(codebook_filename).encode(), int(from_), int(to)))
 
 
+def prd_show_file(prd_filename, show_reflections=False, from_=1, to=0):
+    """ecoz2_lib::prd_show_file (src/ecoz2_lib/mod.rs:227-239; caller src/prd/mod.rs:99)."""
+    check(lib.ecoz2_prd_show_file(str(prd_filename).encode(), int(show_reflections), int(from_), int(to)))
+
+
 @dataclass
 class LevelStats:
     M: int

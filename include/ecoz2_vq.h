@@ -76,6 +76,12 @@ int ecoz2_vq_show(const char *codebook_filename, int from, int to);
 int ecoz2_vq_classify(const char *const *cb_filenames, int num_codebooks,
                       const char *const *prd_filenames, int num_predictors, int show_ranked);
 
+/* replaces `fn ecoz2_prd_show_file(prd_filename, show_reflections, from, to)`   src/ecoz2_lib/mod.rs:89-94
+ * (caller src/prd/mod.rs:99).  Prints the header and the coefficient range [from, to] of every predictor vector of a
+ * .prd file (to <= 0: up to P), as in notes.md:77-85; with show_reflections the reflection coefficients k<n> of each
+ * vector (Levinson recursion of src/lpc/lpca_r_rs.rs:8-43 on its autocorrelation) instead of the r<n>. */
+int ecoz2_prd_show_file(const char *prd_filename, int show_reflections, int from, int to);
+
 /* Knobs the reference has no argument for (environment):
  *   ECOZ2_VQ_MAX_CODEBOOK_SIZE  last codebook size trained (default 2048, notes.md:147)
  *   ECOZ2_VQ_DEVICE             HIP device ordinal (default 0)

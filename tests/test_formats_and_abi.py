@@ -139,6 +139,30 @@ def test_cli_seq_show_and_prd_show(tmp_path):
     out = _cli("prd", "show", "--from", "0", "--to", "2", "x.prd", cwd=tmp_path).stdout.splitlines()
     assert out[1] == "# className='HB', T=3, P=36" and out[2] == "r0,r1,r2"
     assert out[3] == ",".join(f"{v:.5f}" for v in fr[0, :3])
+    # defaults of the reference's options (src/prd/mod.rs:45-51): --from 1, --to 0 = up to P
+    out = _cli("prd", "show", "x.prd", cwd=tmp_path).stdout.splitlines()
+    assert out[2] == ",".join(f"r{n}" for n in range(1, 37)) and len(out) == 6
+    # -k: reflection coefficients of each vector = lpca_r (src/lpc/lpca_r_rs.rs:8-43) on its autocorrelation
+    from tests import oracle_lib
+
+    oracle = oracle_lib.load()
+    out = _cli("prd", "show", "-k", "-f", "1", "-t", "5", "x.prd", cwd=tmp_path).stdout.splitlines()
+    assert out[2] == "k1,k2,k3,k4,k5"
+    for t in range(3):
+        st, _pe, rc, _a = oracle.lpca_r(fr[t], 36)
+        assert st == 0 and out[3 + t] == ",".join(f"{v:.5f}" for v in rc[1:6])
+
+
+def test_prd_show_file_symbol_is_what_the_reference_binds(tmp_path, capfd):
+    """ecoz2_prd_show_file(prd_filename, show_reflections, from, to): src/ecoz2_lib/mod.rs:89-94, called on the main
+    thread by prd::prd_show_file (:220-239)."""
+    fr = e.synth.synth_frames(3, 1, 12, 0, 5)
+    e.formats.write_prd(str(tmp_path / "y.prd"), "W", fr)
+    e.vq.prd_show_file(tmp_path / "y.prd", False, 0, 0)
+    out = capfd.readouterr().out.splitlines()
+    assert out[1] == "# className='W', T=5, P=12" and out[2] == ",".join(f"r{n}" for n in range(13))
+    assert out[3 + 4] == ",".join(f"{v:.5f}" for v in fr[4])
+    assert e.lib.ecoz2_prd_show_file(str(tmp_path / "missing.prd").encode(), 0, 1, 0) != 0
 
 
 def test_cli_seq_show_pickle(tmp_path):
