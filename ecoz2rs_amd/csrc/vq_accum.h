@@ -125,6 +125,9 @@ __device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((N
     constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
     constexpr int HYB_CELLS = mfma_hyb_cells(NC);
     const int q = lane >> 4, j = lane & 15;
+    // (fix2_mul: same limbs as fix2 at a fraction of its cost, whenever 2^sh_r is a normal double)
+    const bool fast_fix = sh_r >= -1000 && sh_r <= 1000;
+    const double scale_r = ldexp(1.0, fast_fix ? sh_r : 0);
 #pragma unroll
     for (int ft = 0; ft < NFT; ++ft) {
         int* my = img + j * IMG;
@@ -135,7 +138,10 @@ __device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((N
         for (int st = 0; st < NS; ++st) {
             if (limbs && (st < NS - 1 || q < REM)) {  // with TAILV only q = 0 writes r[NC-1] (all q lanes hold it)
                 int hi, lo;
-                fix2(Bf[ft][st], sh_r, hi, lo);
+                if (fast_fix)
+                    fix2_mul(Bf[ft][st], scale_r, hi, lo);
+                else
+                    fix2(Bf[ft][st], sh_r, hi, lo);
                 if (SKIP && skip[ft]) hi = lo = 0;
                 *(int2*)&my[2 * (4 * st + q)] = make_int2(hi, lo);
             }

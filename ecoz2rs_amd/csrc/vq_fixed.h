@@ -17,6 +17,23 @@ __host__ __device__ __forceinline__ void fix2(double x, int sh, int& hi, int& lo
     lo = (int)l;
 }
 
+// fix2 with the scaling done by one multiplication (scale = 2^sh, exact while 2^sh is a normal double: |sh| <= 1000 is
+// what callers check) and both roundings by the 1.5 * 2^52 trick: y + C lies in [2^52, 2^53), where doubles are the
+// integers, so the addition IS round-to-nearest-even to an integer -- the value of rint(y) -- and the low mantissa
+// word of the sum is that integer in two's complement (C's own low word is zero).  Valid for |y| < 2^51; here
+// |y| < 2^30 and |(y - h) 2^31| <= 2^30.  Identical limbs to fix2 for every input (a product that underflows gives
+// (0, 0) either way); six full-rate FP64 operations instead of ldexp / rndne / cvt, which run at a fraction of that rate.
+__device__ __forceinline__ void fix2_mul(double x, double scale, int& hi, int& lo)
+{
+    const double C = 6755399441055744.0;  // 1.5 * 2^52
+    const double y = x * scale;
+    const double yc = y + C;
+    hi = __double2loint(yc);
+    const double h = yc - C;
+    const double zc = (y - h) * 2147483648.0 + C;
+    lo = __double2loint(zc);
+}
+
 // (sum_hi*2^31 + sum_lo), rounded to the nearest double (ties to even), times 2^-(sh+31)
 __host__ __device__ inline double unfix(long long sum_hi, long long sum_lo, int sh)
 {

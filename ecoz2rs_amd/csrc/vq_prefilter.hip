@@ -592,6 +592,33 @@ __device__ unsigned long long g_pre_stamps[32];
         E2VQ_PRE_PIN                                                                                              \
     }
 
+// The same job with its order spelled out instead of pinned: behind MFMA s come the six key-epilogue operations of the
+// values r with r * NSTEP / 16 == s (one or two per MFMA at NSTEP = 15), then a scheduling barrier nothing may cross.
+// k_pass_pre_lds uses this form: with its codeword tiles loaded by inline asm in another basic block, the pipeline
+// solver behind sched_group_barrier left the second job of a tile unpinned (its 15 MFMAs ended up back to back behind
+// 45 epilogue operations: the tile loop ran 30 % slower).
+#define E2VQ_PRE_JOB_ORDERED(ACC, BC, PREV, PTILE, PCB)                                                            \
+    {                                                                                                             \
+        const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
+        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
+        {                                                                                                         \
+            const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \
+            const bool first = s == PK::level_first(lv);                                                         \
+            ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                        \
+            {                                                                                                     \
+                if (r * PK::NSTEP / 16 != s) continue;                                                            \
+                const int sidx = __builtin_amdgcn_readfirstlane((PTILE) * 32 + 8 * (r >> 2) + (r & 3));          \
+                const float v = __builtin_fmaf(PREV[0][r], 262144.f, __builtin_fmaf(PREV[1][r], 512.f, PREV[2][r])); \
+                const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);                             \
+                k3[PCB] = med3f(k2[PCB], k3[PCB], key);                                                           \
+                k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                           \
+                k1[PCB] = med3f(k1[PCB], key, ninf);                                                              \
+            }                                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
+    }
+
 // One wave = 64 frames, independent of every other wave (no LDS sharing, no barriers): the codeword tile images come
 // straight from L2 (512 KB at M = 1024; 16 B per lane and k-step) -- measured as fast as a workgroup-shared LDS ring
 // (tools/probe/pre_sweep.hip -DDIRECT_L2), and it lets the two waves of a SIMD drift apart so that one sweeps (matrix
@@ -1060,6 +1087,8 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
     const int sh_r = sc->sh_r;
     const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
     const int sh_d = 30 - Ed, sh_d2 = 30 - 2 * Ed;
+    const bool fast_fix = sh_r >= -1000 && sh_r <= 1000;  // fix2_mul applies (always, but for absurdly scaled data)
+    const double scale_r = ldexp(1.0, fast_fix ? sh_r : 0);
     const float ymax1 = __int_as_float(ps->ymax_bits);
     const float relk = 2.0f / (float)(1u << (22 - __builtin_popcount(~idxmask)));  // 2 rho, rho = 2^-(22-idxbits)
 
@@ -1132,8 +1161,12 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
                 static_assert(PK::NSTEP <= 18, "operand list of the wait below");
                 pre_wait_loaded<PK::NSTEP>(A);
             }
-            E2VQ_PRE_JOB(acc0, B[0], acc1, (t - 1) & 0xffff, 1)  // (t = 0: the "previous" accumulators hold 3e38)
-            E2VQ_PRE_JOB(acc1, B[1], acc0, t, 0)
+            E2VQ_PRE_JOB_ORDERED(acc0, B[0], acc1, (t - 1) & 0xffff, 1)  // (t = 0: the "previous" accumulators hold 3e38)
+            E2VQ_PRE_JOB_ORDERED(acc1, B[1], acc0, t, 0)
+#ifdef E2VQ_PRE_STAMP
+            if (t == 0) E2VQ_STAMP(8)   // tile 0 (operands prefetched)
+            if (t == 1) E2VQ_STAMP(10)  // tile 1 (its loads queue behind the previous block's atomics and this block's LDS-DMA)
+#endif
         }
         E2VQ_PRE_EPILOGUE(acc1, MT - 1, 1)
         E2VQ_STAMP(1)  // tile loop
@@ -1248,8 +1281,10 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
 
         // ---- the next block's limb images and first codeword tile: requested now -- behind the register-hungry chains,
         // ahead of the limb conversion, which covers most of their latency -- and complete before the atomics go out
-        if (bn < nblocks) {
-            E2VQ_LDS_LOAD_B(bn, ln)
+        {   // (unconditional -- the wave's last block reloads its own images: a conditional load would keep the old B and A
+            // alive, 116 registers, through the evaluation above)
+            const long bl = bn < nblocks ? bn : b;
+            E2VQ_LDS_LOAD_B(bl, ln)
             E2VQ_LDS_LOAD_A(0, ln)
         }
 
@@ -1258,11 +1293,20 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         const bool mov = live && !skip && (!incr || old != idx);
         if (mov) {
             double* fr = stage + ln * NC;
+            if (fast_fix) {  // (wave-uniform: 2^sh_r is a normal double)
 #pragma unroll
-            for (int n = 0; n < NC; ++n) {
-                int hi, lo;
-                fix2(fr[n], sh_r, hi, lo);
-                *(int2*)&fr[n] = make_int2(hi, lo);
+                for (int n = 0; n < NC; ++n) {
+                    int hi, lo;
+                    fix2_mul(fr[n], scale_r, hi, lo);
+                    *(int2*)&fr[n] = make_int2(hi, lo);
+                }
+            } else {
+#pragma unroll 1
+                for (int n = 0; n < NC; ++n) {
+                    int hi, lo;
+                    fix2(fr[n], sh_r, hi, lo);
+                    *(int2*)&fr[n] = make_int2(hi, lo);
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

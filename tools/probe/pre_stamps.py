@@ -10,8 +10,8 @@ P, S = 36, 1 << 21
 os.environ["ECOZ2_VQ_QUIET"] = "1"
 NAMES = ["limb images (+ older atomics)", "tile loop", "certify + old cells", "FP64 frames", "gather 1", "exact 1",
          "runners-up", "outputs", "accumulate (issue)", "final drain"]
-NAMES_LDS = ["", "tile loop", "merge + certify", "exact evaluation", "outputs", "limb conversion", "atomics (issue)",
-             "request next frames", ""]
+NAMES_LDS = ["", "tiles 2..", "merge + certify", "exact evaluation", "outputs", "limb conversion", "atomics (issue)",
+             "request next frames", "tile 0", "", "tile 1"]
 frames = e.synth.synth_frames(20244, 20, P, 0, S)
 out = (C.c_ulonglong * 32)()
 with e.VqSession(P) as s:
@@ -32,10 +32,10 @@ with e.VqSession(P) as s:
                 if v[13] == 0:
                     continue
                 nblk, nwav = max(v[12], 1), max(v[13], 1)
-                tot = v[:10].sum()
+                tot = v[:12].sum()
                 print(f"M={M} pass {p}: kernel {ms:.3f} ms {'k_pass_pre_lds' if base else 'k_pass_pre'} fallback={fb} blocks={int(v[12])} "
                       f"waves={int(v[13])} cycles/block {tot / nblk:.0f} ({tot / nwav / 1e3:.0f} kcyc per wave)")
-                print("    " + "  ".join(f"{names[k]}: {v[k] / nblk:.0f}" for k in range(9) if names[k]) +
+                print("    " + "  ".join(f"{names[k]}: {v[k] / nblk:.0f}" for k in range(len(names)) if names[k]) +
                       f"  | final drain per wave: {v[9] / nwav:.0f}", flush=True)
             if not pre:
                 print(f"M={M} pass {p}: kernel {ms:.3f} ms (plain sweep)", flush=True)
