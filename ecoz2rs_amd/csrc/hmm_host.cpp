@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace e2host;
@@ -43,6 +44,46 @@ int env_device()
 {
     const char* v = getenv("ECOZ2_VQ_DEVICE");
     return v && *v ? atoi(v) : 0;
+}
+
+// ECOZ2_VQ_GPUS = N: sequences (or predictor files) are dealt in contiguous shares to N workers, worker w on device
+// (ECOZ2_VQ_DEVICE + w) % device count -- workers beyond the device count share devices, which is how the 1-GPU tests run
+int env_workers()
+{
+    const char* v = getenv("ECOZ2_VQ_GPUS");
+    const int n = v && *v ? atoi(v) : 1;
+    return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+void share_of(int total, int workers, int w, int* lo, int* hi)
+{
+    const int base = total / workers, rem = total % workers;
+    *lo = w * base + std::min(w, rem);
+    *hi = *lo + base + (w < rem ? 1 : 0);
+}
+int device_of_worker(int w)
+{
+    int n = 1;
+    (void)hipGetDeviceCount(&n);
+    const char* v = getenv("ECOZ2_VQ_DEVICE");
+    return ((v && *v ? atoi(v) : 0) + w) % std::max(n, 1);
+}
+// runs fn(w) for w = 0 .. workers - 1, worker 0 on the calling thread; the first failing worker's message is kept
+template <typename Fn>
+int run_workers(int workers, Fn fn)
+{
+    std::vector<int> rcs((size_t)workers, 0);
+    std::vector<std::string> errs((size_t)workers);
+    std::vector<std::thread> th;
+    auto body = [&](int w) {
+        rcs[(size_t)w] = fn(w);
+        if (rcs[(size_t)w]) errs[(size_t)w] = e2vq_last_error();
+    };
+    for (int w = 1; w < workers; ++w) th.emplace_back(body, w);
+    body(0);
+    for (auto& t : th) t.join();
+    for (int w = 0; w < workers; ++w)
+        if (rcs[(size_t)w]) return w == 0 ? rcs[0] : e2vq_set_error("%s", errs[(size_t)w].c_str());
+    return 0;
 }
 
 int require_device(int device)
@@ -331,8 +372,9 @@ struct Trainer {
         stat.resize((size_t)S);
         return 0;
     }
-    // E-step: expected counts into d_acc; returns L = sequential sum of log P over the used sequences
-    int estep(const unsigned short* d_sym, const i64* d_offs, double* L, i64* used, i64* skipped)
+    // E-step, the device part: expected counts of this trainer's sequences into d_acc, P(O) of each into mant / ex / stat.
+    // acc_out (optional): the count words copied to the host (several workers: summed there and handed back)
+    int estep_counts(const unsigned short* d_sym, const i64* d_offs, std::vector<i64>* acc_out = nullptr)
     {
         HIPCHK(hipMemsetAsync(d_acc.p, 0, (size_t)W * 8, st));
         e2hmm::launch_fb(md, d_sym, d_offs, S, d_alpha.p, d_c.p, d_acc.p, d_mant.p, d_exp.p, d_status.p, st);
@@ -340,7 +382,23 @@ struct Trainer {
         HIPCHK(hipMemcpyAsync(mant.data(), d_mant.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(ex.data(), d_exp.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(stat.data(), d_status.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+        if (acc_out) {
+            acc_out->resize((size_t)W);
+            HIPCHK(hipMemcpyAsync(acc_out->data(), d_acc.p, (size_t)W * 8, hipMemcpyDeviceToHost, st));
+        }
         HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    }
+    int acc_upload(const std::vector<i64>& acc)
+    {
+        HIPCHK(hipMemcpyAsync(d_acc.p, acc.data(), (size_t)W * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    }
+    // E-step: expected counts into d_acc; returns L = sequential sum of log P over the used sequences
+    int estep(const unsigned short* d_sym, const i64* d_offs, double* L, i64* used, i64* skipped)
+    {
+        if (estep_counts(d_sym, d_offs)) return 1;
         double sum = 0.0;
         i64 u = 0;
         for (int s = 0; s < S; ++s)
@@ -376,9 +434,90 @@ typedef void (*hmm_learn_callback_t)(char* variable, double value);
 constexpr int MAX_ESTEPS = 1000;  // safety cap, same in the oracle (val_auto <= 0 with no iteration limit would never stop)
 
 // the training loop of oracle/hmm_oracle.h (e2h_learn): returns the number of E-steps through *n_esteps
+// The same loop with the sequences dealt to `workers` devices (independent sequences; the expected counts
+// are exact int64 limb sums, so their sum over the workers -- taken on the host here: acc_words(N, M) words, 50 KB at
+// N = 6, M = 1024 -- is the count of a single worker bit for bit).  Every worker then runs the M-step on the summed
+// counts: identical parameters everywhere, no broadcast.  L is summed on the host over all sequences in sequence order.
+int train_sharded(Hmm& h, const SeqSet& ss, double epsilon, double val_auto, int max_iterations,
+                  hmm_learn_callback_t callback, std::vector<double>& hist, bool verbose, int workers)
+{
+    struct Worker {
+        int device = 0, s0 = 0, s1 = 0;
+        Stream st;
+        DevBuf<unsigned short> d_sym;
+        DevBuf<i64> d_offs;
+        Trainer tr;
+        std::vector<i64> acc;
+    };
+    std::vector<Worker> ws((size_t)workers);
+    if (run_workers(workers, [&](int w) -> int {
+            Worker& k = ws[(size_t)w];
+            k.device = device_of_worker(w);
+            share_of(ss.S(), workers, w, &k.s0, &k.s1);
+            if (require_device(k.device) || k.st.create()) return 1;
+            const i64 a = ss.offs[(size_t)k.s0], b = ss.offs[(size_t)k.s1];
+            std::vector<i64> offs;
+            for (int i = k.s0; i <= k.s1; ++i) offs.push_back(ss.offs[(size_t)i] - a);
+            if (k.d_sym.upload(ss.sym.data() + a, (size_t)(b - a), k.st.s) || k.d_offs.upload(offs.data(), offs.size(), k.st.s)) return 1;
+            HIPCHK(hipStreamSynchronize(k.st.s));  // (`offs` is a local)
+            return k.tr.setup(h, k.s1 - k.s0, b - a, k.st.s);
+        }))
+        return 1;
+    static char var[] = "sum_log_prob";
+    int it = 0;
+    double Lprev = 0.0;
+    hist.clear();
+    std::vector<i64> total;
+    for (;;) {
+        if ((max_iterations >= 0 && it >= max_iterations) || it >= MAX_ESTEPS) break;
+        if (run_workers(workers, [&](int w) -> int {
+                Worker& k = ws[(size_t)w];
+                HIPCHK(hipSetDevice(k.device));
+                return k.tr.estep_counts(k.d_sym.p, k.d_offs.p, &k.acc);
+            }))
+            return 1;
+        total.assign(ws[0].acc.size(), 0);
+        double L = 0.0;
+        i64 skipped = 0;
+        for (const Worker& k : ws) {
+            for (size_t i = 0; i < total.size(); ++i) total[i] = (i64)((unsigned long long)total[i] + (unsigned long long)k.acc[i]);
+            for (int q = 0; q < k.s1 - k.s0; ++q) {
+                if (k.tr.stat[(size_t)q] == 0)
+                    L = L + log_prob(k.tr.mant[(size_t)q], k.tr.ex[(size_t)q]);
+                else
+                    ++skipped;
+            }
+        }
+        hist.push_back(L);
+        if (verbose)
+            printf("  it=%d  sum log(P) = %.10g%s\n", it, L,
+                   skipped ? (" (" + std::to_string(skipped) + " sequence(s) the model cannot emit were skipped)").c_str() : "");
+        if (callback) callback(var, L);
+        if (it > 0 && L - Lprev <= val_auto) {
+            ++it;
+            break;
+        }
+        if (run_workers(workers, [&](int w) -> int {
+                Worker& k = ws[(size_t)w];
+                HIPCHK(hipSetDevice(k.device));
+                if (k.tr.acc_upload(total)) return 1;
+                if (k.tr.mstep(epsilon)) return 1;
+                HIPCHK(hipStreamSynchronize(k.st.s));
+                return 0;
+            }))
+            return 1;
+        Lprev = L;
+        ++it;
+    }
+    HIPCHK(hipSetDevice(ws[0].device));
+    return ws[0].tr.download(h);
+}
+
 int train(Hmm& h, const SeqSet& ss, double epsilon, double val_auto, int max_iterations, hmm_learn_callback_t callback,
           std::vector<double>& hist, bool verbose)
 {
+    const int workers = std::min(env_workers(), std::max(1, ss.S()));
+    if (workers > 1) return train_sharded(h, ss, epsilon, val_auto, max_iterations, callback, hist, verbose, workers);
     Stream st;
     if (st.create()) return 1;
     DevBuf<unsigned short> d_sym;
@@ -541,15 +680,31 @@ extern "C" int ecoz2_hmm_classify(const char* const* model_filenames, unsigned n
     if (load_models(model_filenames, num_models, models)) return 1;
     SeqSet ss;
     if (load_sequences(sequence_filenames, num_sequences, ss)) return 1;
-    Stream st;
-    if (st.create()) return 1;
-    DevBuf<unsigned short> d_sym;
-    DevBuf<i64> d_offs;
-    if (d_sym.upload(ss.sym.data(), ss.sym.size(), st.s) || d_offs.upload(ss.offs.data(), ss.offs.size(), st.s)) return 1;
     std::vector<const Hmm*> ms;
     for (const Hmm& h : models) ms.push_back(&h);
-    std::vector<double> lp;
-    if (score_device(ms, d_sym.p, d_offs.p, ss.S(), st.s, lp)) return 1;
+    // ECOZ2_VQ_GPUS workers, each scoring a contiguous share of the sequences under every model (independent: the
+    // scores are the single worker's bit for bit)
+    const int workers = std::min(env_workers(), std::max(1, ss.S()));
+    const size_t K = ms.size();
+    std::vector<double> lp((size_t)ss.S() * K);
+    if (run_workers(workers, [&](int w) -> int {
+            int s0, s1;
+            share_of(ss.S(), workers, w, &s0, &s1);
+            if (require_device(device_of_worker(w))) return 1;
+            Stream st;
+            if (st.create()) return 1;
+            const i64 a = ss.offs[(size_t)s0], b = ss.offs[(size_t)s1];
+            std::vector<i64> offs;
+            for (int i = s0; i <= s1; ++i) offs.push_back(ss.offs[(size_t)i] - a);
+            DevBuf<unsigned short> d_sym;
+            DevBuf<i64> d_offs;
+            if (d_sym.upload(ss.sym.data() + a, (size_t)(b - a), st.s) || d_offs.upload(offs.data(), offs.size(), st.s)) return 1;
+            std::vector<double> part;
+            if (score_device(ms, d_sym.p, d_offs.p, s1 - s0, st.s, part)) return 1;
+            std::copy(part.begin(), part.end(), lp.begin() + (ptrdiff_t)((size_t)s0 * K));
+            return 0;
+        }))
+        return 1;
     return classify_report(models, ss.files, ss.classes, lp, ss.M < 0 ? models[0].M : ss.M, show_ranked != 0,
                            classification_filename);
 }
@@ -620,42 +775,59 @@ extern "C" int ecoz2_hmm_classify_predictors(const char* const* model_filenames,
     const int S = (int)files.size();
     printf("number of HMM models: %u  number of codebooks: %d  number of predictor files: %d (%lld vectors)\n", num_models,
            num_codebooks, S, (long long)total);
-    // device: frames once, symbols per codebook, scores per model
-    e2vq_session* vq = nullptr;
-    if (e2vq_session_create(device, P, &vq)) return 1;
-    struct SessionGuard {
-        e2vq_session* s;
-        ~SessionGuard() { e2vq_session_destroy(s); }
-    } guard{vq};
-    Stream st;
-    if (st.create()) return 1;
-    if (e2vq_set_stream(vq, (void*)st.s)) return 1;  // quantize and scoring are ordered on one stream
-    DevBuf<double> d_frames;
-    DevBuf<unsigned short> d_sym;
-    DevBuf<i64> d_offs;
-    if (d_frames.upload(frames.data(), frames.size(), st.s) || d_sym.alloc((size_t)total + 64) || d_offs.upload(offs.data(), offs.size(), st.s))
-        return 1;
+    // device: each of the ECOZ2_VQ_GPUS workers takes a contiguous share of the files -- its frames once, symbols per
+    // codebook, scores per model (files are independent: same scores for any worker count)
     std::vector<double> lp((size_t)S * num_models, -INFINITY);
-    for (int c = 0; c < num_codebooks; ++c) {
-        std::vector<const Hmm*> ms;
-        std::vector<unsigned> idx;
-        for (unsigned k = 0; k < num_models; ++k)
-            if (cb_of[k] == c) {
-                ms.push_back(&models[k]);
-                idx.push_back(k);
+    const int workers = std::min(env_workers(), std::max(1, S));
+    if (run_workers(workers, [&](int w) -> int {
+            int f0, f1;
+            share_of(S, workers, w, &f0, &f1);
+            const int dev = workers == 1 ? device : device_of_worker(w);
+            if (require_device(dev)) return 1;
+            const i64 a = offs[(size_t)f0], n_fr = offs[(size_t)f1] - a;
+            const int Sw = f1 - f0;
+            std::vector<i64> loffs;
+            for (int i = f0; i <= f1; ++i) loffs.push_back(offs[(size_t)i] - a);
+            e2vq_session* vq = nullptr;
+            if (e2vq_session_create(dev, P, &vq)) return 1;
+            struct SessionGuard {
+                e2vq_session* s;
+                ~SessionGuard() { e2vq_session_destroy(s); }
+            } guard{vq};
+            Stream st;
+            if (st.create()) return 1;
+            if (e2vq_set_stream(vq, (void*)st.s)) return 1;  // quantize and scoring are ordered on one stream
+            DevBuf<double> d_frames;
+            DevBuf<unsigned short> d_sym;
+            DevBuf<i64> d_offs;
+            if (d_frames.upload(frames.data() + (size_t)a * (P + 1), (size_t)n_fr * (P + 1), st.s) || d_sym.alloc((size_t)n_fr + 64) ||
+                d_offs.upload(loffs.data(), loffs.size(), st.s))
+                return 1;
+            for (int c = 0; c < num_codebooks; ++c) {
+                std::vector<const Hmm*> ms;
+                std::vector<unsigned> idx;
+                for (unsigned k = 0; k < num_models; ++k)
+                    if (cb_of[k] == c) {
+                        ms.push_back(&models[k]);
+                        idx.push_back(k);
+                    }
+                if (ms.empty()) continue;
+                if (e2vq_set_codebook(vq, cbs[c].refl.data(), cbs[c].M)) return 1;
+                const i64 CH = 1 << 24;  // frames per quantize call
+                for (i64 t0 = 0; t0 < n_fr; t0 += CH) {
+                    const i64 n = std::min(CH, n_fr - t0);
+                    if (e2vq_quantize_device(vq, d_frames.p + (size_t)t0 * (P + 1), n, d_sym.p + t0, nullptr)) return 1;
+                }
+                std::vector<double> part;
+                if (score_device(ms, d_sym.p, d_offs.p, Sw, st.s, part)) return 1;
+                for (int q = 0; q < Sw; ++q)
+                    for (size_t j = 0; j < idx.size(); ++j)
+                        lp[(size_t)(f0 + q) * num_models + idx[j]] = part[(size_t)q * idx.size() + j];
             }
-        if (ms.empty()) continue;
-        if (e2vq_set_codebook(vq, cbs[c].refl.data(), cbs[c].M)) return 1;
-        const i64 CH = 1 << 24;  // frames per quantize call
-        for (i64 t0 = 0; t0 < total; t0 += CH) {
-            const i64 n = std::min(CH, total - t0);
-            if (e2vq_quantize_device(vq, d_frames.p + (size_t)t0 * (P + 1), n, d_sym.p + t0, nullptr)) return 1;
-        }
-        std::vector<double> part;
-        if (score_device(ms, d_sym.p, d_offs.p, S, st.s, part)) return 1;
-        for (int s = 0; s < S; ++s)
-            for (size_t j = 0; j < idx.size(); ++j) lp[(size_t)s * num_models + idx[j]] = part[(size_t)s * idx.size() + j];
-    }
+            HIPCHK(hipStreamSynchronize(st.s));  // (`loffs` is a local)
+            return 0;
+        }))
+        return 1;
     return classify_report(models, files, classes, lp, models[0].M, show_ranked != 0, classification_filename);
 }
 

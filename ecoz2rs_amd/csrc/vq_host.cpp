@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <float.h>
 #include <math.h>
 #include <stdarg.h>
@@ -166,6 +167,7 @@ struct e2vq_session {
     e2vq_allreduce_fn allreduce = nullptr;
     void* ar_user = nullptr;
     int rank = 0, world = 1;
+    bool ar_force = false;  // call the hook even for one rank (a 1-rank RCCL group: exercises the plumbing on one GPU)
 };
 
 static int ensure_codebook_capacity(e2vq_session* s, int M)
@@ -335,7 +337,7 @@ extern "C" int e2vq_synchronize(e2vq_session* s)
 static int reduce(e2vq_session* s, void* buf, i64 count, int op)
 {
     // ECOZ2_VQ_FORCE_ALLREDUCE: call the hook even for a single rank (tests exercise the RCCL plumbing on one GPU)
-    if (!s->allreduce || (s->world <= 1 && !getenv("ECOZ2_VQ_FORCE_ALLREDUCE"))) return 0;
+    if (!s->allreduce || (s->world <= 1 && !s->ar_force && !getenv("ECOZ2_VQ_FORCE_ALLREDUCE"))) return 0;
     const int rc = s->allreduce(s->ar_user, buf, count, op, (void*)s->stream);
     if (rc != 0) return e2vq_set_error("all-reduce hook failed (%d)", rc);
     return 0;
@@ -600,7 +602,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     }
     const int mode = pass_mode(s);
     s->last_prefiltered = use_prefilter(s, mode);
-    const bool collective = s->allreduce && (s->world > 1 || getenv("ECOZ2_VQ_FORCE_ALLREDUCE"));
+    const bool collective = s->allreduce && (s->world > 1 || s->ar_force || getenv("ECOZ2_VQ_FORCE_ALLREDUCE"));
     const bool keep = s->last_prefiltered && mode != 0 && s->incr_enabled;  // rows and cells persist for the next pass
     i64* rows = s->d_rows;
     if (keep && collective) {  // the all-reduce overwrites d_rows: accumulate into the rank's own copy
@@ -1274,6 +1276,83 @@ int local_allreduce(void* user, void* buf, int64_t count, int op, void* stream_)
     return 0;
 }
 
+// ---- RCCL inside the library (north_star: "an RCCL all-reduce over xGMI of the per-cluster sums each LBG iteration") ----
+// librccl.so is loaded on first use (dlopen: the library itself keeps linking against the HIP runtime only, and a
+// process that never shards never loads RCCL).  One communicator per in-process rank (ncclCommInitAll over the ranks'
+// devices, which must be distinct); every rank's host thread enqueues ncclAllReduce(buf, buf, count, ncclInt64 /
+// ncclUint64, ncclSum / ncclMax) on its session's stream -- in place, exact integers, so any rank count gives the same bits.
+struct Rccl {
+    typedef int (*get_version_t)(int*);
+    typedef int (*comm_init_all_t)(void**, int, const int*);
+    typedef int (*all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    typedef int (*comm_destroy_t)(void*);
+    typedef const char* (*error_string_t)(int);
+    void* handle = nullptr;
+    get_version_t get_version = nullptr;
+    comm_init_all_t comm_init_all = nullptr;
+    all_reduce_t all_reduce = nullptr;
+    comm_destroy_t comm_destroy = nullptr;
+    error_string_t error_string = nullptr;
+    std::string why;  // why it could not be loaded
+    enum { Int64 = 4, Uint64 = 5, Sum = 0, Max = 2 };  // ncclDataType_t / ncclRedOp_t values of rccl.h (stable ABI)
+};
+
+Rccl* rccl_api()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // an RCCL that the process has loaded already (a host application's, PyTorch's) is the one to use: a second copy
+        // of the library beside it fails to initialise ("unhandled cuda error")
+        const char* names[] = {getenv("ECOZ2_VQ_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+        for (int pass = 0; pass < 2 && !r.handle; ++pass)
+            for (const char* n : names) {
+                if (!n || !*n) continue;
+                r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (r.handle) break;
+                if (pass == 1) r.why = dlerror();
+            }
+        if (!r.handle) return;
+        r.get_version = (Rccl::get_version_t)dlsym(r.handle, "ncclGetVersion");
+        r.comm_init_all = (Rccl::comm_init_all_t)dlsym(r.handle, "ncclCommInitAll");
+        r.all_reduce = (Rccl::all_reduce_t)dlsym(r.handle, "ncclAllReduce");
+        r.comm_destroy = (Rccl::comm_destroy_t)dlsym(r.handle, "ncclCommDestroy");
+        r.error_string = (Rccl::error_string_t)dlsym(r.handle, "ncclGetErrorString");
+        if (!r.comm_init_all || !r.all_reduce || !r.comm_destroy) {
+            r.why = "librccl.so lacks ncclCommInitAll / ncclAllReduce / ncclCommDestroy";
+            dlclose(r.handle);
+            r.handle = nullptr;
+        }
+    });
+    return r.handle ? &r : nullptr;
+}
+
+struct RcclRank {
+    LocalGroup* g;
+    void* comm;
+    int rank, device;
+    long calls = 0, bytes = 0;
+};
+
+int rccl_allreduce(void* user, void* buf, int64_t count, int op, void* stream_)
+{
+    RcclRank* rr = (RcclRank*)user;
+    Rccl* api = rccl_api();
+    if (!api) return e2vq_set_error("RCCL is not loaded");
+    if (hipSetDevice(rr->device) != hipSuccess) return e2vq_set_error("hipSetDevice(%d) failed", rr->device);
+    (void)hipGetLastError();  // (see ncclCommInitAll below: hipErrorNotReady of a polled event must not reach RCCL)
+    const int rc = api->all_reduce(buf, buf, (size_t)count, op == 0 ? Rccl::Int64 : Rccl::Uint64, op == 0 ? Rccl::Sum : Rccl::Max,
+                                   rr->comm, (hipStream_t)stream_);
+    if (rc != 0) {
+        e2vq_set_error("ncclAllReduce failed: %s", api->error_string ? api->error_string(rc) : "?");
+        rr->g->fail();
+        return 1;
+    }
+    rr->calls += 1;
+    rr->bytes += (long)count * 8;
+    return 0;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -1388,8 +1467,17 @@ static int upload_predictors(e2vq_session* s, const PrdSet& ps, i64 lo, i64 hi)
 
 // one rank of a learn: session on `device`, frames [lo, hi) of the training set.
 // Every failing path of a group rank marks the group failed, so the other ranks leave their barriers.
+// how a rank of an in-process group exchanges its cell sums: the hook, its argument, and the group to mark failed
+struct RankCtx {
+    LocalGroup* g = nullptr;
+    int rank = 0;
+    e2vq_allreduce_fn fn = nullptr;
+    void* user = nullptr;
+    bool force = false;  // call the hook even in a group of one
+};
+
 static int learn_rank(int device, double eps, const char* class_name, const double* base_refl, int base_M,
-                      const PrdSet& ps, i64 lo, i64 hi, LocalRank* lr, int world, void* target,
+                      const PrdSet& ps, i64 lo, i64 hi, const RankCtx* lr, int world, void* target,
                       ecoz2_vq_learn_callback_t cb)
 {
     // ECOZ2_VQ_TIMING=1: wall time of the stages of a rank on stderr (diagnostics)
@@ -1404,7 +1492,10 @@ static int learn_rank(int device, double eps, const char* class_name, const doub
     };
     e2vq_session* s = nullptr;
     int rc = e2vq_session_create(device, ps.P, &s);
-    if (!rc && lr) rc = e2vq_set_allreduce(s, local_allreduce, lr, lr->rank, world);
+    if (!rc && lr) {
+        rc = e2vq_set_allreduce(s, lr->fn, lr->user, lr->rank, world);
+        s->ar_force = lr->force;
+    }
     lap("session");
     if (!rc) rc = upload_predictors(s, ps, lo, hi);
     lap("read + upload + re-layout");
@@ -1415,7 +1506,7 @@ static int learn_rank(int device, double eps, const char* class_name, const doub
         rc = e2vq_learn(s, eps, env_int("ECOZ2_VQ_MAX_CODEBOOK_SIZE", 2048), class_name,
                         env_str("ECOZ2_VQ_OUT_ROOT", "."), target, cb, nullptr, 0, nullptr);
     lap("LBG ladder (+ files)");
-    if (rc && lr) lr->g->fail();
+    if (rc && lr && lr->g) lr->g->fail();
     if (s) e2vq_session_destroy(s);
     return rc;
 }
@@ -1433,7 +1524,13 @@ static int learn_common(int P, double eps, const char* class_name, const double*
     int world = env_int("ECOZ2_VQ_GPUS", 1);
     if (world < 1) world = 1;
     if ((i64)world > T) world = (int)T;  // every rank needs at least one training vector
-    if (world == 1) return learn_rank(dev0, eps, class_name, base_refl, base_M, ps, 0, T, nullptr, 1, target, cb);
+    // ECOZ2_VQ_COLLECTIVE = rccl | p2p (default: RCCL when every rank has a device of its own, else the peer-to-peer
+    // slice kernel -- RCCL cannot place two ranks of a communicator on one device)
+    const std::string coll = env_str("ECOZ2_VQ_COLLECTIVE", "");
+    if (!coll.empty() && coll != "rccl" && coll != "p2p")
+        return e2vq_set_error("ECOZ2_VQ_COLLECTIVE=%s: expected rccl or p2p", coll.c_str());
+    if (world == 1 && coll != "rccl")
+        return learn_rank(dev0, eps, class_name, base_refl, base_M, ps, 0, T, nullptr, 1, target, cb);
 
     // ---- in-process group: rank r on device (dev0 + r) % ndev, contiguous frame shards --------------------------
     printf("sharding over %d rank(s) on %d device(s)\n", world, ndev);
@@ -1442,38 +1539,81 @@ static int learn_common(int P, double eps, const char* class_name, const double*
     g.n = world;
     g.ev_ready.assign((size_t)world, nullptr);
     g.ev_done.assign((size_t)world, nullptr);
-    struct GroupCleanup {  // events are released on every return path
+    std::vector<void*> comms;  // RCCL communicators, one per rank
+    struct GroupCleanup {  // events and communicators are released on every return path
         LocalGroup& g;
+        std::vector<void*>& comms;
         ~GroupCleanup()
         {
             for (hipEvent_t ev : g.ev_ready)
                 if (ev) (void)hipEventDestroy(ev);
             for (hipEvent_t ev : g.ev_done)
                 if (ev) (void)hipEventDestroy(ev);
+            if (Rccl* api = comms.empty() ? nullptr : rccl_api())
+                for (void* c : comms)
+                    if (c) (void)api->comm_destroy(c);
         }
-    } cleanup{g};
+    } cleanup{g, comms};
     std::vector<LocalRank> ranks((size_t)world);
+    std::vector<int> devs((size_t)world);
+    bool distinct = world <= ndev;
     for (int r = 0; r < world; ++r) {
         ranks[r] = LocalRank{&g, r, (dev0 + r) % ndev};
-        HIPCHK(hipSetDevice(ranks[r].device));
-        HIPCHK(hipEventCreateWithFlags(&g.ev_ready[r], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&g.ev_done[r], hipEventDisableTiming));
+        devs[r] = ranks[r].device;
     }
-    // every rank's slice kernel reads and writes every other rank's buffer: peer access between all pairs of distinct
-    // devices ("already enabled" is the only tolerated failure)
-    for (int a = 0; a < world; ++a)
-        for (int b = 0; b < world; ++b) {
-            const int from = ranks[a].device, to = ranks[b].device;
-            if (from == to) continue;
-            int can = 0;
-            HIPCHK(hipDeviceCanAccessPeer(&can, from, to));
-            if (!can) return e2vq_set_error("device %d cannot access device %d (no peer path): ECOZ2_VQ_GPUS needs P2P", from, to);
-            HIPCHK(hipSetDevice(from));
-            const hipError_t pe = hipDeviceEnablePeerAccess(to, 0);
-            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
-                return e2vq_set_error("hipDeviceEnablePeerAccess(%d -> %d) failed: %s", from, to, hipGetErrorString(pe));
-            (void)hipGetLastError();
+    bool use_rccl = coll == "rccl" || (coll.empty() && distinct);
+    if (use_rccl && !distinct) {
+        printf("collective: %d ranks share %d device(s): RCCL needs one device per rank, using the peer-to-peer exchange\n", world, ndev);
+        use_rccl = false;
+    }
+    if (use_rccl && !rccl_api()) {
+        if (coll == "rccl") return e2vq_set_error("ECOZ2_VQ_COLLECTIVE=rccl: librccl.so could not be loaded (%s)", rccl_api() ? "" : "dlopen failed");
+        printf("collective: librccl.so not found, using the peer-to-peer exchange\n");
+        use_rccl = false;
+    }
+    std::vector<RcclRank> rranks((size_t)world);
+    std::vector<RankCtx> ctx((size_t)world);
+    if (use_rccl) {
+        Rccl* api = rccl_api();
+        comms.assign((size_t)world, nullptr);
+        // (RCCL reads the thread's last HIP error after some of its calls: one left behind by an earlier, handled
+        // condition -- an event polled before it completed, a probe for free memory -- would fail the initialisation)
+        (void)hipGetLastError();
+        const int rc = api->comm_init_all(comms.data(), world, devs.data());
+        if (rc != 0) return e2vq_set_error("ncclCommInitAll over %d device(s) failed: %s", world, api->error_string ? api->error_string(rc) : "?");
+        int ver = 0;
+        if (api->get_version) (void)api->get_version(&ver);
+        printf("collective: RCCL %d.%d.%d, ncclAllReduce(int64 sum) per LBG iteration over %d rank(s)\n", ver / 10000, (ver / 100) % 100,
+               ver % 100, world);
+        for (int r = 0; r < world; ++r) {
+            rranks[r] = RcclRank{&g, comms[r], r, devs[r]};
+            ctx[r] = RankCtx{&g, r, rccl_allreduce, &rranks[r], world == 1};
         }
+    } else {
+        printf("collective: peer-to-peer reduce-scatter + all-gather kernel (int64 sum) per LBG iteration over %d rank(s)\n", world);
+        for (int r = 0; r < world; ++r) {
+            HIPCHK(hipSetDevice(ranks[r].device));
+            // (release-to-system events: a peer device waits on them before it reads this rank's words)
+            HIPCHK(hipEventCreateWithFlags(&g.ev_ready[r], hipEventDisableTiming | hipEventReleaseToSystem));
+            HIPCHK(hipEventCreateWithFlags(&g.ev_done[r], hipEventDisableTiming | hipEventReleaseToSystem));
+            ctx[r] = RankCtx{&g, r, local_allreduce, &ranks[r], false};
+        }
+        // every rank's slice kernel reads and writes every other rank's buffer: peer access between all pairs of distinct
+        // devices ("already enabled" is the only tolerated failure)
+        for (int a = 0; a < world; ++a)
+            for (int b = 0; b < world; ++b) {
+                const int from = ranks[a].device, to = ranks[b].device;
+                if (from == to) continue;
+                int can = 0;
+                HIPCHK(hipDeviceCanAccessPeer(&can, from, to));
+                if (!can) return e2vq_set_error("device %d cannot access device %d (no peer path): ECOZ2_VQ_COLLECTIVE=p2p needs P2P", from, to);
+                HIPCHK(hipSetDevice(from));
+                const hipError_t pe = hipDeviceEnablePeerAccess(to, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                    return e2vq_set_error("hipDeviceEnablePeerAccess(%d -> %d) failed: %s", from, to, hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
+    }
     std::vector<int> rcs((size_t)world, 0);
     std::vector<std::thread> th;
     auto shard = [&](int r, i64* lo, i64* hi) {
@@ -1485,16 +1625,17 @@ static int learn_common(int P, double eps, const char* class_name, const double*
         th.emplace_back([&, r]() {
             i64 lo, hi;
             shard(r, &lo, &hi);
-            rcs[r] = learn_rank(ranks[r].device, eps, class_name, base_refl, base_M, ps, lo, hi, &ranks[r], world, nullptr,
-                                nullptr);
+            rcs[r] = learn_rank(ranks[r].device, eps, class_name, base_refl, base_M, ps, lo, hi, &ctx[r], world, nullptr, nullptr);
         });
     }
     {  // rank 0 runs on the calling thread: files, messages and the callback come from here
         i64 lo, hi;
         shard(0, &lo, &hi);
-        rcs[0] = learn_rank(ranks[0].device, eps, class_name, base_refl, base_M, ps, lo, hi, &ranks[0], world, target, cb);
+        rcs[0] = learn_rank(ranks[0].device, eps, class_name, base_refl, base_M, ps, lo, hi, &ctx[0], world, target, cb);
     }
     for (auto& t : th) t.join();
+    if (use_rccl && !getenv("ECOZ2_VQ_QUIET"))
+        printf("collective: rank 0 made %ld ncclAllReduce call(s), %ld bytes\n", rranks[0].calls, rranks[0].bytes);
     for (int rc : rcs)
         if (rc) {
             // the message of the rank that failed FIRST (the others only report the broken barrier)
@@ -1539,7 +1680,35 @@ bool all_finite(const double* v, size_t n)
     return true;
 }
 
-// one in-flight predictor file of a quantize worker: pinned host buffers, device buffers, completion event
+// ---- ecoz2_vq_quantize: units of at most CHUNK frames through fixed-size pinned staging ------------------------------
+// A unit is a run of consecutive frames of the corpus (file order, frame order) made of segments (file, first frame,
+// count): many short files are batched into one unit -- one upload, ONE sweep, one download for all of them (frames are
+// independent, a 64-frame block may span files) --, a file longer than a chunk is split into several units that any
+// worker may take.  Workers (ECOZ2_VQ_GPUS: one session + host thread each, device (dev0 + w) % ndev) pull units from a
+// shared counter; each keeps two units in flight so that file reads, the host-to-device copy, the sweep and the .seq
+// writes overlap.  Every worker allocates ONE pinned and ONE device block (2 slots x CHUNK frames), whatever the file
+// sizes: round 2's whole-file slots cost 370 MB of pinned memory per slot at 1.25 M frames, and four workers sharing a
+// device took 0.82 s where one took 0.23.
+struct QSegment {
+    int file;
+    i64 t0, n;    // frames [t0, t0 + n) of the file
+    i64 off;      // position of the segment's first frame in the unit
+    bool whole;   // the segment is the whole file
+};
+struct QUnit {
+    std::vector<QSegment> segs;
+    i64 n = 0;
+};
+struct QFileResult {
+    i64 T = 0;
+    double e = 0.0;  // sum over the file's frames of (dmin - 1), frame order
+    std::string cls, seq_path;
+    // split files: chunks fold into `e` in frame order whatever order the workers finish them in
+    std::mutex mu;
+    i64 next_t = 0;
+    std::vector<std::pair<i64, std::vector<double>>> pending;
+};
+
 struct QSlot {
     double* h_frames = nullptr;
     uint16_t* h_sym = nullptr;
@@ -1547,125 +1716,154 @@ struct QSlot {
     double* d_frames = nullptr;
     unsigned short* d_sym = nullptr;
     double* d_dmin = nullptr;
-    i64 cap = 0;
     hipEvent_t done = nullptr;
-    int file = -1;  // index of the file in flight, -1 = free
-    i64 T = 0;
-    char cls[96];
-    void release()
-    {
-        if (h_frames) (void)hipHostFree(h_frames);
-        if (h_sym) (void)hipHostFree(h_sym);
-        if (h_dmin) (void)hipHostFree(h_dmin);
-        if (d_frames) (void)hipFree(d_frames);
-        if (d_sym) (void)hipFree(d_sym);
-        if (d_dmin) (void)hipFree(d_dmin);
-        if (done) (void)hipEventDestroy(done);
-        h_frames = nullptr; h_sym = nullptr; h_dmin = nullptr; d_frames = nullptr; d_sym = nullptr; d_dmin = nullptr;
-        done = nullptr; cap = 0;
-    }
-    int ensure(i64 T, int NC)
-    {
-        if (!done) HIPCHK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-        if (T <= cap) return 0;
-        hipEvent_t keep = done;
-        done = nullptr;
-        release();
-        done = keep;
-        const i64 c = std::max<i64>(T, 1024);
-        HIPCHK(hipHostMalloc(&h_frames, (size_t)c * NC * 8, hipHostMallocDefault));
-        HIPCHK(hipHostMalloc(&h_sym, (size_t)c * 2 + 64, hipHostMallocDefault));
-        HIPCHK(hipHostMalloc(&h_dmin, (size_t)c * 8, hipHostMallocDefault));
-        HIPCHK(hipMalloc(&d_frames, (size_t)c * NC * 8));
-        HIPCHK(hipMalloc(&d_sym, (size_t)c * 2 + 64));
-        HIPCHK(hipMalloc(&d_dmin, (size_t)c * 8));
-        cap = c;
-        return 0;
-    }
+    int unit = -1;  // index of the unit in flight, -1 = free
 };
 
-struct QFileResult {
-    int rc = 0;
-    i64 T = 0;
-    double e = 0.0;  // sum over the file's frames of (dmin - 1), frame order
-    std::string cls, seq_path, error;
+struct QShared {
+    const char* const* files;
+    int P, M;
+    const char* root;
+    i64 chunk;
+    std::vector<QUnit> units;
+    std::vector<QFileResult> results;
+    std::atomic<int> next{0};
+    std::atomic<bool> failed{false};
+    QShared(int nfiles) : results((size_t)nfiles) {}
 };
 
-// worker w of W: files w, w + W, ... on `device`.  Two slots: while the GPU sweeps file k, the host reads file k + 1
-// into pinned memory and writes the .seq of file k - 1.
-int quantize_worker(int device, int w, int W, int P, int M, const double* refl, const char* const* files, int n,
-                    const char* root, std::vector<QFileResult>& results)
+// folds the distortions of frames [t0, t0 + n) of a file into its sum, in frame order
+void quantize_fold(QFileResult& r, i64 t0, const double* dmin, i64 n)
 {
+    std::lock_guard<std::mutex> lk(r.mu);
+    if (t0 != r.next_t) {  // an earlier chunk of the file is still in flight: park this one
+        r.pending.emplace_back(t0, std::vector<double>(dmin, dmin + n));
+        return;
+    }
+    double e = r.e;
+    for (i64 t = 0; t < n; ++t) e += dmin[t] - 1.0;
+    r.next_t += n;
+    for (bool again = true; again;) {
+        again = false;
+        for (size_t k = 0; k < r.pending.size(); ++k)
+            if (r.pending[k].first == r.next_t) {
+                for (double d : r.pending[k].second) e += d - 1.0;
+                r.next_t += (i64)r.pending[k].second.size();
+                r.pending.erase(r.pending.begin() + (long)k);
+                again = true;
+                break;
+            }
+    }
+    r.e = e;
+}
+
+int quantize_worker(int device, QShared& sh, const double* refl)
+{
+    static const bool timing = getenv("ECOZ2_VQ_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
+    const int NC = sh.P + 1;
     e2vq_session* s = nullptr;
-    if (e2vq_session_create(device, P, &s)) return 1;
+    if (e2vq_session_create(device, sh.P, &s)) return 1;
     hipStream_t st = nullptr;
     QSlot slots[2];
-    int rc = e2vq_set_codebook(s, refl, M);
+    char* h_block = nullptr;
+    char* d_block = nullptr;
+    int rc = e2vq_set_codebook(s, refl, sh.M);
     if (!rc && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = e2vq_set_error("stream creation failed");
     if (!rc) rc = e2vq_set_stream(s, (void*)st);
-    const int NC = P + 1;
-    auto finish = [&](QSlot& q) -> int {  // results of the file in flight in q: distortion sum + .seq
-        if (q.file < 0) return 0;
+    // one pinned and one device allocation, carved into the two slots (frames | distortions | symbols, 256-byte aligned)
+    const size_t fb = ((size_t)sh.chunk * NC * 8 + 255) & ~(size_t)255, db = ((size_t)sh.chunk * 8 + 255) & ~(size_t)255,
+                 sb = ((size_t)sh.chunk * 2 + 64 + 255) & ~(size_t)255, slot_bytes = fb + db + sb;
+    if (!rc && hipHostMalloc((void**)&h_block, 2 * slot_bytes, hipHostMallocDefault) != hipSuccess)
+        rc = e2vq_set_error("no pinned memory for the quantize staging (%zu bytes)", 2 * slot_bytes);
+    if (!rc && hipMalloc((void**)&d_block, 2 * slot_bytes) != hipSuccess)
+        rc = e2vq_set_error("no device memory for the quantize staging (%zu bytes)", 2 * slot_bytes);
+    for (int k = 0; k < 2 && !rc; ++k) {
+        QSlot& q = slots[k];
+        q.h_frames = (double*)(h_block + k * slot_bytes);
+        q.h_dmin = (double*)(h_block + k * slot_bytes + fb);
+        q.h_sym = (uint16_t*)(h_block + k * slot_bytes + fb + db);
+        q.d_frames = (double*)(d_block + k * slot_bytes);
+        q.d_dmin = (double*)(d_block + k * slot_bytes + fb);
+        q.d_sym = (unsigned short*)(d_block + k * slot_bytes + fb + db);
+        if (hipEventCreateWithFlags(&q.done, hipEventDisableTiming) != hipSuccess) rc = e2vq_set_error("event creation failed");
+    }
+    const double t_setup = now();
+    auto finish = [&](QSlot& q) -> int {  // results of the unit in flight in q: distortion sums + .seq files
+        if (q.unit < 0) return 0;
         HIPCHK(hipEventSynchronize(q.done));
-        QFileResult& r = results[(size_t)q.file];
-        double e = 0.0;
-        for (i64 t = 0; t < q.T; ++t) e += q.h_dmin[t] - 1.0;
-        r.e = e;
-        r.T = q.T;
-        r.cls = q.cls;
-        const std::string base = e2vq_io::basename_noext(files[q.file]);
-        char path[4096];
-        snprintf(path, sizeof path, "%s/data/sequences/M%d/%s/%s.seq", root, M, q.cls, base.c_str());
-        r.seq_path = path;
-        q.file = -1;
-        return e2vq_seq_write(path, r.cls.c_str(), M, q.h_sym, q.T);
+        const QUnit& u = sh.units[(size_t)q.unit];
+        q.unit = -1;
+        for (const QSegment& g : u.segs) {
+            QFileResult& r = sh.results[(size_t)g.file];
+            if (g.whole) {
+                double e = 0.0;
+                for (i64 t = 0; t < g.n; ++t) e += q.h_dmin[g.off + t] - 1.0;
+                r.e = e;
+                if (e2vq_seq_write(r.seq_path.c_str(), r.cls.c_str(), sh.M, q.h_sym + g.off, g.n)) return 1;
+            } else {
+                quantize_fold(r, g.t0, q.h_dmin + g.off, g.n);
+                if (e2vq_io::seq_write_range(r.seq_path.c_str(), g.t0, q.h_sym + g.off, g.n)) return 1;
+            }
+        }
+        return 0;
     };
-    int k = 0;
-    for (int i = w; i < n && !rc; i += W, ++k) {
+    int k = 0, done_units = 0;
+    while (!rc && !sh.failed.load()) {
+        const int ui = sh.next.fetch_add(1);
+        if (ui >= (int)sh.units.size()) break;
         QSlot& q = slots[k & 1];
+        ++k;
         rc = finish(q);
         if (rc) break;
-        int p;
-        int64_t T;
-        rc = e2vq_prd_info(files[i], q.cls, &p, &T);
-        if (rc) break;
-        if (p != P) {
-            rc = e2vq_set_error("%s: prediction order %d differs from the codebook's %d", files[i], p, P);
-            break;
-        }
-        rc = q.ensure(T, NC);
-        if (rc) break;
+        const QUnit& u = sh.units[(size_t)ui];
         bool finite = true;
-        rc = e2vq_io::prd_read_range_mt(files[i], P, 0, T, q.h_frames, e2vq_io::io_threads(), &finite);
-        if (rc) break;
-        if (!finite) {
-            rc = e2vq_set_error("%s: contains NaN or infinite values", files[i]);
-            break;
+        for (const QSegment& g : u.segs) {
+            if (g.n < 1) continue;
+            bool fin = true;
+            rc = e2vq_io::prd_read_range_mt(sh.files[g.file], sh.P, g.t0, g.n, q.h_frames + (size_t)g.off * NC,
+                                            e2vq_io::io_threads(), &fin);
+            if (rc) break;
+            if (!fin) {
+                rc = e2vq_set_error("%s: contains NaN or infinite values", sh.files[g.file]);
+                finite = false;
+                break;
+            }
         }
-        q.file = i;
-        q.T = T;
-        if (T > 0) {
-            hipError_t e = hipMemcpyAsync(q.d_frames, q.h_frames, (size_t)T * NC * 8, hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) rc = e2vq_quantize_device(s, q.d_frames, T, q.d_sym, q.d_dmin);
-            if (e == hipSuccess && !rc) e = hipMemcpyAsync(q.h_sym, q.d_sym, (size_t)T * 2, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess && !rc) e = hipMemcpyAsync(q.h_dmin, q.d_dmin, (size_t)T * 8, hipMemcpyDeviceToHost, st);
-            if (e != hipSuccess) rc = e2vq_set_error("%s: copy failed: %s", files[i], hipGetErrorString(e));
+        if (rc || !finite) break;
+        q.unit = ui;
+        if (u.n > 0) {
+            hipError_t e = hipMemcpyAsync(q.d_frames, q.h_frames, (size_t)u.n * NC * 8, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) rc = e2vq_quantize_device(s, q.d_frames, u.n, q.d_sym, q.d_dmin);
+            if (e == hipSuccess && !rc) e = hipMemcpyAsync(q.h_sym, q.d_sym, (size_t)u.n * 2, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && !rc) e = hipMemcpyAsync(q.h_dmin, q.d_dmin, (size_t)u.n * 8, hipMemcpyDeviceToHost, st);
+            if (e != hipSuccess) rc = e2vq_set_error("quantize: copy failed: %s", hipGetErrorString(e));
         }
         if (!rc && hipEventRecord(q.done, st) != hipSuccess) rc = e2vq_set_error("event record failed");
+        ++done_units;
     }
     for (int j = 0; j < 2 && !rc; ++j) rc = finish(slots[(k + j) & 1]);  // oldest first
+    if (rc) sh.failed.store(true);
     if (st) (void)hipStreamSynchronize(st);
-    for (QSlot& q : slots) q.release();
+    const double t_work = now();
+    for (QSlot& q : slots)
+        if (q.done) (void)hipEventDestroy(q.done);
+    if (h_block) (void)hipHostFree(h_block);
+    if (d_block) (void)hipFree(d_block);
     e2vq_session_destroy(s);
     if (st) (void)hipStreamDestroy(st);
+    if (timing)
+        fprintf(stderr, "[ecoz2 vq quantize, device %d] setup %.1f ms, %d unit(s) %.1f ms, teardown %.1f ms\n", device,
+                (t_setup - t_start) * 1e3, done_units, (t_work - t_setup) * 1e3, (now() - t_work) * 1e3);
     return rc;
 }
 
 }  // namespace
 
-// ECOZ2_VQ_GPUS = N: the files are dealt round-robin to N workers (one session + host thread per GPU; ranks beyond the
-// device count share devices).  Frames are independent, so there is no collective; every .seq, and the totals (summed in
-// file order on the calling thread), are the same for any N.
+// ECOZ2_VQ_GPUS = N workers (one session + host thread each; ranks beyond the device count share devices).  Frames are
+// independent, so there is no collective; every .seq, and the totals (per file in frame order, files in list order, on
+// the calling thread), are the same for any N.  ECOZ2_VQ_QUANTIZE_CHUNK: frames per unit (default 2^17 = 39 MB at P = 36).
 extern "C" int ecoz2_vq_quantize(const char* nom_raas, const char* const* predictor_filenames, int num_predictors,
                                  int show_filenames)
 {
@@ -1678,16 +1876,57 @@ extern "C" int ecoz2_vq_quantize(const char* nom_raas, const char* const* predic
     const int ndev = e2vq_device_count();
     if (ndev < 1) return e2vq_set_error("no HIP device available; this library has no CPU path");
     const int dev0 = env_int("ECOZ2_VQ_DEVICE", 0);
-    int W = std::max(1, env_int("ECOZ2_VQ_GPUS", 1));
-    W = std::max(1, std::min(W, num_predictors));
     const char* root = env_str("ECOZ2_VQ_OUT_ROOT", ".");
-    std::vector<QFileResult> results((size_t)num_predictors);
+    QShared sh(num_predictors);
+    sh.files = predictor_filenames;
+    sh.P = P;
+    sh.M = M;
+    sh.root = root;
+    sh.chunk = std::max(1024, env_int("ECOZ2_VQ_QUANTIZE_CHUNK", 1 << 17));
+    // plan: headers of every file, then units of at most `chunk` frames
+    {
+        QUnit cur;
+        auto flush = [&] {
+            if (!cur.segs.empty()) sh.units.push_back(std::move(cur));
+            cur = QUnit();
+        };
+        for (int i = 0; i < num_predictors; ++i) {
+            char cls[96];
+            int p;
+            int64_t T;
+            if (e2vq_prd_info(predictor_filenames[i], cls, &p, &T)) return 1;
+            if (p != P) return e2vq_set_error("%s: prediction order %d differs from the codebook's %d", predictor_filenames[i], p, P);
+            QFileResult& r = sh.results[(size_t)i];
+            r.T = T;
+            r.cls = cls;
+            char path[4096];
+            snprintf(path, sizeof path, "%s/data/sequences/M%d/%s/%s.seq", root, M, cls,
+                     e2vq_io::basename_noext(predictor_filenames[i]).c_str());
+            r.seq_path = path;
+            if (T <= sh.chunk) {
+                if (cur.n + T > sh.chunk) flush();
+                cur.segs.push_back(QSegment{i, 0, T, cur.n, true});
+                cur.n += T;
+            } else {  // longer than a chunk: units of its own, any worker takes them; the .seq is written piecewise
+                flush();
+                if (e2vq_io::seq_create(path, cls, M, T)) return 1;
+                for (i64 t0 = 0; t0 < T; t0 += sh.chunk) {
+                    const i64 n = std::min<i64>(sh.chunk, T - t0);
+                    cur.segs.push_back(QSegment{i, t0, n, 0, false});
+                    cur.n = n;
+                    flush();
+                }
+            }
+        }
+        flush();
+    }
+    int W = std::max(1, env_int("ECOZ2_VQ_GPUS", 1));
+    W = std::max(1, std::min(W, (int)sh.units.size()));
     std::vector<int> rcs((size_t)W, 0);
     std::vector<std::string> errs((size_t)W);
     std::vector<std::thread> th;
     auto run = [&](int w) {
-        rcs[(size_t)w] = quantize_worker((dev0 + w) % ndev, w, W, P, M, refl.data(), predictor_filenames, num_predictors, root,
-                                         results);
+        rcs[(size_t)w] = quantize_worker((dev0 + w) % ndev, sh, refl.data());
         if (rcs[(size_t)w]) errs[(size_t)w] = g_err;
     };
     for (int w = 1; w < W; ++w) th.emplace_back(run, w);
@@ -1701,7 +1940,7 @@ extern "C" int ecoz2_vq_quantize(const char* nom_raas, const char* const* predic
     double total_e = 0.0;
     i64 total_T = 0;
     for (int i = 0; i < num_predictors; ++i) {
-        const QFileResult& r = results[(size_t)i];
+        const QFileResult& r = sh.results[(size_t)i];
         total_e += r.e;
         total_T += r.T;
         if (show_filenames)

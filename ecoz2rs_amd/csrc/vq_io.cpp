@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -380,6 +381,37 @@ extern "C" int e2vq_seq_write(const char* path, const char* class_name, int M, c
         buf[(size_t)2 * t + 1] = (unsigned char)(sym[t] >> 8);
     }
     const bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    if (fclose(f) != 0 || !ok) return e2vq_set_error("%s: write failed", path);
+    return 0;
+}
+
+// a .seq written piecewise (a .prd larger than a quantize chunk is split over workers): header + final size first, then
+// each worker stores its symbol range at byte 120 + 2 t0
+int e2vq_io::seq_create(const char* path, const char* class_name, int M, int64_t T)
+{
+    if (T < 0 || T > (int64_t)UINT32_MAX) return e2vq_set_error("%s: %lld symbols do not fit the u32 header field", path, (long long)T);
+    if (M < 1 || M > 65536) return e2vq_set_error("%s: codebook size %d does not fit u16 symbols", path, M);
+    if (e2vq_io::mkdirs_for(path) != 0) return e2vq_set_error("%s: cannot create directories", path);
+    FILE* f = fopen(path, "wb");
+    if (!f) return e2vq_set_error("%s: %s", path, strerror(errno));
+    put_header(f, "<sequence>", class_name);
+    put_u32(f, (uint32_t)T);
+    put_u32(f, (uint32_t)M);
+    bool ok = fflush(f) == 0 && ftruncate(fileno(f), (off_t)(120 + 2 * T)) == 0;
+    if (fclose(f) != 0 || !ok) return e2vq_set_error("%s: write failed", path);
+    return 0;
+}
+
+int e2vq_io::seq_write_range(const char* path, int64_t t0, const uint16_t* sym, int64_t n)
+{
+    FILE* f = fopen(path, "r+b");
+    if (!f) return e2vq_set_error("%s: %s", path, strerror(errno));
+    std::vector<unsigned char> buf((size_t)n * 2);
+    for (int64_t t = 0; t < n; ++t) {
+        buf[(size_t)2 * t] = (unsigned char)sym[t];
+        buf[(size_t)2 * t + 1] = (unsigned char)(sym[t] >> 8);
+    }
+    bool ok = fseeko(f, (off_t)(120 + 2 * t0), SEEK_SET) == 0 && fwrite(buf.data(), 1, buf.size(), f) == buf.size();
     if (fclose(f) != 0 || !ok) return e2vq_set_error("%s: write failed", path);
     return 0;
 }

@@ -22,5 +22,8 @@ int prd_read_range(const char* path, int P, int64_t first, int64_t count, double
 // ... by up to `threads` reader threads; *finite (optional) = no NaN / infinite value among them
 int prd_read_range_mt(const char* path, int P, int64_t first, int64_t count, double* frames, int threads,
                       bool* finite = nullptr);
+// a .seq written piecewise: header and final size, then symbol ranges (layout: src/sequence/mod.rs:49-75)
+int seq_create(const char* path, const char* class_name, int M, int64_t T);
+int seq_write_range(const char* path, int64_t t0, const uint16_t* sym, int64_t n);
 int io_threads();  // ECOZ2_VQ_IO_THREADS (default 4): reader threads per rank / worker
 }  // namespace e2vq_io

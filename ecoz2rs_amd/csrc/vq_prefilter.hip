@@ -797,6 +797,53 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             c2[cb] = __float_as_int(u2) & ~idxmask;
         }
 
+        if constexpr (QF) {
+            // fused quantize (round 3): the frames are in the wave's LDS stage, so each lane evaluates ITS frame
+            // (frame lane of the block = column block lane >> 5, column lane & 31; both halves hold the merged keys)
+            // against both candidates with the canonical chain -- acc = fma(r[n], cq[n], acc), n ascending from +0.0,
+            // the oracle's definition, which the FP64 MFMA reproduces -- instead of the diagonals of 16x16 MFMA tiles
+            const int hsel = lane >> 5;
+            const bool certl = hsel ? cert[1] : cert[0];
+            const int ca = hsel ? c1[1] : c1[0], cb2 = hsel ? c2[1] : c2[0];
+            constexpr int NH = (NC + 1) / 2, NPADQ = (NC + 7) & ~7;
+            const double2* r1 = (const double2*)(cbq + (long)ca * NPADQ);
+            const double2* r2 = (const double2*)(cbq + (long)cb2 * NPADQ);
+            double2 x[NH], y[NH];
+#pragma unroll
+            for (int n2 = 0; n2 < NH; ++n2) {  // (rows are padded to a multiple of 8 doubles)
+                x[n2] = r1[n2];
+                y[n2] = r2[n2];
+            }
+            const double* fr = stage + lane * NC;
+            double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int n2 = 0; n2 < NH; ++n2) {
+                if ((n2 & 3) == 0) asm volatile("" ::: "memory");  // (frame reads eight at a time, not all hoisted)
+                const double f0 = fr[2 * n2];
+                d1 = __builtin_fma(f0, x[n2].x, d1);
+                d2 = __builtin_fma(f0, y[n2].x, d2);
+                if (2 * n2 + 1 < NC) {
+                    const double f1 = fr[2 * n2 + 1];
+                    d1 = __builtin_fma(f1, x[n2].y, d1);
+                    d2 = __builtin_fma(f1, y[n2].y, d2);
+                }
+            }
+            // (a runner-up whose key is out of reach cannot win: comparing it anyway changes nothing)
+            const bool take_b = d2 < d1 || (d2 == d1 && cb2 < ca);
+            const long t = b * 64 + lane;
+            if (t < T) {
+                if (!certl) {
+                    fb_list[atomicAdd(&ps->fb_count, 1)] = (int)t;
+                } else {
+                    if (sym) sym[t] = (unsigned short)(take_b ? cb2 : ca);
+                    if (dmin) dmin[t] = take_b ? d2 : d1;
+                }
+            }
+            // (the next block's LDS-DMA overwrites the stage: this block's reads are complete first)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            continue;
+        }
+
         // cells of the previous pass (incremental accumulation): loaded here, with the frames, not after the evaluation
         int oldidx[4] = {0, 0, 0, 0};
         if (ACC && incr) {

@@ -180,9 +180,11 @@ def test_config2_full_ladder_cbook_bit_exact(oracle, tmp_path):
         assert open(tmp_path / "g" / name, "rb").read() == open(tmp_path / "o" / name, "rb").read()
 
 
-def test_config3_sized_quantize_properties(oracle):
+def test_config3_sized_quantize_properties(oracle, tmp_path, monkeypatch):
     """configs[2] scale: 10M frames against M=1024.  Full oracle check on a 2M-frame slice; size-independent
-    properties on all 10M: chunking invariance, dmin recomputed independently, every symbol < M."""
+    properties on all 10M: chunking invariance, dmin recomputed independently, every symbol < M.  Then the same 10 M
+    frames as ONE .prd through ecoz2_vq_quantize with 1, 2 and 5 workers (the file is split into chunks that any
+    worker takes; the .seq is written piecewise): byte-identical .seq whatever the worker count."""
     T, M = 10_000_000, 1024
     frames = e.synth.synth_frames(20243, 20, P, 0, T)
     refl = np.zeros((M, P + 1))
@@ -201,6 +203,27 @@ def test_config3_sized_quantize_properties(oracle):
     idx = np.random.default_rng(0).choice(T, 20000, replace=False)
     d = np.einsum("ij,ij->i", frames[idx], cq[sym[idx]])
     assert np.allclose(d, dmin[idx], rtol=1e-12, atol=1e-12)
+    # one 10 M-frame file (2.96 GB), split over the workers
+    os.environ["ECOZ2_VQ_QUIET"] = "1"
+    prd = tmp_path / "data" / "predictors" / "_" / "all.prd"
+    cb = tmp_path / "cb.cbook"
+    e.formats.write_prd(str(prd), "_", frames)
+    e.formats.write_cbook(str(cb), "_", refl)
+    del frames
+    monkeypatch.setenv("ECOZ2_VQ_OUT_ROOT", str(tmp_path))
+    want = None
+    for workers in (1, 2, 5):
+        monkeypatch.setenv("ECOZ2_VQ_GPUS", str(workers))
+        seq = tmp_path / "data" / "sequences" / f"M{M}" / "_" / "all.seq"
+        if seq.exists():
+            seq.unlink()
+        e.vq_quantize(str(cb), [str(prd)])
+        got = open(seq, "rb").read()
+        if want is None:
+            want = got
+            cls, m, sy = e.formats.read_seq(str(seq))
+            assert (cls, m) == ("_", M) and np.array_equal(sy, sym)  # = the session call's symbols (oracle-checked slice)
+        assert got == want, f"{workers} workers"
 
 
 def test_config4_sized_learn_properties(oracle):
@@ -500,8 +523,73 @@ def test_in_process_group_reproduces_golden_codebooks(tmp_path, monkeypatch, ran
         assert got == open(os.path.join(GOLD, "config1_" + name), "rb").read()
 
 
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus N` with no launcher around it: the parent starts the N ranks itself (fresh child
+    processes, before any GPU call of its own), relays rank 0's JSON line and reports the collective.  Two ranks share
+    the one GPU here, so the exchange is staged through gloo; on an N-GPU node the same command runs nccl = RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    c = d["config"]["collective"]
+    assert c["world_size"] == 2 and c["devices_per_rank"] == 1 and c["backend"].startswith("gloo")
+    assert c["allreduce_calls"] >= 6 and c["bytes_per_call"] == 1024 * e.lib.e2vq_row_stride(P) * 8
+    # a rank that fails makes the launcher fail
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "no-such-backend", "--steps", "3",
+                        "--frames-per-gpu", "4096"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+
+
+def test_rccl_inside_the_library_single_rank_group(tmp_path):
+    """ECOZ2_VQ_COLLECTIVE=rccl: libecoz2vq.so loads librccl.so itself (dlopen), builds a communicator with
+    ncclCommInitAll over the in-process ranks' devices and all-reduces the int64 cell sums with ncclAllReduce on the
+    session's stream -- here a group of ONE rank (all a 1-GPU box allows: RCCL wants one device per rank), through
+    ecoz2_vq_learn, with the hook forced: the golden codebooks and callback scalars must come out unchanged.
+    Runs in a process of its own, as the library runs under the reference's Rust host: this test process has PyTorch's
+    bundled ROCm libraries mapped beside /opt/rocm's, and an RCCL initialised in that mix finds no device."""
+    meta = json.load(open(os.path.join(GOLD, "config1.json")))
+    frames = e.synth.synth_frames(meta["seed"], meta["classes"], P, 0, meta["T"])
+    f = tmp_path / "data" / "predictors" / "_" / "all.prd"
+    e.formats.write_prd(str(f), "_", frames)
+    env = dict(os.environ, ECOZ2_VQ_OUT_ROOT=str(tmp_path), ECOZ2_VQ_MAX_CODEBOOK_SIZE=str(meta["max_M"]), ECOZ2_VQ_GPUS="1",
+               ECOZ2_VQ_COLLECTIVE="rccl", NCCL_DEBUG="WARN")
+    env.pop("ECOZ2_VQ_QUIET", None)
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import ecoz2rs_amd as e; seen = []; "
+            f"e.vq_learn(None, {P}, {meta['eps']!r}, '_', [{str(f)!r}], callback=lambda *a: seen.append(a)); "
+            "print('SEEN', [(s[0], s[1].hex(), s[2].hex(), s[3].hex()) for s in seen])")
+
+    def run(gpus):
+        env["ECOZ2_VQ_GPUS"] = str(gpus)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return r.stdout
+
+    out = run(1)
+    assert "collective: RCCL" in out and "ncclAllReduce(int64 sum)" in out
+    calls = [ln for ln in out.splitlines() if "ncclAllReduce call(s)" in ln]
+    # one MAX + one SUM at e2vq_prepare, then one SUM of the rows per pass
+    assert calls and int(calls[0].split("made")[1].split()[0]) >= 2 + sum(g["passes"] for g in meta["levels"])
+    seen = eval([ln for ln in out.splitlines() if ln.startswith("SEEN ")][0][5:])
+    assert seen == [(g["M"], g["avg"], g["sigma"], g["inertia"]) for g in meta["levels"]]
+    for g in meta["levels"]:
+        name = f"eps_0.05_M_{g['M']:04d}.cbook"
+        got = open(tmp_path / "data" / "codebooks" / "_" / name, "rb").read()
+        assert got == open(os.path.join(GOLD, "config1_" + name), "rb").read()
+    # two ranks on the one device: RCCL refuses that placement, the library says so and uses the peer-to-peer kernel
+    if e.lib.e2vq_device_count() < 2:
+        out = run(2)
+        assert "RCCL needs one device per rank" in out and "peer-to-peer" in out
+        got = open(tmp_path / "data" / "codebooks" / "_" / "eps_0.05_M_0016.cbook", "rb").read()
+        assert got == open(os.path.join(GOLD, "config1_eps_0.05_M_0016.cbook"), "rb").read()
+
+
+@pytest.mark.parametrize("chunk", [None, 4096])
 @pytest.mark.parametrize("workers", [1, 2, 5])
-def test_quantize_workers_give_identical_seq_files(tmp_path, monkeypatch, capfd, oracle, workers):
+def test_quantize_workers_give_identical_seq_files(tmp_path, monkeypatch, capfd, oracle, workers, chunk):
     """ecoz2_vq_quantize with ECOZ2_VQ_GPUS=N (frames are independent -- files dealt to N workers, no
     collective; the workers share the one GPU here): every .seq byte-identical to the oracle's symbols whatever N, totals
     summed in file order.  Ragged files, an empty file, more workers than some ranks have files."""
@@ -520,6 +608,8 @@ def test_quantize_workers_give_identical_seq_files(tmp_path, monkeypatch, capfd,
         files.append(str(f))
     monkeypatch.setenv("ECOZ2_VQ_OUT_ROOT", str(tmp_path))
     monkeypatch.setenv("ECOZ2_VQ_GPUS", str(workers))
+    if chunk:  # small units: short files are batched into one sweep, the long ones split over the workers
+        monkeypatch.setenv("ECOZ2_VQ_QUANTIZE_CHUNK", str(chunk))
     capfd.readouterr()
     e.vq_quantize(str(cb), files, True)
     out = capfd.readouterr().out

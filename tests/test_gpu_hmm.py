@@ -199,6 +199,55 @@ def test_config5_end_to_end_20_classes(H, tmp_path, monkeypatch, capfd):
         assert acc >= (0.9 if kind == "nb" else 0.3), (kind, acc)
 
 
+@pytest.mark.parametrize("workers", [2, 3])
+def test_hmm_workers_give_identical_models_and_reports(tmp_path, monkeypatch, capfd, workers):
+    """ECOZ2_VQ_GPUS=N behind ecoz2_hmm_learn / ecoz2_hmm_classify / ecoz2_hmm_classify_predictors: the
+    sequences (predictor files) are dealt to N workers -- sharing the one GPU here --; the E-step's expected counts are
+    exact int64 limb sums, added up over the workers, so the .hmm bytes, the training measure, the c12n CSV and the
+    report are those of a single worker, byte for byte."""
+    monkeypatch.setenv("ECOZ2_VQ_OUT_ROOT", str(tmp_path))
+    monkeypatch.setenv("ECOZ2_VQ_QUIET", "1")
+    monkeypatch.setenv("NO_COLOR", "1")
+    monkeypatch.setenv("ECOZ2_VQ_MAX_CODEBOOK_SIZE", "64")
+    monkeypatch.chdir(tmp_path)
+    M, N = 64, 5
+    classes, files = _corpus(tmp_path, 4, 7, 4, seed=11)
+    train_prd = sorted(sum((files[(c, "TRAIN")] for c in classes), []))
+    test_prd = sorted(sum((files[(c, "TEST")] for c in classes), []))
+    monkeypatch.setenv("ECOZ2_VQ_GPUS", "1")
+    e.vq_learn(None, P, 0.05, "_", train_prd)
+    cbook = str(tmp_path / "data" / "codebooks" / "_" / f"eps_0.05_M_{M:04d}.cbook")
+    e.vq_quantize(cbook, train_prd + test_prd)
+    seq_of = lambda prd: prd.replace("/predictors/", f"/sequences/M{M}/").replace(".prd", ".seq")
+    hmm_dir = tmp_path / "data" / "hmms" / f"N{N}__M{M}_t3__a0.05"
+
+    def run(nw):
+        monkeypatch.setenv("ECOZ2_VQ_GPUS", str(nw))
+        hists, blobs = [], []
+        for ci, cls in enumerate(classes):
+            e.hmm.set_random_seed(77 + ci)
+            seen = []
+            e.hmm.hmm_learn(N, 3, [seq_of(f) for f in files[(cls, "TRAIN")]], 1e-5, 0.05, -1,
+                            callback=lambda v, x: seen.append(x))
+            hists.append(seen)
+            blobs.append(open(hmm_dir / f"{cls}.hmm", "rb").read())
+        models = sorted(str(p) for p in hmm_dir.glob("*.hmm"))
+        capfd.readouterr()
+        e.hmm.hmm_classify_sequences(models, [seq_of(f) for f in test_prd], True, str(tmp_path / f"s{nw}.csv"))
+        out_s = capfd.readouterr().out
+        e.hmm.hmm_classify_predictors(models, [cbook], test_prd, True, str(tmp_path / f"p{nw}.csv"))
+        out_p = capfd.readouterr().out
+        strip = lambda o: o.split("Confusion matrix:")[1].split(".csv saved")[0].rsplit("\n", 1)[0]
+        return hists, blobs, open(tmp_path / f"s{nw}.csv").read(), open(tmp_path / f"p{nw}.csv").read(), strip(out_s), strip(out_p)
+
+    one = run(1)
+    many = run(workers)
+    assert many[0] == one[0], "training measure differs"
+    assert many[1] == one[1], ".hmm bytes differ"
+    assert many[2] == one[2] and many[3] == one[3] and many[4] == one[4] and many[5] == one[5]
+    assert len(one[0][0]) >= 2  # (several E-steps ran)
+
+
 def test_hmm_cli_end_to_end(tmp_path):
     """`ecoz2 hmm learn / classify / show` through the CLI binary with the reference's flags (src/hmm/mod.rs:40-145)"""
     exe = os.path.join(ROOT, "ecoz2rs_amd", "csrc", "ecoz2")

@@ -53,5 +53,28 @@ for gpus in (1, 4):
     print(f"vq quantize {NF*TF} frames vs M={M}, {gpus} worker(s): {dt:.2f} s wall incl. file reads, H2D, .seq writes "
           f"= {NF*TF/dt/1e6:.1f} M frames/s; .seq sha {seq_digest[gpus]}", flush=True)
 assert seq_digest[1] == seq_digest[4], ".seq files differ between 1 and 4 workers"
+# a corpus of many short recordings (notes.md: thousands of files of a few thousand frames): 5 000 files x 2 000 frames
+shutil.rmtree(os.path.join(root, "data", "predictors"), ignore_errors=True)
+NS, TS = 5000, 2000
+t0 = time.time()
+small = []
+block = e.synth.synth_frames(20243, 20, P, 0, NS * TS)
+for i in range(NS):
+    f = os.path.join(root, "data", "predictors", f"c{i % 20}", f"{i:05d}.prd")
+    e.formats.write_prd(f, f"c{i % 20}", block[i * TS:(i + 1) * TS])
+    small.append(f)
+del block
+print(f"wrote {NS} files x {TS} frames in {time.time()-t0:.1f} s", flush=True)
+seq_small = {}
+for gpus in (1, 4):
+    os.environ["ECOZ2_VQ_GPUS"] = str(gpus)
+    shutil.rmtree(os.path.join(root, "data", "sequences"), ignore_errors=True)
+    t0 = time.time()
+    e.vq_quantize(cbook, small, False)
+    dt = time.time() - t0
+    seq_small[gpus] = digest(os.path.join(root, "data", "sequences"), ".seq")
+    print(f"vq quantize {NS} files x {TS} frames vs M={M}, {gpus} worker(s): {dt:.2f} s wall = {NS*TS/dt/1e6:.1f} M frames/s, "
+          f"{NS/dt:.0f} files/s; .seq sha {seq_small[gpus]}", flush=True)
+assert seq_small[1] == seq_small[4]
 shutil.rmtree(root)
 print("scale check ok: identical bytes for 1 and 4 ranks / workers")
