@@ -111,6 +111,7 @@ struct PublishArgs {
     long long* h_failed;
     volatile unsigned long long* h_seq2;
     unsigned long long seq;
+    volatile unsigned long long* h_err;  // set to seq if a flag did not arrive within the publisher's spin cap
 };
 void launch_cell_update(const long long* rows, int M, int NC, const DevScalars* sc, const double* refl_in,
                         double* refl_out, double* cbq, double* cbm, unsigned long long* l1max_bits, double* within,

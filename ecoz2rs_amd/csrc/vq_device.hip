@@ -771,10 +771,22 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
     if (pub.flags && (int)blockIdx.x == nb) {      // the publisher (dispatched last: every cell workgroup is under way)
         // (every datum read below was written device-coherently -- memory-side atomics, agent-scope atomic stores -- and
         // is read with agent-scope atomic loads: no cache write-back or invalidate is involved anywhere)
+        // The cells' workgroups are dispatched before this one (lower indices: the order HIP launches in, though it
+        // promises none), so the flags polled here are on their way.  Should one never arrive -- a workgroup that was
+        // not scheduled, a lost store -- the spin gives up after ~0.5 s, publishes what is there and raises *h_err:
+        // the host turns that into an error instead of hanging.
         const unsigned int want = (unsigned int)pub.seq;
-        for (int i = threadIdx.x; i < M; i += blockDim.x)
-            while (__hip_atomic_load(&pub.flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want)
+        constexpr int SPIN_CAP = 1 << 22;
+        bool late = false;
+        for (int i = threadIdx.x; i < M; i += blockDim.x) {
+            int spins = 0;
+            while (__hip_atomic_load(&pub.flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want && spins < SPIN_CAP) {
                 __builtin_amdgcn_s_sleep(4);
+                ++spins;
+            }
+            late |= spins >= SPIN_CAP;
+        }
+        if (late && pub.h_err) *pub.h_err = pub.seq;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         __syncthreads();
         for (int i = threadIdx.x; i < 64 * 8; i += blockDim.x) {
@@ -795,9 +807,16 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
 #ifdef E2VQ_CU_NOLATE  // A/B (tools/probe/ab): no second publication
         return;
 #endif
-        for (int i = threadIdx.x; i < M; i += blockDim.x)
-            while (__hip_atomic_load(&pub.flags[M + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want)
+        late = false;
+        for (int i = threadIdx.x; i < M; i += blockDim.x) {
+            int spins = 0;
+            while (__hip_atomic_load(&pub.flags[M + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want && spins < SPIN_CAP) {
                 __builtin_amdgcn_s_sleep(4);
+                ++spins;
+            }
+            late |= spins >= SPIN_CAP;
+        }
+        if (late && pub.h_err) *pub.h_err = pub.seq;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         __syncthreads();
         if (threadIdx.x < 64) {

@@ -94,7 +94,9 @@ struct e2vq_session {
     bool spec_valid = false;
     bool spec_zeroed = false;  // the pass prologue zeroed d_l1max_spec and the shadow image's scalars
     hipEvent_t ev_stats = nullptr;
-    struct HostStats { i64 l[64 * 8]; u64 l1bits; volatile u64 seq; i64 failed; volatile u64 seq2; }* h_stats = nullptr;  // pinned, host-mapped
+    struct HostStats { i64 l[64 * 8]; u64 l1bits; volatile u64 seq; i64 failed; volatile u64 seq2; volatile u64 err; }* h_stats = nullptr;  // pinned, host-mapped
+    long verified_passes = 0;
+    bool verify_publish = false;  // ECOZ2_VQ_VERIFY_PUBLISH: recompute every published statistic on the host from the rows
     bool failed_pending = false;              // the failed-recursion count of stats_seq has not been read yet (seq2)
     e2vq_level_stats* failed_patch = nullptr;  // e2vq_learn: the level record that still waits for that count
     u64 stats_seq = 0;
@@ -246,6 +248,9 @@ static int session_init(e2vq_session* s)
     HIPCHK(hipMalloc(&s->d_l1max_spec, 8));
     HIPCHK(hipHostMalloc(&s->h_stats, sizeof(*s->h_stats), hipHostMallocMapped | hipHostMallocCoherent));
     s->h_stats->seq = 0;
+    s->h_stats->seq2 = 0;
+    s->h_stats->err = 0;
+    if (const char* vp = getenv("ECOZ2_VQ_VERIFY_PUBLISH")) s->verify_publish = atoi(vp) != 0;
     // ECOZ2_VQ_PREFILTER=0 keeps every pass on the FP64 sweep; ECOZ2_VQ_PREFILTER_MIN_M moves the switch-over size
     const char* pf = getenv("ECOZ2_VQ_PREFILTER");
     s->pre_enabled = e2vq::prefilter_supports(s->NC, 64) && !(pf && atoi(pf) == 0);
@@ -763,22 +768,99 @@ extern "C" int e2vq_last_pass_kernel_ms(e2vq_session* s, float* ms)
     return 0;
 }
 
-// the count of failed recursions of the last fused update arrives at the kernel's end (PublishArgs::h_seq2)
-static int resolve_failed_cells(e2vq_session* s)
+// Waits until the device has stored the current sequence number at *word (host-mapped memory; microseconds).  Safety
+// nets: the event recorded behind the kernel (a kernel that has finished without storing the number: fall back to a
+// stream synchronisation, then fail), a wall-clock limit, and the word the publishing workgroup raises when one of the
+// flags it polls never arrived (its own spin is bounded, so the kernel always ends).
+static int spin_for_sequence(e2vq_session* s, volatile u64* word, const char* what)
 {
-    if (!s->failed_pending) return 0;
-    for (unsigned long spins = 0; s->h_stats->seq2 != s->stats_seq; ++spins) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long spins = 0; *word != s->stats_seq; ++spins) {
         if ((spins & 0xfff) == 0xfff) {
             const hipError_t q = hipEventQuery(s->ev_stats);
             if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) return e2vq_set_error("update kernel failed: %s", hipGetErrorString(q));
+            if (q != hipErrorNotReady) return e2vq_set_error("%s failed: %s", what, hipGetErrorString(q));
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+                return e2vq_set_error("%s: no statistics after 30 s (sequence %llu, device reports %llu)", what,
+                                      (unsigned long long)s->stats_seq, (unsigned long long)*word);
         }
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
     }
-    if (s->h_stats->seq2 != s->stats_seq) HIPCHK(hipStreamSynchronize(s->stream));
+    if (*word != s->stats_seq) {
+        HIPCHK(hipStreamSynchronize(s->stream));
+        if (*word != s->stats_seq)
+            return e2vq_set_error("%s finished without publishing sequence %llu", what, (unsigned long long)s->stats_seq);
+    }
     std::atomic_thread_fence(std::memory_order_acquire);
+    if (s->h_stats->err == s->stats_seq)
+        return e2vq_set_error("%s: the publishing workgroup gave up waiting for a cell's flag (sequence %llu)", what,
+                              (unsigned long long)s->stats_seq);
+    return 0;
+}
+
+// ECOZ2_VQ_VERIFY_PUBLISH=1: everything the update kernel published through host-mapped memory -- level statistics,
+// within-cell terms, the L1 maximum, the count of failed recursions -- is recomputed on the host from a copy of the
+// accumulator rows (after a stream synchronisation) and compared bit for bit.  A lost or early publication would
+// otherwise only show as a different convergence decision.
+static int verify_published(e2vq_session* s, const i64 (&l)[8], double l1max)
+{
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const int NC = s->NC, RS = s->RS, M = s->M;
+    std::vector<i64> rows((size_t)M * RS);
+    std::vector<double> within((size_t)M);
+    u64 l1bits = 0;
+    HIPCHK(hipMemcpy(rows.data(), s->d_rows, rows.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(within.data(), s->d_within, (size_t)M * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&l1bits, s->d_l1max, 8, hipMemcpyDeviceToHost));
+    i64 want[5] = {0, 0, 0, 0, 0}, failed = 0;
+    std::vector<double> S((size_t)NC), rc((size_t)NC), a((size_t)NC);
+    for (int m = 0; m < M; ++m) {
+        const i64* row = rows.data() + (size_t)m * RS;
+        for (int k = 0; k < 4; ++k) want[k] = (i64)((u64)want[k] + (u64)row[2 * NC + 1 + k]);
+        const i64 cnt = row[2 * NC];
+        double w = 0.0;
+        if (cnt == 0) {
+            want[4] += 1;
+        } else {
+            double ss = 0.0;
+            for (int n = 0; n < NC; ++n) {
+                S[(size_t)n] = e2vq::unfix(row[2 * n], row[2 * n + 1], s->h_sc.sh_r);
+                ss += S[(size_t)n] * S[(size_t)n];
+            }
+            w = ss / (double)cnt;
+            if (e2vq_io::lpca_r_host(s->P, S.data(), rc.data(), a.data()) != 0) ++failed;
+        }
+        u64 wb, hb, db;
+        memcpy(&wb, &w, 8);
+        memcpy(&hb, &s->h_within[m], 8);
+        memcpy(&db, &within[(size_t)m], 8);
+        if (wb != hb || wb != db)
+            return e2vq_set_error("publish verification: within-cell term of cell %d: host %.17g, published %.17g, device %.17g "
+                                  "(M = %d, sequence %llu)", m, w, s->h_within[m], within[(size_t)m], M, (unsigned long long)s->stats_seq);
+    }
+    for (int k = 0; k < 5; ++k)
+        if (want[k] != l[k])
+            return e2vq_set_error("publish verification: level statistic %d: rows give %lld, published %lld (M = %d, sequence %llu)",
+                                  k, (long long)want[k], (long long)l[k], M, (unsigned long long)s->stats_seq);
+    u64 pub_l1;
+    memcpy(&pub_l1, &l1max, 8);
+    if (pub_l1 != l1bits)
+        return e2vq_set_error("publish verification: L1 maximum differs (M = %d, sequence %llu)", M, (unsigned long long)s->stats_seq);
+    if (s->h_stats->seq2 != s->stats_seq || s->h_stats->failed != failed)
+        return e2vq_set_error("publish verification: failed recursions: host %lld, published %lld (M = %d, sequence %llu / %llu)",
+                              (long long)failed, (long long)s->h_stats->failed, M, (unsigned long long)s->h_stats->seq2,
+                              (unsigned long long)s->stats_seq);
+    s->verified_passes += 1;
+    return 0;
+}
+
+// the count of failed recursions of the last fused update arrives at the kernel's end (PublishArgs::h_seq2)
+static int resolve_failed_cells(e2vq_session* s)
+{
+    if (!s->failed_pending) return 0;
+    if (spin_for_sequence(s, &s->h_stats->seq2, "update kernel")) return 1;
     s->last.failed_cells = s->h_stats->failed;
     if (s->failed_patch) s->failed_patch->failed_cells = s->h_stats->failed;
     s->failed_patch = nullptr;
@@ -831,6 +913,7 @@ static int pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_fai
         pub.h_seq = (volatile u64*)&dstats->seq;
         pub.h_failed = &dstats->failed;
         pub.h_seq2 = (volatile u64*)&dstats->seq2;
+        pub.h_err = (volatile u64*)&dstats->err;
         pub.seq = ++s->stats_seq;
         e2vq::launch_cell_update(s->d_rows, s->M, s->NC, s->d_sc, s->d_refl, s->d_refl_spec, s->d_cbq_spec,
                                  s->d_cbm_spec, s->d_l1max_spec, s->d_within, s->d_lstats, s->stream,
@@ -858,18 +941,7 @@ static int pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_fai
     HIPCHK(hipGetLastError());
     s->spec_valid = true;
     // spin on the sequence number (microseconds); the event is the safety net should the kernel never get there
-    for (unsigned long spins = 0; s->h_stats->seq != s->stats_seq; ++spins) {
-        if ((spins & 0xfff) == 0xfff) {
-            const hipError_t q = hipEventQuery(s->ev_stats);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) return e2vq_set_error("statistics kernel failed: %s", hipGetErrorString(q));
-        }
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
-#endif
-    }
-    if (s->h_stats->seq != s->stats_seq) HIPCHK(hipStreamSynchronize(s->stream));
-    std::atomic_thread_fence(std::memory_order_acquire);
+    if (spin_for_sequence(s, &s->h_stats->seq, "statistics kernel")) return 1;
     i64 l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int slot = 0; slot < 64; ++slot)
         for (int k = 0; k < 8; ++k) l[k] += s->h_stats->l[slot * 8 + k];
@@ -893,6 +965,7 @@ static int pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_fai
     s->last.inertia = s->h_sc.Q - w;
     s->last.empty_cells = l[4];
     s->last.failed_cells = 0;
+    if (fused && s->verify_publish && verify_published(s, l, l1max)) return 1;
     if (fused) {
         if (wait_failed && resolve_failed_cells(s)) return 1;
     } else {
@@ -910,6 +983,13 @@ static int pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_fai
 }
 
 extern "C" int e2vq_pass_stats(e2vq_session* s, e2vq_level_stats* out) { return pass_stats_impl(s, out, true); }
+
+// passes whose published statistics were verified against a host recomputation (ECOZ2_VQ_VERIFY_PUBLISH=1)
+extern "C" int e2vq_verified_passes(e2vq_session* s, int64_t* passes)
+{
+    if (passes) *passes = s->verified_passes;
+    return 0;
+}
 
 extern "C" int e2vq_update(e2vq_session* s)
 {

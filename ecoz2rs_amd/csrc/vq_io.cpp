@@ -429,7 +429,7 @@ int e2vq_io::seq_write_range(const char* path, int64_t t0, const uint16_t* sym, 
 // `# <file>:` line, `# className='..', T=.., P=..`, the column names r<from>..r<to> (k<..> for reflections), then one
 // line of %.5f values per vector.  Reflections come from the Levinson recursion on the vector's autocorrelation,
 // restated from src/lpc/lpca_r_rs.rs:8-43 (status 1: r0 == 0, 2: prediction error <= 0; such rows print zeros).
-static int host_lpca_r(int P, const double* r, double* rc, double* a)
+int e2vq_io::lpca_r_host(int P, const double* r, double* rc, double* a)
 {
     const double r0 = r[0];
     if (0.0 == r0) return 1;
@@ -475,7 +475,7 @@ extern "C" int ecoz2_prd_show_file(const char* prd_filename, int show_reflection
             const double* v = fr.data() + (size_t)t * NC;
             if (show_reflections) {
                 std::fill(rc.begin(), rc.end(), 0.0);
-                if (host_lpca_r(P, v, rc.data(), a.data()) != 0) std::fill(rc.begin(), rc.end(), 0.0);
+                if (e2vq_io::lpca_r_host(P, v, rc.data(), a.data()) != 0) std::fill(rc.begin(), rc.end(), 0.0);
                 v = rc.data();
             }
             for (int k = from; k <= to; ++k) printf("%s%.5f", k == from ? "" : ",", v[k]);

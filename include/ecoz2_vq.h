@@ -94,6 +94,12 @@ int ecoz2_prd_show_file(const char *prd_filename, int show_reflections, int from
  *   ECOZ2_VQ_QUANTIZE_UNFUSED   1 = quantize with a separate preparation pass (limb image through HBM) instead of the
  *                               fused kernel that builds the limb images of its frames itself (default for P <= 38)
  *   ECOZ2_VQ_IO_THREADS         reader threads per rank / worker for the .prd payloads (default 4)
+ *   ECOZ2_VQ_COLLECTIVE         rccl | p2p: the in-process exchange of ECOZ2_VQ_GPUS > 1 (default: RCCL -- librccl.so is
+ *                               loaded with dlopen -- when every rank has a device of its own, else the peer-to-peer kernel)
+ *   ECOZ2_VQ_QUANTIZE_CHUNK     frames per quantize unit (default 2^17): short files are batched into one sweep, longer
+ *                               files are split over the workers
+ *   ECOZ2_VQ_VERIFY_PUBLISH     1 = check every published pass statistic against a host recomputation (diagnostics)
+ *   ECOZ2_VQ_PRE_LDS            0 = accumulating prefiltered passes on the round-2 kernel (A/B; same results)
  *   ECOZ2_VQ_TIMING             wall time of the stages of ecoz2_vq_learn on stderr (diagnostics)
  *   ECOZ2_VQ_OUT_ROOT           prefix for data/... outputs (default ".")               */
 
@@ -162,6 +168,10 @@ int e2vq_last_pass_info(e2vq_session *s, int *prefiltered, int64_t *fallback_fra
  * kernel trace of a whole run be cut to the dispatches of a timed region */
 int e2vq_sweep_launch_counts(e2vq_session *s, int64_t *prefiltered, int64_t *plain);
 int e2vq_update(e2vq_session *s);
+/* ECOZ2_VQ_VERIFY_PUBLISH=1 (read at session creation): after every pass the statistics the update kernel published
+ * through host-mapped memory (level sums, within-cell terms, L1 maximum, failed recursions) are recomputed on the host
+ * from a copy of the accumulator rows and compared bit for bit; a mismatch fails the call.  Number of passes checked: */
+int e2vq_verified_passes(e2vq_session *s, int64_t *passes);
 /* one whole LBG iteration in a single call: e2vq_pass + e2vq_pass_stats + e2vq_update */
 int e2vq_iterate(e2vq_session *s, void *device_sym, void *device_dmin, e2vq_level_stats *out);
 /* the reduced accumulator rows of the last pass (M x row_stride int64) copied to the host.  Row of a cell: [0, 2 NC) the

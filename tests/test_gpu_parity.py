@@ -165,3 +165,26 @@ def test_large_codebooks_statistics_and_update(oracle, M, T):
     assert (ls.DD, ls.sigma, ls.inertia, ls.empty_cells, ls.failed_cells) == (ls_o.DD, ls_o.sigma, ls_o.inertia, ls_o.empty_cells, failed_o)
     assert ls.empty_cells > M // 2
     assert np.array_equal(cb.view(np.uint64), refl_o.view(np.uint64))
+
+
+def test_publish_verification_mode(oracle, monkeypatch):
+    """ECOZ2_VQ_VERIFY_PUBLISH=1: after every pass the statistics the update kernel published through host-mapped memory
+    while it was still running -- level sums, within-cell terms, L1 maximum, failed recursions -- are recomputed on the host
+    from a copy of the rows and compared bit for bit (a lost or early publication would otherwise only show as a different
+    convergence decision).  A whole ladder to M = 256 with it on: every pass checked, same codebook as the oracle."""
+    import ctypes as C
+
+    monkeypatch.setenv("ECOZ2_VQ_VERIFY_PUBLISH", "1")
+    monkeypatch.setenv("ECOZ2_VQ_QUIET", "1")
+    frames = e.synth.synth_frames(4242, 6, P, 0, 30011)
+    rc, levels_o, _cbs = oracle.learn(frames, 0.05, 256)
+    assert rc == 0
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        levels = s.learn(0.05, 256)
+        v = C.c_int64()
+        e.check(e.lib.e2vq_verified_passes(s._h, C.byref(v)))
+        assert v.value == sum(lv.passes for lv in levels) > 20
+        assert np.array_equal(s.get_codebook().view(np.uint64), levels_o[-1]["reflections"].view(np.uint64))

@@ -13,6 +13,41 @@ import numpy as np
 import ecoz2rs_amd as e
 from tests import oracle_lib
 
+def soak_publish(n_passes, rng, oracle):
+    """Soak of the update kernel's self-publication (statistics through host-mapped memory while the kernel still runs):
+    n_passes LBG iterations in all over M in {2, 64, 1024, 8192}, every one checked by ECOZ2_VQ_VERIFY_PUBLISH=1 (host
+    recomputation of every published number from the rows, bit for bit); uneven data sizes so that the cells' workgroups
+    finish at different times."""
+    import ctypes as C
+    from ecoz2rs_amd._lib import lib
+    os.environ["ECOZ2_VQ_VERIFY_PUBLISH"] = "1"
+    P = 36
+    plan = ((2, 0.30, 3000), (64, 0.30, 20000), (1024, 0.30, 60000), (8192, 0.10, 40000))
+    total = 0
+    t0 = time.time()
+    for M, share, T in plan:
+        want = max(1, int(n_passes * share))
+        frames = e.synth.synth_frames(int(rng.integers(1, 1 << 30)), 7, P, 0, T)
+        done = 0
+        while done < want:
+            src = e.synth.synth_frames(int(rng.integers(1, 1 << 30)), 9, P, 0, M)
+            refl = np.zeros((M, P + 1))
+            for i in range(M):
+                refl[i, 1:] = oracle.lpca_r(src[i], P)[2][1:] * rng.uniform(0.9, 1.0)
+            with e.VqSession(P) as s:
+                s.set_frames(frames[: int(rng.integers(T // 2, T + 1))]); s.prepare(); s.set_codebook(refl)
+                k = min(want - done, 500)
+                for _ in range(k):
+                    s.iterate()
+                v = C.c_int64()
+                lib.e2vq_verified_passes(s._h, C.byref(v))
+                assert v.value == k, (v.value, k)
+                done += k
+        total += done
+        print(f"M={M}: {done} passes verified ({time.time() - t0:.0f} s)", flush=True)
+    print(f"publish soak: {total} / {total} passes verified against the host recomputation")
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -22,6 +57,8 @@ def main():
         return fuzz_prefilter(n, rng, oracle)
     if len(sys.argv) > 3 and sys.argv[3] == "hmm":
         return fuzz_hmm(n, rng)
+    if len(sys.argv) > 3 and sys.argv[3] == "publish":
+        return soak_publish(n, rng, oracle)
     bad = 0
     t0 = time.time()
     for case in range(n):
