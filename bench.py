@@ -4,8 +4,9 @@
 A "step" is one LBG pass of the REAL M=1024 level over the resident shard of every rank:
   sweep+accumulate kernel (K1+K2)  ->  int64 all-reduce of the cell sums (RCCL, N>1)
   ->  level statistics (the host reads DD for the convergence test)  ->  centroid update (K3/K4).
-The timed region repeats the level exactly as the ladder runs it: restore the converged M=512 codebook and its
-DD, split to M=1024, then passes until (DDprv-DD)/DD < eps ends the level (3 passes on this data: one full
+The timed region repeats the level as the ladder runs it: restore the converged M=512 codebook (upload + codeword
+images: inside the timed region; its DD too, which only changes the ratio printed for pass 0 -- pass 0 never ends a
+level), split to M=1024, then passes until (DDprv-DD)/DD < eps ends the level (3 passes on this data: one full
 accumulation + two incremental ones), through the library's own e2vq_learn.  K steps = K such passes (whole
 levels; a remainder of K is run as the leading passes of one more level).
 Frames are synthetic (seeded, counter based: rank r holds frames [r*S, (r+1)*S) of one stream) and
@@ -149,12 +150,21 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU)
+    ap.add_argument("--codebook-size", type=int, default=1024,
+                    help="time this level of the ladder instead of M = 1024 (profiles of the M = 256 / 512 kernels; the "
+                         "metric of BASELINE.json is the default)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the informational extras (steady state, end-to-end ladder, quantize, 16 M-frame run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefilter", action="store_true",
                     help="keep every pass on the plain FP64 sweep (A/B against the prefiltered sweep; same results)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL over xGMI; "
                     "gloo lets several ranks share one GPU when rehearsing the N > 1 path)")
     args = ap.parse_args()
+    M = args.codebook_size
+    FLOP_PER_FRAME_PASS = 2 * M * (P + 1)
+    if M < 4 or M & (M - 1):
+        raise SystemExit("--codebook-size must be a power of two >= 4")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
@@ -265,6 +275,8 @@ def main():
     kernel_ms_total, kernel_passes = sess.timing_total()
     assert kernel_passes == args.steps, (kernel_passes, args.steps)
     prefiltered, fallback_frames = sess.last_pass_info()
+    launches_after = sess.sweep_launch_counts()
+    timed_pre, timed_plain = launches_after[0] - launches_before[0], launches_after[1] - launches_before[1]
     collective = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
@@ -292,47 +304,121 @@ def main():
             "rccl_version": rccl,
         }
 
-    # ---- steady state (informational): back-to-back iterations on the converged M = 1024 codebook, where the
-    # incremental accumulate has almost nothing left to move -- round 1's headline regime, kept as an extra key
-    whole_level()
-    for _ in range(3):
-        sess.iterate(sym, dmin)
-    sess.enable_timing(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        sess.iterate(sym, dmin)
-    fence()
-    steady_ms = (time.perf_counter() - t0) / 10 * 1e3
-    steady_kernel_ms = sess.timing_total()[0] / 10
-
-    # ---- secondary figures (SURVEY 8d ii / iii), outside the timed region, informational --------------------
-    sess.enable_timing(False)
-    sess.init_codebook()
-    fence()
-    t0 = time.perf_counter()
-    e2e_levels = sess.learn(0.05, M)  # the whole ladder 2..1024 with the real convergence rule
-    fence()
-    e2e_s = time.perf_counter() - t0
-    q_rate = None
-    if world == 1:
-        fr = torch.from_numpy(e.synth.synth_frames(SEED, N_CLASSES, P, lo, S)).cuda()
+    extras = not args.no_extras
+    steady_ms = steady_kernel_ms = e2e_s = q_rate = None
+    e2e_levels, level_detail, big = [], [], None
+    if extras:
+        # ---- steady state (informational): back-to-back iterations on the converged codebook, where the
+        # incremental accumulate has almost nothing left to move -- round 1's headline regime, kept as an extra key
+        whole_level()
         for _ in range(3):
-            torch.cuda.synchronize()
+            sess.iterate(sym, dmin)
+        sess.enable_timing(True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            sess.iterate(sym, dmin)
+        fence()
+        steady_ms = (time.perf_counter() - t0) / 10 * 1e3
+        steady_kernel_ms = sess.timing_total()[0] / 10
+
+        # ---- secondary figures (SURVEY 8d ii / iii), outside the timed region, informational --------------------
+        sess.enable_timing(False)
+        sess.init_codebook()
+        fence()
+        t0 = time.perf_counter()
+        e2e_levels = sess.learn(0.05, M)  # the whole ladder 2..M with the real convergence rule, one library call
+        fence()
+        e2e_s = time.perf_counter() - t0
+        # the same ladder level by level (a synchronisation per level: ~30 us each), with the sweep kernel's event time:
+        # per level {passes, kernel ms per pass, step ms per pass, what bounds the level's sweep, fraction of that bound}
+        sess.init_codebook()
+        m = 2
+        while m <= M:
+            sess.enable_timing(True)
+            fence()
             t0 = time.perf_counter()
-            sess.quantize_device(fr, S, sym, dmin)
-            sess.synchronize()
-            q_rate = max(q_rate or 0.0, S / (time.perf_counter() - t0))
-        del fr
+            lvm = sess.learn(0.05, m)[0]
+            fence()
+            wall = time.perf_counter() - t0
+            kms, kn = sess.timing_total()
+            hbm_ms = BYTES_PER_FRAME_PASS * S / (HBM_PEAK_GBS * 1e9) * 1e3
+            fp64_ms = 2.0 * m * (P + 1) * S / (FP64_PEAK_TFLOPS * 1e12) * 1e3
+            f16_ms = F16_MFMA_FLOP_PER_FRAME_CODEWORD * m * S / (F16_PEAK_TFLOPS * 1e12) * 1e3
+            if prefiltered and m >= 256:
+                bound, bound_ms = "f16 mfma (executed limb products)", f16_ms
+            elif hbm_ms >= fp64_ms:
+                bound, bound_ms = "hbm (306 B per frame-pass)", hbm_ms
+            else:
+                bound, bound_ms = "fp64 mfma (2 M (P+1) flop per frame-pass)", fp64_ms
+            level_detail.append({"M": m, "passes": lvm.passes, "kernel_ms": kms / max(1, kn), "step_ms": wall / lvm.passes * 1e3,
+                                 "bound": bound, "bound_ms": bound_ms, "frac_of_bound": bound_ms / (kms / max(1, kn))})
+            m *= 2
+        sess.enable_timing(False)
+        if world == 1:
+            fr = torch.from_numpy(e.synth.synth_frames(SEED, N_CLASSES, P, lo, S)).cuda()
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                sess.quantize_device(fr, S, sym, dmin)
+                sess.synchronize()
+                q_rate = max(q_rate or 0.0, S / (time.perf_counter() - t0))
+            del fr
+        # ---- config 4's whole set (2^24 frames) on ONE GPU: strong-scaling reference point, informational ----------------
+        if world == 1 and M == 1024 and S == FRAMES_PER_GPU and not os.environ.get("ECOZ2_BENCH_SKIP_16M"):
+            try:
+                T16 = 1 << 24
+                t0 = time.perf_counter()
+                fr16 = e.synth.synth_frames(SEED, N_CLASSES, P, 0, T16)
+                synth_s = time.perf_counter() - t0
+                with e.VqSession(P, device=local) as s16:
+                    t0 = time.perf_counter()
+                    s16.set_frames(fr16)
+                    s16.prepare()
+                    s16.synchronize()
+                    upload_s = time.perf_counter() - t0
+                    del fr16
+                    s16.init_codebook()
+                    s16.learn(0.05, M // 2)
+                    s16.enable_timing(True)
+                    s16.synchronize()
+                    t0 = time.perf_counter()
+                    lv16 = s16.learn(0.05, M)[0]
+                    s16.synchronize()
+                    level_s = time.perf_counter() - t0
+                    kms16, kn16 = s16.timing_total()
+                    s16.enable_timing(False)
+                    s16.init_codebook()
+                    s16.synchronize()
+                    t0 = time.perf_counter()
+                    lad16 = s16.learn(0.05, M)
+                    s16.synchronize()
+                    ladder_s = time.perf_counter() - t0
+                big = {
+                    "what": f"config 4's whole training set ({T16} frames) resident on ONE GPU: the M={M} level and the whole ladder",
+                    "frames": T16,
+                    "host_synth_seconds": round(synth_s, 2),
+                    "upload_relayout_statistics_seconds": round(upload_s, 3),
+                    "level_passes": lv16.passes,
+                    "level_kernel_ms_per_pass": kms16 / max(1, kn16),
+                    "level_ms_per_pass": level_s / lv16.passes * 1e3,
+                    "level_frames_per_sec": T16 * lv16.passes / level_s,
+                    "ladder_seconds": round(ladder_s, 4),
+                    "ladder_frames_per_sec": T16 / ladder_s,
+                    "ladder_passes_per_level": [x.passes for x in lad16],
+                }
+            except Exception as ex:  # (a box short of host memory: the figure is informational)
+                big = {"error": repr(ex)}
 
     if rank == 0:
         k_ms = kernel_ms_total / kernel_passes
         frames_per_launch = S
         # PMC traffic cannot be collected inside this process: it comes from separate rocprofv3 --pmc passes over this
-        # same command (tools/summarize_profiles.py -> profiles/r02_traffic.json).  The file records the hash of the
+        # same command (tools/summarize_profiles.py -> profiles/r03_traffic*.json).  The file records the hash of the
         # kernel sources it was measured on; a figure measured on other sources is reported as stale (null).
         traffic, traffic_detail = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json" if prefiltered else "r02_traffic_noprefilter.json")
+        tname = "r03_traffic" + ("" if M == 1024 else f"_M{M}") + ("" if prefiltered else "_noprefilter") + ".json"
+        tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and S == FRAMES_PER_GPU:
             try:
                 tj = json.load(open(tpath))
@@ -365,7 +451,8 @@ def main():
                 "traffic_detail": traffic_detail,
                 "kernel_ms": k_ms,
                 "launches": kernel_passes,
-                "trace_dispatches": {"kernel": "k_pass_pre", "first": launches_before[0], "count": kernel_passes},
+                "trace_dispatches": {"kernel": "k_pass_pre", "first": launches_before[0], "count": timed_pre,
+                                     "plain_first": launches_before[1], "plain_count": timed_plain},
                 "work_per_launch": f"{F16_MFMA_FLOP_PER_FRAME_CODEWORD} f16 MFMA flop x {M} codewords x {S} frames "
                                    "(limb products actually issued)",
                 "executed_dtype": "f16 limbs (exact integers) -> f32 accumulators; candidates in f64",
@@ -394,10 +481,10 @@ def main():
                 "traffic_detail": traffic_detail,
                 "kernel_ms": k_ms,
                 "launches": kernel_passes,
-                "trace_dispatches": {"kernel": "k_pass_mfma", "first": launches_before[1], "count": kernel_passes},
+                "trace_dispatches": {"kernel": "k_pass_mfma", "first": launches_before[1], "count": timed_plain},
             }
         out = {
-            "metric": "vq_learn_frames_per_sec_M1024_P36",
+            "metric": f"vq_learn_frames_per_sec_M{M}_P36",
             "value": world * S * args.steps / dt,
             "unit": "frames/s",
             "n_gpus": world,
@@ -411,9 +498,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"vq learn, the real M={M} level at P={P}: {S} frames per GPU (config 4 shard: 16M frames "
-                            f"over 8 GPUs); per repetition the converged M={M // 2} codebook is restored, split, and "
-                            f"passes run until (DDprv-DD)/DD < {EPS} ({L} passes: 1 full + {L - 1} incremental "
-                            f"accumulations); a step = one such pass; eps={EPS} ladder 2..{M // 2} run untimed first",
+                            f"over 8 GPUs); per repetition the converged M={M // 2} codebook is restored (its upload and the "
+                            f"rebuild of the codeword images are inside the timed region), split, and passes run until "
+                            f"(DDprv-DD)/DD < {EPS} ({L} passes: 1 full + {L - 1} incremental accumulations); a step = one "
+                            f"such pass; eps={EPS} ladder 2..{M // 2} run untimed first",
                 "frames_per_gpu": S,
                 "codebook_size": M,
                 "prediction_order": P,
@@ -424,20 +512,28 @@ def main():
                          if prefiltered else "plain FP64 MFMA sweep",
                 "ladder_seconds_untimed": round(t_ladder, 3),
                 "final_avg_distortion": st.avg_distortion,
-                "steady_state": {
+                "timed_sweep_launches": {"prefiltered": timed_pre, "plain": timed_plain},
+                "steady_state": None if not extras else {
                     "what": "back-to-back iterations on the converged codebook (incremental accumulate nearly idle): "
                             "round 1's headline regime, informational",
                     "ms_per_step": steady_ms,
                     "kernel_ms": steady_kernel_ms,
                     "frames_per_sec": world * S / (steady_ms * 1e-3),
                 },
-                "learn_end_to_end": {
-                    "what": f"whole LBG ladder M=2..{M}, eps=0.05, resident frames, all ranks",
+                "learn_end_to_end": None if not extras else {
+                    "what": f"whole LBG ladder M=2..{M}, eps=0.05, resident frames, all ranks, one library call",
                     "seconds": round(e2e_s, 4),
                     "frames_per_sec": world * S / e2e_s,
                     "passes_per_level": [lv.passes for lv in e2e_levels],
+                    "levels": level_detail,
+                    "levels_note": "the same ladder run level by level (one synchronisation per level): sweep-kernel time "
+                                   "per pass from HIP events, step = wall time of the level / its passes; bound = what the "
+                                   "level's sweep is priced against (HBM for M <= 32, the FP64 matrix pipe for the plain "
+                                   "sweep of 64 <= M <= 128, the f16 limb products actually issued for the prefiltered "
+                                   "levels; the first, full pass of M = 256 runs the plain sweep)",
                 },
                 "quantize_frames_per_sec_device_resident": q_rate,
+                "strong_scaling_16M": big,
             },
             "roofline": roofline,
             "roofline_algorithmic": roofline_algorithmic,

@@ -74,9 +74,13 @@ def counters(path, hint):
 
 def main():
     os.makedirs(DST, exist_ok=True)
+    global M
     b = bench_line("kt")
     hint = b["roofline"]["trace_dispatches"]
+    M = b["config"].get("codebook_size", 1024)
     L = b["config"]["passes_per_level"]
+    if hint["kernel"] == "k_pass_pre" and hint["count"] != b["steps"]:
+        L = max(1, hint["count"] * L // b["steps"])  # (some passes of the level ran the plain sweep: M = 256)
     kt = newest(f"{SRC}/{TAG}_kt/*/*_kernel_trace.csv")
     rows = timed_rows(kt, hint)
     d = [ms(r) for r in rows]
@@ -94,9 +98,10 @@ def main():
         "source": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --steps 21 "
                   f"--warmup 3; timed dispatches = {hint['kernel']} launches [{hint['first']}, {hint['first'] + hint['count']})",
     }
-    json.dump(out, open(f"{DST}/{TAG}_pass_kernel.json", "w"), indent=1)
-    shutil.copy(newest(f"{SRC}/{TAG}_kt/*/*_kernel_stats.csv"), f"{DST}/{TAG}_kernel_stats.csv")
-    json.dump(b, open(f"{DST}/{TAG}_bench_under_trace.json", "w"), indent=1)
+    sfx = "" if M == 1024 else f"_M{M}"
+    json.dump(out, open(f"{DST}/{TAG}_pass_kernel{sfx}.json", "w"), indent=1)
+    shutil.copy(newest(f"{SRC}/{TAG}_kt/*/*_kernel_stats.csv"), f"{DST}/{TAG}_kernel_stats{sfx}.csv")
+    json.dump(b, open(f"{DST}/{TAG}_bench_under_trace{sfx}.json", "w"), indent=1)
     print(json.dumps(out, indent=1))
 
     # ---- PMC traffic ------------------------------------------------------------------------------------------
@@ -117,7 +122,7 @@ def main():
             "kernel_sources_sha16": kernel_sources_sha16(),
             "note": "average over the timed launches (full-accumulate and incremental passes of the level mixed as in the bench)",
         }
-        json.dump(tj, open(f"{DST}/{TAG}_traffic{'' if prefiltered else '_noprefilter'}.json", "w"), indent=1)
+        json.dump(tj, open(f"{DST}/{TAG}_traffic{sfx}{'' if prefiltered else '_noprefilter'}.json", "w"), indent=1)
         print("fetch raw KB", f["FETCH_SIZE"], "write raw KB per step", [round(x["WRITE_SIZE"]) for x in wsel])
     except (IndexError, FileNotFoundError, KeyError) as ex:
         print("no PMC traffic passes:", ex)
@@ -142,7 +147,7 @@ def main():
             f16 = (T // 32) * (M // 32) * 15
             sq["expected_f16_mfma_instructions"] = f16
             sq["fp64_mfma_instructions"] = c["SQ_INSTS_MFMA"] - f16
-        json.dump(sq, open(f"{DST}/{TAG}_sq_counters.json", "w"), indent=1)
+        json.dump(sq, open(f"{DST}/{TAG}_sq_counters{sfx}.json", "w"), indent=1)
         print({k: sq[k] for k in ("kernel_ms_under_pmc", "clock_GHz_under_pmc", "mfma_pipe_busy_fraction",
                                   "other_valu_instructions_per_mfma")})
     except (IndexError, FileNotFoundError, KeyError) as ex:
