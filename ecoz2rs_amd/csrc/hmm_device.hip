@@ -41,7 +41,7 @@ __device__ __forceinline__ void scale_step(double c, double& p, i64& E)
 constexpr int SCORE_WAVES = 4;
 
 // grid: (ceil(S / SCORE_WAVES), K).  models[k]: N, M, pi, A, B.  out index: s * K + k.
-__global__ __launch_bounds__(64 * SCORE_WAVES) void k_hmm_score(const ModelDev* __restrict__ models, int K,
+__global__ __launch_bounds__(64 * SCORE_WAVES) void k_hmm_score(const ModelDev* __restrict__ models, int K, int k0,
                                                                  const unsigned short* __restrict__ sym,
                                                                  const i64* __restrict__ offs, int S,
                                                                  double* __restrict__ mant, i64* __restrict__ exp2,
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64 * SCORE_WAVES) void k_hmm_score(const ModelDev* 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* As = (double*)smem;  // [N][N], row i = from-state
-    const int k = blockIdx.y;
+    const int k = k0 + (int)blockIdx.y;  // (models beyond 65535 come in further launches)
     const ModelDev md = models[k];
     const int N = md.N, M = md.M;
     for (int x = threadIdx.x; x < N * N; x += blockDim.x) As[x] = md.A[x];
@@ -101,6 +101,8 @@ __global__ __launch_bounds__(64 * SCORE_WAVES) void k_hmm_score(const ModelDev* 
             scale_step(c, p, E);
         }
     }
+    // (an empty sequence scores P = 1 = 0.5 * 2^1 with status 0: the empty product; the E-step reports the same P but
+    // status 1 -- "not used": an empty sequence has no counts to give and must not enter the pi denominator)
     if (lane == 0) {
         const size_t idx = (size_t)s * K + k;
         mant[idx] = st == 0 ? p : 0.0;
@@ -319,9 +321,13 @@ void launch_score(const ModelDev* models, int K, int maxN, const unsigned short*
                   i64* exp2, int* status, hipStream_t st)
 {
     if (S < 1 || K < 1) return;
-    const dim3 grid((unsigned)((S + SCORE_WAVES - 1) / SCORE_WAVES), (unsigned)K);
-    hipLaunchKernelGGL(k_hmm_score, grid, dim3(64 * SCORE_WAVES), (size_t)maxN * maxN * 8, st, models, K, sym, offs, S,
-                       mant, exp2, status);
+    // grid.y carries the models: at most 65535 per launch (HIP's limit for that dimension), more in further launches
+    for (int k0 = 0; k0 < K; k0 += 65535) {
+        const int kn = K - k0 < 65535 ? K - k0 : 65535;
+        const dim3 grid((unsigned)((S + SCORE_WAVES - 1) / SCORE_WAVES), (unsigned)kn);
+        hipLaunchKernelGGL(k_hmm_score, grid, dim3(64 * SCORE_WAVES), (size_t)maxN * maxN * 8, st, models, K, k0, sym, offs, S,
+                           mant, exp2, status);
+    }
 }
 
 void launch_fb(const ModelDev& md, const unsigned short* sym, const i64* offs, int S, double* alpha_buf, double* c_buf,
@@ -329,7 +335,9 @@ void launch_fb(const ModelDev& md, const unsigned short* sym, const i64* offs, i
 {
     if (S < 1) return;
     const size_t lds = (size_t)md.N * md.N * (2 * 8 + 16);  // A, A^T, and the workgroup's AN limb table: 128 KB at N = 64
-    (void)hipFuncSetAttribute((const void*)k_hmm_fb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (a refusal shows up as a launch failure below, which the caller's hipGetLastError reports; say why here)
+    if (hipFuncSetAttribute((const void*)k_hmm_fb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        fprintf(stderr, "ecoz2vq: the device refuses 160 KB of dynamic LDS for the E-step kernel (N = %d needs %zu bytes)\n", md.N, lds);
     const int blocks = (S + FB_WAVES - 1) / FB_WAVES;
     const int grid = blocks < 2048 ? blocks : 2048;  // persistent: each workgroup flushes its AN table once
     hipLaunchKernelGGL(k_hmm_fb, dim3((unsigned)grid), dim3(64 * FB_WAVES), lds, st, md, sym, offs, S, alpha_buf, c_buf, acc,

@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
     const long nwaves = (long)gridDim.x * (TPBM >> 6);
     unsigned char* wbase = smem + (size_t)wib * PL::WAVE_BYTES;
     double* stage = (double*)wbase;
-    int* stagei = (int*)wbase;
+    const int* stagei = (const int*)wbase;
     const float* fgs = (const float*)(wbase + PL::STAGE_BYTES);
     const unsigned short* prevs = (const unsigned short*)(wbase + PL::STAGE_BYTES + 256);
     E2VQ_STAMP_DECL
@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
             }
             E2VQ_PRE_JOB_ORDERED(acc0, B[0], acc1, (t - 1) & 0xffff, 1)  // (t = 0: the "previous" accumulators hold 3e38)
             E2VQ_PRE_JOB_ORDERED(acc1, B[1], acc0, t, 0)
-#ifdef E2VQ_PRE_STAMP
+#if defined(E2VQ_PRE_STAMP) && E2VQ_PRE_STAMP == 3  // (stamps inside the loop cost the sweep ~30 %: a build of their own)
             if (t == 0) E2VQ_STAMP(8)   // tile 0 (operands prefetched)
             if (t == 1) E2VQ_STAMP(10)  // tile 1 (its loads queue behind the previous block's atomics and this block's LDS-DMA)
 #endif
@@ -1251,6 +1251,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         const float g = live ? fgs[ln] : 0.f;
         const float tau = 1.27f * (512.f * (g + ymax1 + (NC + 4.0f)) + relk * t1);
         const bool cert = t1 >= 1.0e-30f && t1 < 1.0e37f && w3 > t1 + tau;
+        const bool amb = !(u2 > t1 + tau);  // the runner-up is within reach: it needs the exact evaluation too
         const int c1 = __float_as_int(t1) & ~idxmask, c2 = __float_as_int(u2) & ~idxmask;
         const int old = incr ? (int)prevs[ln] : 0;
         E2VQ_STAMP(2)  // merge, certification
@@ -1268,9 +1269,13 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
             const double2* r2 = (const double2*)(cbq + (long)c2 * NPAD);
             double2 x[NH], y[NH];
 #pragma unroll
-            for (int n2 = 0; n2 < NH; ++n2) {  // (rows are padded to a multiple of 8 doubles)
-                x[n2] = r1[n2];
-                y[n2] = r2[n2];
+            for (int n2 = 0; n2 < NH; ++n2) x[n2] = r1[n2];  // (rows are padded to a multiple of 8 doubles)
+            // (the runner-up's row only where it can matter: a gather costs the texture path a request per lane)
+#pragma unroll
+            for (int n2 = 0; n2 < NH; ++n2) y[n2] = make_double2(0.0, 0.0);
+            if (amb) {
+#pragma unroll
+                for (int n2 = 0; n2 < NH; ++n2) y[n2] = r2[n2];
             }
             const double* fr = stage + ln * NC;
             double d1 = 0.0, d2 = 0.0;
@@ -1286,14 +1291,23 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
                     d2 = __builtin_fma(f1, y[n2].y, d2);
                 }
             }
-            // (a runner-up whose key is out of reach cannot win: comparing it anyway changes nothing)
-            const bool take_b = d2 < d1 || (d2 == d1 && c2 < c1);
+            const bool take_b = amb && (d2 < d1 || (d2 == d1 && c2 < c1));
             best = take_b ? d2 : d1;
             idx = take_b ? c2 : c1;
         }
         const bool skip = !cert;
         idx = skip ? 0 : idx;
         E2VQ_STAMP(3)  // exact evaluation
+
+        // ---- the next block's limb images and first codeword tile: requested now -- behind the register-hungry chains,
+        // ahead of the outputs and the distortion sums, which cover part of their latency -- and complete before the atomics go out
+        {   // (unconditional -- the wave's last block reloads its own images: a conditional load would keep the old B and A
+            // alive, 116 registers, through the evaluation above)
+            const long bl = bn < nblocks ? bn : b;
+            E2VQ_LDS_LOAD_B(bl, ln)
+            E2VQ_LDS_LOAD_A(0, ln)
+        }
+
 
         // ---- outputs; uncertified frames go to the fallback list -----------------------------------------------------
         if (live) {
@@ -1309,6 +1323,8 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         // with the block's other atomics (no per-lane running sums to keep across the tile loops)
         i64 dsum;
         {
+            // (tried: four ds_add_u64 per lane into four words of the wave's LDS region instead of the shuffles below -- 64
+            // adds on one address serialise at ~100 cycles each: 27 k cycles per block against 2.7 k)
             int h0 = 0, l0 = 0, h1 = 0, l1 = 0;
             if (live && !skip) {
                 const double e = best - 1.0;
@@ -1326,40 +1342,37 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         }
         E2VQ_STAMP(4)  // outputs
 
-        // ---- the next block's limb images and first codeword tile: requested now -- behind the register-hungry chains,
-        // ahead of the limb conversion, which covers most of their latency -- and complete before the atomics go out
-        {   // (unconditional -- the wave's last block reloads its own images: a conditional load would keep the old B and A
-            // alive, 116 registers, through the evaluation above)
-            const long bl = bn < nblocks ? bn : b;
-            E2VQ_LDS_LOAD_B(bl, ln)
-            E2VQ_LDS_LOAD_A(0, ln)
-        }
-
-
-        // ---- frames that contribute (all of a full pass, the movers of an incremental one): rows -> limb pairs, in place
+        // ---- frames that contribute: all of a full pass, the movers of an incremental one ---------------------------------
         const bool mov = live && !skip && (!incr || old != idx);
-        if (mov) {
-            double* fr = stage + ln * NC;
-            if (fast_fix) {  // (wave-uniform: 2^sh_r is a normal double)
+        // Many contributors (a full pass; the first incremental pass of a level): every contributing lane converts its own
+        // row to limb pairs in place -- 37 conversions per lane, whatever the number of contributors.  Few: the lanes of
+        // each atomic convert just the value they add (below) -- one conversion per lane and contributor.
+        const u64 movers = __ballot(mov);
+        const bool bulk = __builtin_popcountll(movers) > 28;  // wave-uniform
+        if (bulk) {
+            if (mov) {
+                double* fr = stage + ln * NC;
+                if (fast_fix) {
 #pragma unroll
-                for (int n = 0; n < NC; ++n) {
-                    int hi, lo;
-                    fix2_mul(fr[n], scale_r, hi, lo);
-                    *(int2*)&fr[n] = make_int2(hi, lo);
-                }
-            } else {
+                    for (int n = 0; n < NC; ++n) {
+                        int hi, lo;
+                        fix2_mul(fr[n], scale_r, hi, lo);
+                        *(int2*)&fr[n] = make_int2(hi, lo);
+                    }
+                } else {
 #pragma unroll 1
-                for (int n = 0; n < NC; ++n) {
-                    int hi, lo;
-                    fix2(fr[n], sh_r, hi, lo);
-                    *(int2*)&fr[n] = make_int2(hi, lo);
+                    for (int n = 0; n < NC; ++n) {
+                        int hi, lo;
+                        fix2(fr[n], sh_r, hi, lo);
+                        *(int2*)&fr[n] = make_int2(hi, lo);
+                    }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        E2VQ_STAMP(5)  // limb conversion
+        E2VQ_STAMP(5)  // limb conversion (bulk)
 
         // ---- the block's atomics, four frames per step ------------------------------------------------------------------
         // Every load of this block -- and of the next block's limb images -- has to be complete before the first atomic:
@@ -1367,11 +1380,22 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         // that the compiler's own counter bookkeeping sees it and inserts no later wait for those registers.
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         {
-            u64 mm = __ballot(mov);
+            u64 mm = movers;
             const int tq = ln >> 4, te = ln & 15;
             constexpr int NE = PL::NE;            // limb pairs + count
             constexpr bool TAIL = NE > 64;        // rows longer than a wave: one more add carries four row tails
             constexpr int NT = TAIL ? NE - 64 : 0;  // tail elements, the count last
+            // lane e of a 64-lane add handles element e = 2 n + limb of a frame's contribution: it reads coefficient n from
+            // the frame's LDS row and converts it itself (pairs of lanes convert the same value and keep one limb each): one
+            // conversion per lane and contributing frame, where converting whole rows in place cost every lane 37 of them
+            auto limb = [&](double x, int odd) -> int {
+                int hi, lo;
+                if (fast_fix)
+                    fix2_mul(x, scale_r, hi, lo);
+                else
+                    fix2(x, sh_r, hi, lo);
+                return odd ? lo : hi;
+            };
             while (mm != 0) {
                 int f[4], cell[4], oldc[4], v[4];
                 bool on[4];
@@ -1383,7 +1407,8 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
                     cell[k] = __builtin_amdgcn_readlane(idx, f[k]);
                     oldc[k] = __builtin_amdgcn_readlane(old, f[k]);
                     const int e = ln;  // element handled in the full-width add
-                    v[k] = e < 2 * NC ? stagei[f[k] * (2 * NC) + e] : 1;  // (e == 2 NC, short rows only: the count)
+                    v[k] = e >= 2 * NC ? 1  // (e == 2 NC, short rows only: the count)
+                                       : (bulk ? stagei[f[k] * (2 * NC) + e] : limb(stage[f[k] * NC + (e >> 1)], e & 1));
                 }
                 int tv = 0, tcell = 0, told = 0;
                 bool ton = false;
@@ -1392,7 +1417,8 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
                     ton = tq == 0 ? on[0] : tq == 1 ? on[1] : tq == 2 ? on[2] : on[3];
                     tcell = tq == 0 ? cell[0] : tq == 1 ? cell[1] : tq == 2 ? cell[2] : cell[3];
                     told = tq == 0 ? oldc[0] : tq == 1 ? oldc[1] : tq == 2 ? oldc[2] : oldc[3];
-                    tv = te < NT - 1 ? stagei[tf * (2 * NC) + 64 + te] : 1;
+                    const int et = 64 + te;  // (te < NT - 1: a limb; te == NT - 1: the count)
+                    tv = te >= NT - 1 ? 1 : (bulk ? stagei[tf * (2 * NC) + et] : limb(stage[tf * NC + (et >> 1)], et & 1));
                     ton = ton && te < NT;
                 }
 #pragma unroll

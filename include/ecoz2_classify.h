@@ -84,7 +84,12 @@ typedef void (*ecoz2_hmm_learn_callback_t)(char *variable, double value);
  * GPU (one wavefront per sequence, exact fixed-point expected counts), M-step on the GPU, until the increase of
  * sum ln P drops to val_auto or max_iterations (>= 0) E+M steps ran.  hmm_epsilon > 0 floors B and renormalises.
  * Writes data/hmms/N<N>__M<M>_t<type>__a<val_auto>[_I<max>]/<class>.hmm (+ .csv with the measure per iteration).
- * use_par is accepted and ignored. */
+ * use_par is accepted and ignored.
+ * Limits: 1 <= N <= 64 (one lane of a wavefront per state; the reference's -N is free: larger N fail with a message).
+ * An empty sequence is skipped by the training (no counts, not in the pi denominator) and scores P = 1 in classify.
+ * ECOZ2_VQ_GPUS = W: the sequences are dealt to W workers (devices ECOZ2_VQ_DEVICE + w modulo the device count); the
+ * exact int64 expected counts are summed over the workers each E-step, so the model is the single worker's bit for
+ * bit; ecoz2_hmm_classify / ecoz2_hmm_classify_predictors deal the sequences / predictor files the same way. */
 int ecoz2_hmm_learn(int N, int model_type, const char *const *sequence_filenames, unsigned num_sequences,
                     double hmm_epsilon, double val_auto, int max_iterations, int use_par,
                     ecoz2_hmm_learn_callback_t callback);
