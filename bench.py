@@ -4,10 +4,10 @@
 A "step" is one LBG pass of the REAL M=1024 level over the resident shard of every rank:
   sweep+accumulate kernel (K1+K2)  ->  int64 all-reduce of the cell sums (RCCL, N>1)
   ->  level statistics (the host reads DD for the convergence test)  ->  centroid update (K3/K4).
-The timed region repeats the level as the ladder runs it: restore the converged M=512 codebook (upload + codeword
-images: inside the timed region; its DD too, which only changes the ratio printed for pass 0 -- pass 0 never ends a
-level), split to M=1024, then passes until (DDprv-DD)/DD < eps ends the level (3 passes on this data: one full
-accumulation + two incremental ones), through the library's own e2vq_learn.  K steps = K such passes (whole
+The timed region repeats the level as the ladder runs it: restore the point where the M=512 level ended (device copies
+of the codebook, its rows and cells, and the rebuild of the codeword images: inside the timed region), split to M=1024,
+then passes until (DDprv-DD)/DD < eps ends the level (3 passes on this data: the first seeded with the parents' sums,
+two incremental ones), through the library's own e2vq_learn.  K steps = K such passes (whole
 levels; a remainder of K is run as the leading passes of one more level).
 Frames are synthetic (seeded, counter based: rank r holds frames [r*S, (r+1)*S) of one stream) and
 resident in HBM before the timed region.  Weak scaling: S = 2^21 frames per GPU (config 4's shard).
@@ -218,15 +218,13 @@ def main():
     levels = sess.learn(0.05, M // 2)  # real LBG ladder 2..512 (untimed) -> realistic codebook state
     torch.cuda.synchronize()
     t_ladder = time.time() - t_ladder
-    cb512 = sess.get_codebook()          # the converged M = 512 codebook ...
-    dd512 = levels[-1].DD                # ... and the DD the stopping rule carries into the M = 1024 level
+    sess.save_state()  # the converged M / 2 codebook, its DD, and the rows and cells the next level's seeded first pass starts from
     sym = torch.empty(S, dtype=torch.int16, device=f"cuda:{local}")
     dmin = torch.empty(S, dtype=torch.float64, device=f"cuda:{local}")
     EPS = 0.05
 
     def restore():
-        sess.set_codebook(cb512)
-        sess.set_prev_distortion(dd512)
+        sess.restore_state()
 
     def whole_level():
         """the M = 1024 level through the library's LBG driver (e2vq_learn): split + passes until convergence"""
@@ -498,10 +496,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"vq learn, the real M={M} level at P={P}: {S} frames per GPU (config 4 shard: 16M frames "
-                            f"over 8 GPUs); per repetition the converged M={M // 2} codebook is restored (its upload and the "
-                            f"rebuild of the codeword images are inside the timed region), split, and passes run until "
-                            f"(DDprv-DD)/DD < {EPS} ({L} passes: 1 full + {L - 1} incremental accumulations); a step = one "
-                            f"such pass; eps={EPS} ladder 2..{M // 2} run untimed first",
+                            f"over 8 GPUs); per repetition the point where the M={M // 2} level ended is restored (device copies "
+                            f"and the rebuild of the codeword images: inside the timed region), split, and passes run until "
+                            f"(DDprv-DD)/DD < {EPS} ({L} passes: the first seeded with the parents' sums -- in-family frames "
+                            f"add once or not at all --, {L - 1} incremental ones); a step = one such pass; eps={EPS} ladder 2..{M // 2} run untimed first",
                 "frames_per_gpu": S,
                 "codebook_size": M,
                 "prediction_order": P,

@@ -71,6 +71,8 @@ _sig("e2vq_init_codebook", C.c_int, C.c_void_p)
 _sig("e2vq_grow", C.c_int, C.c_void_p)
 _sig("e2vq_pass", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("e2vq_pass_stats", C.c_int, C.c_void_p, C.POINTER(LevelStatsC))
+_sig("e2vq_save_state", C.c_int, C.c_void_p)
+_sig("e2vq_restore_state", C.c_int, C.c_void_p)
 _sig("e2vq_verified_passes", C.c_int, C.c_void_p, C.POINTER(C.c_int64))
 _sig("e2vq_update", C.c_int, C.c_void_p)
 _sig("e2vq_enable_timing", C.c_int, C.c_void_p, C.c_int)

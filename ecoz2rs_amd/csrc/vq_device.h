@@ -59,7 +59,7 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                             long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
                             hipStream_t s, const double* rowmajor_frames = nullptr, const int* ea_fused = nullptr,
-                            const double* resident_rowmajor = nullptr);
+                            const double* resident_rowmajor = nullptr, long long* family_table = nullptr);
 // resident_rowmajor (accumulating passes): a row-major copy of the training frames padded with zero rows to whole
 // 64-frame blocks; with it (and prefilter_lds_stage(NC)) the pass runs k_pass_pre_lds; prev_sym must then be padded
 // by 128 bytes
@@ -68,10 +68,15 @@ bool prefilter_lds_stage(int NC);
 // its frames from rowmajor_frames with the per-coefficient scales ea_fused (launch_prefilter_quantize_scales)
 bool prefilter_fused_quantize(int NC);
 void launch_prefilter_quantize_scales(const double* cbq, int M, int NC, int* ea, hipStream_t s);
+// incremental: 0 = full, 1 = incremental (old cell = prev_sym), 2 = the seeded first pass of a level (old cell = 2 prev_sym)
 int launch_pass_fallback(int NC, bool accumulate, const double* blk, const double* cbm, int M, const DevScalars* sc,
                          const unsigned long long* l1max_bits, unsigned short* sym, double* dmin, long long* rows,
-                         const int* fb_list, const int* fb_count, unsigned short* prev_sym, bool incremental,
+                         const int* fb_list, const int* fb_count, unsigned short* prev_sym, int incremental,
                          hipStream_t s, bool rowmajor = false);
+// the seeded first pass after a split (vq_device.hip: k_seed_family): rows <- parents' sums in the even children, X <- 0;
+// after the pass (and its fallback sweep) launch_family_fixup moves the in-family arrivals X[i] from row 2 i to row 2 i + 1
+void launch_seed_family(const long long* parent, long long* rows, long long* X, int Mold, int NC, hipStream_t s);
+void launch_family_fixup(long long* rows, const long long* X, int Mold, int NC, hipStream_t s);
 void launch_zero_distortion_columns(long long* rows, int M, int NC, hipStream_t s);
 void launch_rows_stats(const long long* rows, int M, int NC, const DevScalars* sc, double* S, double* within,
                        long long* lstats, hipStream_t s);

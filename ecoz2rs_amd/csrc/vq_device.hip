@@ -460,7 +460,9 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             // fallback of a prefiltered pass: incremental like the pass it completes (vq_accum.h)
             const long slot = b * FPB + j;
             const long t = slot < T ? fb_list[slot] : -1;
-            const int oldidx[4] = {(incr && t >= 0) ? (int)prev_sym[t] : 0, 0, 0, 0};
+            // (incr == 2: the first pass after a split, rows seeded with the parents' sums -- the frame counts as sitting
+            // in the even child of its old cell; see k_seed_family)
+            const int oldidx[4] = {(incr && t >= 0) ? (incr == 2 ? 2 : 1) * (int)prev_sym[t] : 0, 0, 0, 0};
             accumulate_block<NC, MODE, false, NFT, true>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2, b, T,
                                                          lane, {false, false, false, false}, incr != 0, oldidx);
             if (prev_sym && q == 0 && t >= 0) prev_sym[t] = (unsigned short)idx[0];
@@ -1186,7 +1188,7 @@ int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const
 // full FP64 sweep of the frames a prefiltered pass could not certify (vq_prefilter.hip): fb_list[0 .. *fb_count)
 int launch_pass_fallback(int NC, bool accumulate, const double* blk, const double* cbm, int M, const DevScalars* sc,
                          const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows, const int* fb_list,
-                         const int* fb_count, unsigned short* prev_sym, bool incremental, hipStream_t s, bool rowmajor)
+                         const int* fb_count, unsigned short* prev_sym, int incremental, hipStream_t s, bool rowmajor)
 {
     const int MT = (M + 15) / 16;
     switch (NC) {
@@ -1196,7 +1198,7 @@ int launch_pass_fallback(int NC, bool accumulate, const double* blk, const doubl
         const size_t lds = (size_t)4 * 16 * (2 * N + 5 + IMG_STRIDE_PAD) * 4 + (size_t)2 * 4 * 64 * (8 + 4);          \
         if (accumulate)                                                                                                \
             hipLaunchKernelGGL((k_pass_mfma<N, 2, 256, 2>), dim3(1024), dim3(256), lds, s, blk, 0L, 0L, cbm, MT, M, sc, \
-                               l1max_bits, sym, dmin, rows, 0, fb_list, fb_count, prev_sym, incremental ? 1 : 0,      \
+                               l1max_bits, sym, dmin, rows, 0, fb_list, fb_count, prev_sym, incremental,              \
                                rowmajor ? 1 : 0);                                                                      \
         else                                                                                                           \
             hipLaunchKernelGGL((k_pass_mfma<N, 0, 256, 2>), dim3(1024), dim3(256), lds, s, blk, 0L, 0L, cbm, MT, M, sc, \
@@ -1208,6 +1210,54 @@ int launch_pass_fallback(int NC, bool accumulate, const double* blk, const doubl
 #undef X
         default: return 1;
     }
+}
+
+// ---- the first pass after a split, seeded (round 3) -----------------------------------------------------------------------
+// The children of codeword i are 2 i and 2 i + 1, and after the split 90-97 % of the frames of cell i land in one of
+// the two (tools/probe/family_moves.py).  So the level's first pass need not accumulate in full: the rows start as
+// "every frame in the even child of its old cell" (rows[2 i] = the parent's exact sums, rows[2 i + 1] = 0), a frame that
+// lands in 2 i adds nothing, a frame that lands in 2 i + 1 adds its limbs ONCE -- to row i of a side table X --, and only
+// a frame that leaves its family is moved with a subtraction and an addition.  k_family_fixup then moves X: rows[2 i + 1]
+// += X[i], rows[2 i] -= X[i].  Exact 64-bit integers throughout: the rows equal a full accumulation bit for bit, at
+// ~0.55-0.65 of its atomic traffic (1 add for ~46 % of the frames, 2 for the 3-10 % that leave, none for the rest).
+__global__ void k_seed_family(const i64* __restrict__ parent, i64* __restrict__ rows, i64* __restrict__ X, int Mold, int NC,
+                              int RS)
+{
+    const long n = (long)Mold * RS;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
+        const long i = o / RS;
+        const int e = (int)(o - i * RS);
+        const i64 v = e <= 2 * NC ? parent[o] : 0;  // limb pairs and count; the distortion columns start at zero
+        rows[(2 * i) * RS + e] = v;
+        rows[(2 * i + 1) * RS + e] = 0;
+        X[o] = 0;
+    }
+}
+
+__global__ void k_family_fixup(i64* __restrict__ rows, const i64* __restrict__ X, int Mold, int NC, int RS)
+{
+    const long n = (long)Mold * RS;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
+        const long i = o / RS;
+        const int e = (int)(o - i * RS);
+        if (e > 2 * NC) continue;
+        const i64 x = X[o];
+        if (x == 0) continue;
+        rows[(2 * i + 1) * RS + e] = (i64)((u64)rows[(2 * i + 1) * RS + e] + (u64)x);
+        rows[(2 * i) * RS + e] = (i64)((u64)rows[(2 * i) * RS + e] - (u64)x);
+    }
+}
+
+void launch_seed_family(const i64* parent, i64* rows, i64* X, int Mold, int NC, hipStream_t s)
+{
+    const int RS = row_stride(NC);
+    hipLaunchKernelGGL(k_seed_family, dim3(grid_for((long)Mold * RS, 256, 1024)), dim3(256), 0, s, parent, rows, X, Mold, NC, RS);
+}
+
+void launch_family_fixup(i64* rows, const i64* X, int Mold, int NC, hipStream_t s)
+{
+    const int RS = row_stride(NC);
+    hipLaunchKernelGGL(k_family_fixup, dim3(grid_for((long)Mold * RS, 256, 1024)), dim3(256), 0, s, rows, X, Mold, NC, RS);
 }
 
 // incremental accumulation: the distortion elements of every row are rebuilt each pass, the cell sums persist

@@ -165,6 +165,30 @@ struct e2vq_session {
     unsigned short* d_prev_sym = nullptr;
     i64* d_rows_local = nullptr;  // world > 1: the un-reduced rows (d_rows holds the all-reduced copy)
     int rows_local_cap = 0;
+    // the seeded first pass of a level (vq_device.hip: k_seed_family): the rank's own rows of the last pass at the previous
+    // size, stashed by e2vq_grow, and the side table of the in-family arrivals
+    bool fam_enabled = true, fam_pending = false;
+    int fam_M = 0, fam_cap = 0;
+    int fam_min_M = 512;  // smallest size whose first pass is seeded: at M = 256 the atomics of 2^21 frames crowd onto 384
+                          // rows and the plain first pass with its workgroup LDS table is faster (0.96 vs 1.08 ms)
+    int cells_M = 0;             // codebook size d_prev_sym's cells belong to (0: not valid)
+    bool rows_local_is_current = false;  // d_rows_local (not d_rows) holds this rank's rows of the last pass
+    bool rows_are_local = false; // the rows of the last pass are this rank's own sums (no collective, or d_rows_local)
+    i64* d_rows_parent = nullptr;
+    i64* d_fam = nullptr;
+    // e2vq_save_state / e2vq_restore_state: one saved point of the ladder (codebook, DDprv, rows, cells)
+    struct Saved {
+        bool valid = false;
+        int M = 0, cells_M = 0, incr_M = 0;
+        double DDprv = 0.0;
+        bool rows_fresh = false, rows_are_local = false, rows_local_is_current = false, incr_valid = false;
+        double* refl = nullptr;
+        i64* rows = nullptr;
+        i64* rows_local = nullptr;
+        unsigned short* cells = nullptr;
+        int cap_M = 0;
+        i64 cap_T = 0;
+    } sv;
     // collective hook
     e2vq_allreduce_fn allreduce = nullptr;
     void* ar_user = nullptr;
@@ -257,6 +281,8 @@ static int session_init(e2vq_session* s)
     if (const char* mm = getenv("ECOZ2_VQ_PREFILTER_MIN_M")) s->pre_min_M = std::max(64, atoi(mm));
     if (const char* inc = getenv("ECOZ2_VQ_INCREMENTAL")) s->incr_enabled = atoi(inc) != 0;
     if (const char* pf1 = getenv("ECOZ2_VQ_PLAIN_FIRST")) s->plain_first = atoi(pf1) != 0;
+    if (const char* fm = getenv("ECOZ2_VQ_FAMILY")) s->fam_enabled = atoi(fm) != 0;
+    if (const char* fm = getenv("ECOZ2_VQ_FAMILY_MIN_M")) s->fam_min_M = std::max(64, atoi(fm));
     if (s->pre_enabled) {
         HIPCHK(hipMalloc(&s->d_colmax, (size_t)s->NC * 8));
         HIPCHK(hipMalloc(&s->d_ea, (size_t)s->NC * sizeof(int)));
@@ -301,7 +327,7 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* ptrs[] = {s->d_aos, s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
+    void* ptrs[] = {s->sv.refl, s->sv.rows, s->sv.rows_local, s->sv.cells, s->d_rows_parent, s->d_fam, s->d_aos, s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
                     s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg2[0], s->d_cimg2[1], s->d_ps2[0], s->d_ps2[1], s->d_ps, s->d_fblist, s->d_prev_sym, s->d_rows_local,
                     s->d_ea_q, s->d_qfimg, s->d_qfg, s->d_qfblist, s->d_qcimg};
@@ -362,6 +388,8 @@ extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames
     s->rows_fresh = false;
     s->spec_valid = false;
     s->incr_valid = false;
+    s->fam_pending = false;
+    s->cells_M = 0;
     s->maxabs_scanned = false;
     s->T = 0;
     s->nblocks = 0;
@@ -481,9 +509,10 @@ extern "C" int e2vq_prepare(e2vq_session* s)
 // ---- codebook ----------------------------------------------------------------------------
 
 // (callers that redefine the codebook's size or contents from outside: set / init / grow)
-static int codebook_prepare(e2vq_session* s, bool redefined = true)
+static int codebook_prepare(e2vq_session* s, bool redefined = true, bool grown = false)
 {
     if (redefined) s->incr_valid = false;
+    if (!grown) s->fam_pending = false;  // (set / init: whatever e2vq_grow stashed belongs to another codebook)
     s->img_valid[0] = s->img_valid[1] = false;  // the codebook in d_cbq is a new one
     s->cb_version++;
     if (e2vq::has_cell_update(s->NC))
@@ -540,11 +569,33 @@ extern "C" int e2vq_grow(e2vq_session* s)
     if (s->M < 1) return e2vq_set_error("no codebook to grow");
     if (2 * s->M > 65536) return e2vq_set_error("codebook size limit (u16 symbols) reached");
     HIPCHK(hipSetDevice(s->device));
+    // The rows and cells of the last pass over the codebook about to be split seed the first pass of the next size
+    // (k_seed_family): they must be this rank's own sums, for the codebook as it stands, with every frame's cell recorded.
+    const bool seed = s->fam_enabled && s->pre_enabled && s->d_aos && s->d_prev_sym && s->rows_fresh && s->rows_are_local &&
+                      s->cells_M == s->M && 2 * s->M >= s->pre_min_M && 2 * s->M >= s->fam_min_M &&
+                      e2vq::prefilter_supports(s->NC, 2 * s->M) &&
+                      e2vq::prefilter_lds_stage(s->NC) && s->incr_enabled;
+    if (seed) {
+        if (s->fam_cap < s->M) {
+            for (i64** p : {&s->d_rows_parent, &s->d_fam}) {
+                if (*p) HIPCHK(hipFree(*p));
+                *p = nullptr;
+            }
+            s->fam_cap = std::max(s->M, 1024);
+            HIPCHK(hipMalloc(&s->d_rows_parent, (size_t)s->fam_cap * s->RS * 8));
+            HIPCHK(hipMalloc(&s->d_fam, (size_t)s->fam_cap * s->RS * 8));
+        }
+        const i64* src = (s->d_rows_local && s->rows_local_is_current) ? s->d_rows_local : s->d_rows;
+        HIPCHK(hipMemcpyAsync(s->d_rows_parent, src, (size_t)s->M * s->RS * 8, hipMemcpyDeviceToDevice, s->stream));
+        s->fam_M = s->M;
+    }
     if (ensure_codebook_capacity(s, 2 * s->M)) return 1;
     e2vq::launch_grow(s->d_refl, s->M, s->NC, s->d_refl_next, s->stream);
     std::swap(s->d_refl, s->d_refl_next);
     s->M *= 2;
-    return codebook_prepare(s);
+    if (codebook_prepare(s, true, /*grown=*/true)) return 1;
+    s->fam_pending = seed;
+    return 0;
 }
 
 // ---- LBG iteration pieces ------------------------------------------------------------------
@@ -621,10 +672,13 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         rows = s->d_rows_local;
     }
     const bool incremental = keep && s->incr_valid && s->incr_M == s->M;
+    // the first pass after a split, seeded with the parents' sums (e2vq_grow stashed them): k_seed_family
+    const bool family = s->fam_pending && keep && !incremental && s->d_aos && 2 * s->fam_M == s->M && mode != 0;
+    s->fam_pending = false;
     // The first pass of a level accumulates in full.  For the smallest prefiltered sizes that is cheaper on the plain
     // FP64 sweep with its workgroup-local LDS table (hybrid accumulate: 0.92 vs 1.5 ms at M = 256, where 2^21 frames
     // hammer 256 rows with global atomics); it records the cells for the incremental passes that follow.
-    const bool plain_first = s->plain_first && keep && !incremental && mode == 5 && s->M <= 384;
+    const bool plain_first = s->plain_first && keep && !incremental && !family && mode == 5 && s->M <= 384;
     if (s->last_prefiltered && !plain_first && ensure_codebook_image(s)) return 1;
     {
         // one prologue launch: the rows (all of them, or the distortion columns of an incremental pass), the fallback
@@ -642,9 +696,16 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             z.p[nz] = s->d_ps2[1 - s->img_cur];
             z.words[nz++] = (int)(e2vq::prefilter_scalars_bytes() / 4);
         }
-        e2vq::launch_pass_prologue(rows, s->M, s->NC, incremental ? 2 : (mode != 0 ? 1 : 0), z, s->stream);
+        // (the seeded first pass writes every word of the rows itself)
+        e2vq::launch_pass_prologue(rows, s->M, s->NC, family ? 0 : (incremental ? 2 : (mode != 0 ? 1 : 0)), z, s->stream);
         s->spec_zeroed = true;
+        if (family) e2vq::launch_seed_family(s->d_rows_parent, rows, s->d_fam, s->fam_M, s->NC, s->stream);
     }
+    // a plain pass records every frame's cell when the next size could be seeded from it (the level below the first
+    // prefiltered one)
+    const bool record_cells = !s->last_prefiltered && !plain_first && mode != 0 && s->fam_enabled && s->pre_enabled &&
+                              s->d_prev_sym && s->d_aos && !device_sym && 2 * s->M >= s->pre_min_M && 2 * s->M >= s->fam_min_M &&
+                              e2vq::prefilter_supports(s->NC, 2 * s->M);
     if (plain_first) {
         unsigned short* sym_out = device_sym ? (unsigned short*)device_sym : s->d_prev_sym;
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
@@ -676,8 +737,8 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, d_cimg, d_ps,
                                       s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                                       (double*)device_dmin, rows, s->d_fblist, keep ? s->d_prev_sym : nullptr,
-                                      incremental, /*hybrid_table=*/mode == 5 && !incremental, s->stream, nullptr, nullptr,
-                                      s->d_aos);
+                                      incremental, /*hybrid_table=*/mode == 5 && !incremental && !family, s->stream, nullptr,
+                                      nullptr, s->d_aos, family ? s->d_fam : nullptr);
         if (s->timing) {
             HIPCHK(hipEventRecord(s->ev1, s->stream));
             s->timed = true;
@@ -685,13 +746,14 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         }
         e2vq::launch_pass_fallback(s->NC, mode != 0, s->d_blk, s->d_cbm, s->M, s->d_sc, s->d_l1max,
                                    (unsigned short*)device_sym, (double*)device_dmin, rows, s->d_fblist,
-                                   e2vq::prefilter_fallback_count(d_ps), keep ? s->d_prev_sym : nullptr, incremental,
-                                   s->stream);
+                                   e2vq::prefilter_fallback_count(d_ps), keep ? s->d_prev_sym : nullptr,
+                                   family ? 2 : (incremental ? 1 : 0), s->stream);
+        if (family) e2vq::launch_family_fixup(rows, s->d_fam, s->fam_M, s->NC, s->stream);
     } else {
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
         s->n_plain_launches++;
         e2vq::launch_pass(s->NC, mode, s->d_blk, s->T, s->nblocks, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max,
-                          (unsigned short*)device_sym, (double*)device_dmin, rows, s->stream);
+                          record_cells ? s->d_prev_sym : (unsigned short*)device_sym, (double*)device_dmin, rows, s->stream);
         if (s->timing) {
             HIPCHK(hipEventRecord(s->ev1, s->stream));
             s->timed = true;
@@ -701,6 +763,10 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     if (mode != 0) {
         s->incr_valid = keep;
         s->incr_M = s->M;
+        // what a seeded first pass of the next size needs to know about this one
+        s->cells_M = (keep || record_cells) ? s->M : 0;
+        s->rows_local_is_current = rows != s->d_rows;
+        s->rows_are_local = rows != s->d_rows || !collective;
     }
     if (rows != s->d_rows)
         HIPCHK(hipMemcpyAsync(s->d_rows, rows, (size_t)s->M * s->RS * 8, hipMemcpyDeviceToDevice, s->stream));
@@ -1021,6 +1087,73 @@ extern "C" int e2vq_iterate(e2vq_session* s, void* device_sym, void* device_dmin
     if (e2vq_pass(s, device_sym, device_dmin)) return 1;
     if (e2vq_pass_stats(s, out)) return 1;
     return e2vq_update(s);
+}
+
+// One saved point of the ladder: the codebook, DDprv, and -- what the seeded first pass of the next size starts from --
+// the accumulator rows and every frame's cell of the last pass.  e2vq_restore_state puts the session back there (device
+// copies, microseconds), so that a caller can repeat a level exactly as the uninterrupted ladder runs it: bench.py times
+// the M = 1024 level this way.  Call e2vq_save_state right after the pass (and statistics) that ended a level.
+extern "C" int e2vq_save_state(e2vq_session* s)
+{
+    if (s->M < 1) return e2vq_set_error("no codebook to save");
+    HIPCHK(hipSetDevice(s->device));
+    auto& v = s->sv;
+    v.valid = false;
+    if (v.cap_M < s->M) {
+        for (void** p : {(void**)&v.refl, (void**)&v.rows, (void**)&v.rows_local}) {
+            if (*p) HIPCHK(hipFree(*p));
+            *p = nullptr;
+        }
+        v.cap_M = s->M;
+        HIPCHK(hipMalloc(&v.refl, (size_t)v.cap_M * s->NC * 8));
+        HIPCHK(hipMalloc(&v.rows, (size_t)v.cap_M * s->RS * 8));
+        HIPCHK(hipMalloc(&v.rows_local, (size_t)v.cap_M * s->RS * 8));
+    }
+    if (s->d_prev_sym && v.cap_T < s->nblocks * 64) {
+        if (v.cells) HIPCHK(hipFree(v.cells));
+        v.cells = nullptr;
+        v.cap_T = s->nblocks * 64;
+        HIPCHK(hipMalloc(&v.cells, (size_t)v.cap_T * 2 + 256));
+    }
+    HIPCHK(hipMemcpyAsync(v.refl, s->d_refl, (size_t)s->M * s->NC * 8, hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(v.rows, s->d_rows, (size_t)s->M * s->RS * 8, hipMemcpyDeviceToDevice, s->stream));
+    if (s->d_rows_local && s->rows_local_cap >= s->M)
+        HIPCHK(hipMemcpyAsync(v.rows_local, s->d_rows_local, (size_t)s->M * s->RS * 8, hipMemcpyDeviceToDevice, s->stream));
+    if (s->d_prev_sym) HIPCHK(hipMemcpyAsync(v.cells, s->d_prev_sym, (size_t)s->nblocks * 64 * 2, hipMemcpyDeviceToDevice, s->stream));
+    v.M = s->M;
+    v.cells_M = s->cells_M;
+    v.incr_M = s->incr_M;
+    v.DDprv = s->DDprv;
+    v.rows_fresh = s->rows_fresh;
+    v.rows_are_local = s->rows_are_local;
+    v.rows_local_is_current = s->rows_local_is_current;
+    v.incr_valid = s->incr_valid;
+    v.valid = true;
+    return 0;
+}
+
+extern "C" int e2vq_restore_state(e2vq_session* s)
+{
+    auto& v = s->sv;
+    if (!v.valid) return e2vq_set_error("no saved state");
+    HIPCHK(hipSetDevice(s->device));
+    if (ensure_codebook_capacity(s, v.M)) return 1;
+    HIPCHK(hipMemcpyAsync(s->d_refl, v.refl, (size_t)v.M * s->NC * 8, hipMemcpyDeviceToDevice, s->stream));
+    s->M = v.M;
+    if (codebook_prepare(s)) return 1;  // (codeword images of the restored codebook; drops every derived flag)
+    HIPCHK(hipMemcpyAsync(s->d_rows, v.rows, (size_t)v.M * s->RS * 8, hipMemcpyDeviceToDevice, s->stream));
+    if (s->d_rows_local && s->rows_local_cap >= v.M)
+        HIPCHK(hipMemcpyAsync(s->d_rows_local, v.rows_local, (size_t)v.M * s->RS * 8, hipMemcpyDeviceToDevice, s->stream));
+    if (s->d_prev_sym && v.cells)
+        HIPCHK(hipMemcpyAsync(s->d_prev_sym, v.cells, (size_t)s->nblocks * 64 * 2, hipMemcpyDeviceToDevice, s->stream));
+    s->DDprv = v.DDprv;
+    s->cells_M = v.cells_M;
+    s->incr_M = v.incr_M;
+    s->incr_valid = v.incr_valid;
+    s->rows_fresh = v.rows_fresh;
+    s->rows_are_local = v.rows_are_local;
+    s->rows_local_is_current = v.rows_local_is_current;
+    return 0;
 }
 
 // DDprv of the convergence rule (notes.md:128-153: it carries over between codebook sizes).  A caller that restores

@@ -1113,8 +1113,13 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
                                                          const u64* __restrict__ l1max_bits,
                                                          unsigned short* __restrict__ sym, double* __restrict__ dmin,
                                                          i64* __restrict__ rows, int* __restrict__ fb_list, int stagger,
-                                                         unsigned short* __restrict__ prev_sym, int incr)
+                                                         unsigned short* __restrict__ prev_sym, int incr,
+                                                         i64* __restrict__ fam)
 {
+    // incr: 0 = full accumulation; 1 = incremental (rows and cells of the previous pass persist: only frames that changed
+    // cell are moved); 2 = the seeded first pass of a level (vq_device.hip, k_seed_family): a frame's old cell is the even
+    // child 2 * prev_sym of the cell it had at the previous size; one that lands in the odd child 2 * prev_sym + 1 adds its
+    // limbs to row prev_sym of the side table `fam` and nothing else
     typedef PrePack<NC> PK;
     typedef PreLds<NC> PL;
     constexpr int TPBM = 512;
@@ -1253,7 +1258,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         const bool cert = t1 >= 1.0e-30f && t1 < 1.0e37f && w3 > t1 + tau;
         const bool amb = !(u2 > t1 + tau);  // the runner-up is within reach: it needs the exact evaluation too
         const int c1 = __float_as_int(t1) & ~idxmask, c2 = __float_as_int(u2) & ~idxmask;
-        const int old = incr ? (int)prevs[ln] : 0;
+        const int old = incr ? (incr == 2 ? 2 : 1) * (int)prevs[ln] : 0;
         E2VQ_STAMP(2)  // merge, certification
 
         // ---- exact evaluation of both candidates: the canonical chain, one frame per ln ---------------------------
@@ -1425,13 +1430,21 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
                 for (int k = 0; k < 4; ++k) {
                     if (!on[k]) continue;  // wave-uniform
                     if (TAIL || ln < NE) {
-                        atomicAdd((u64*)&rows[(long)cell[k] * RS + ln], (u64)(i64)v[k]);
-                        if (incr) atomicAdd((u64*)&rows[(long)oldc[k] * RS + ln], (u64)(-(i64)v[k]));
+                        if (incr == 2 && cell[k] == oldc[k] + 1) {  // (wave-uniform) in-family odd child: one add, to the side table
+                            atomicAdd((u64*)&fam[(long)(oldc[k] >> 1) * RS + ln], (u64)(i64)v[k]);
+                        } else {
+                            atomicAdd((u64*)&rows[(long)cell[k] * RS + ln], (u64)(i64)v[k]);
+                            if (incr) atomicAdd((u64*)&rows[(long)oldc[k] * RS + ln], (u64)(-(i64)v[k]));
+                        }
                     }
                 }
                 if (TAIL && ton) {
-                    atomicAdd((u64*)&rows[(long)tcell * RS + 64 + te], (u64)(i64)tv);
-                    if (incr) atomicAdd((u64*)&rows[(long)told * RS + 64 + te], (u64)(-(i64)tv));
+                    if (incr == 2 && tcell == told + 1) {  // (per 16-lane group)
+                        atomicAdd((u64*)&fam[(long)(told >> 1) * RS + 64 + te], (u64)(i64)tv);
+                    } else {
+                        atomicAdd((u64*)&rows[(long)tcell * RS + 64 + te], (u64)(i64)tv);
+                        if (incr) atomicAdd((u64*)&rows[(long)told * RS + 64 + te], (u64)(-(i64)tv));
+                    }
                 }
             }
         }
@@ -1612,7 +1625,7 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                                      const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym,
                                      double* dmin, long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental,
                                      bool hybrid_table, hipStream_t s, const double* aos, const int* ea_fused,
-                                     const double* aos_resident)
+                                     const double* aos_resident, long long* family_table)
 {
     constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
     constexpr int TPBM = 512;  // 8 waves = 2 per SIMD, one persistent workgroup per CU
@@ -1637,7 +1650,7 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
             hipLaunchKernelGGL((k_pass_pre_lds<NC>), dim3(grid), dim3(TPBM), (size_t)8 * PreLds<NC>::WAVE_BYTES, s,
                                aos_resident, T, nblocks, (const h8*)fimg, fg, (const h8*)cimg, (PreScalars*)ps, cbq, M / 32,
                                idxmask, sc, (const u64*)l1max_bits, sym, dmin, rows, fb_list, stagger, prev_sym,
-                               incremental ? 1 : 0);
+                               family_table ? 2 : (incremental ? 1 : 0), (i64*)family_table);
         }
     } else if (accumulate) {
         (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 2, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1677,8 +1690,10 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                             const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                             long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
-                            hipStream_t s, const double* rowmajor_frames, const int* ea_fused, const double* resident_rowmajor)
+                            hipStream_t s, const double* rowmajor_frames, const int* ea_fused, const double* resident_rowmajor,
+                            long long* family_table)
 {
+    if (family_table && (!accumulate || hybrid_table || incremental || !resident_rowmajor || !prefilter_lds_stage(NC))) return 1;
     if (!prefilter_supports(NC, M) || (hybrid_table && incremental)) return 1;
     if (ea_fused && (accumulate || !rowmajor_frames || !prefilter_fused_quantize(NC))) return 1;
     switch (NC) {
@@ -1686,7 +1701,7 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
     case N:                                                                                                           \
         return launch_pass_prefiltered_t<N>(accumulate, blk, T, nblocks, fimg, fg, cimg, ps, cbq, M, sc, l1max_bits, sym, \
                                             dmin, rows, fb_list, prev_sym, incremental, hybrid_table, s, rowmajor_frames, \
-                                            ea_fused, resident_rowmajor);
+                                            ea_fused, resident_rowmajor, family_table);
         E2VQ_PRE_NC_LIST(X)
 #undef X
         default: return 1;

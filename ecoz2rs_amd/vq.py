@@ -224,6 +224,13 @@ class VqSession:
         """DDprv of the stopping rule (carries over between codebook sizes); see e2vq_set_prev_distortion."""
         check(lib.e2vq_set_prev_distortion(self._h, float(dd)))
 
+    def save_state(self):
+        """Save this point of the ladder (codebook, DDprv, rows and cells of the last pass): see e2vq_save_state."""
+        check(lib.e2vq_save_state(self._h))
+
+    def restore_state(self):
+        check(lib.e2vq_restore_state(self._h))
+
     def prev_distortion(self):
         dd = C.c_double()
         check(lib.e2vq_get_prev_distortion(self._h, C.byref(dd)))

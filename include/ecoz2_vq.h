@@ -99,6 +99,8 @@ int ecoz2_prd_show_file(const char *prd_filename, int show_reflections, int from
  *   ECOZ2_VQ_QUANTIZE_CHUNK     frames per quantize unit (default 2^17): short files are batched into one sweep, longer
  *                               files are split over the workers
  *   ECOZ2_VQ_VERIFY_PUBLISH     1 = check every published pass statistic against a host recomputation (diagnostics)
+ *   ECOZ2_VQ_FAMILY             0 = the first pass of every level accumulates in full (default 1: from M = 512
+ *                               -- ECOZ2_VQ_FAMILY_MIN_M -- it is seeded with the parents' sums; same rows bit for bit)
  *   ECOZ2_VQ_PRE_LDS            0 = accumulating prefiltered passes on the round-2 kernel (A/B; same results)
  *   ECOZ2_VQ_TIMING             wall time of the stages of ecoz2_vq_learn on stderr (diagnostics)
  *   ECOZ2_VQ_OUT_ROOT           prefix for data/... outputs (default ".")               */
@@ -190,6 +192,12 @@ int e2vq_learn(e2vq_session *s, double epsilon, int max_M, const char *class_nam
  * After restoring an earlier codebook with e2vq_set_codebook, restore its level's DD here and e2vq_learn repeats the
  * next level exactly as the uninterrupted ladder ran it. */
 int e2vq_set_prev_distortion(e2vq_session *s, double DDprv);
+/* One saved point of the ladder (device copies): codebook, DDprv, and the accumulator rows and cells of the last pass --
+ * what the seeded first pass of the next codebook size starts from.  Save right after the pass + statistics that ended
+ * a level; restoring puts the session back there, so that e2vq_learn repeats the next level exactly as the
+ * uninterrupted ladder runs it (seeded first pass included).  bench.py times the M = 1024 level this way. */
+int e2vq_save_state(e2vq_session *s);
+int e2vq_restore_state(e2vq_session *s);
 int e2vq_get_prev_distortion(e2vq_session *s, double *DDprv);
 
 /* nearest-codeword assignment of arbitrary frames against the session's codebook.  Frames must be finite

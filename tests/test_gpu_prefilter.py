@@ -214,6 +214,74 @@ def test_incremental_rows_match_a_full_accumulation_every_pass(oracle, monkeypat
     assert bool(calls) == collective
 
 
+@pytest.mark.parametrize("collective", [False, True])
+@pytest.mark.parametrize("min_m", [64, 256])
+def test_seeded_first_pass_after_a_split_equals_a_full_accumulation(oracle, monkeypatch, min_m, collective):
+    """The first pass of a level is seeded with the parents' exact sums (rows[2 i] = parent i, frames landing in 2 i + 1
+    add once to a side table, only frames leaving their family are moved; k_seed_family / k_family_fixup): rows after that
+    pass -- and after the incremental passes that build on it -- must equal the oracle's full accumulation bit for bit.
+    Levels 32 -> 64 (parent on the plain sweep, which records the cells) up to 512, through grow / pass / update; with
+    `collective` the parent rows come from the rank's own copy."""
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", str(min_m))
+    monkeypatch.setenv("ECOZ2_VQ_FAMILY_MIN_M", str(min_m))  # (default 512: below, the plain first pass is faster)
+    monkeypatch.setenv("ECOZ2_VQ_QUIET", "1")
+    if collective:
+        monkeypatch.setenv("ECOZ2_VQ_FORCE_ALLREDUCE", "1")
+    frames = _frames(20301, 20011, classes=7)
+    rc, st = oracle.data_stats(frames)
+    sh_r, _ = oracle.shifts(st.maxabs)
+    calls = []
+    with e.VqSession(P) as s:
+        if collective:
+            s.set_allreduce(lambda buf, count, op, stream: calls.append(count) or 0, 0, 1)
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        s.learn(0.05, 32)
+        refl = s.get_codebook()
+        seeded = 0
+        for M in (64, 128, 256, 512):
+            s.grow()
+            refl = oracle.grow(refl) if hasattr(oracle, "grow") else s.get_codebook()
+            assert np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64))
+            for it in range(3):
+                cq = oracle.reflections_to_cq(refl)
+                _sym, _dmin, rows_o = oracle.run_pass(cq, frames, sh_r, oracle.dist_exponent(cq, st.maxabs))
+                s.run_pass()
+                assert oracle_lib.rows_match(s.get_rows(), rows_o, P), f"M={M} pass {it}"
+                if it < 2:
+                    refl, _failed = oracle.update(rows_o, P, sh_r, refl)
+                    s.update()
+                    assert np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64))
+                else:
+                    s.pass_stats()  # (the level ends on a pass without an update, as in e2vq_learn)
+            seeded += M >= min_m
+    assert seeded >= 2 and bool(calls) == collective
+
+
+def test_save_and_restore_state_repeat_a_level(oracle, monkeypatch):
+    """e2vq_save_state / e2vq_restore_state: the point where a level ended (codebook, DDprv, rows, cells) comes back,
+    and the next level -- seeded first pass included -- repeats bit for bit, as often as asked (bench.py's timed region)."""
+    monkeypatch.setenv("ECOZ2_VQ_QUIET", "1")
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
+    frames = _frames(20311, 15000, classes=5)
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        s.learn(0.05, 128)
+        s.save_state()
+        first = s.learn(0.05, 256)[0]
+        cb = s.get_codebook()
+        for _ in range(3):
+            s.restore_state()
+            again = s.learn(0.05, 256)[0]
+            assert (again.passes, again.DD, again.sigma, again.inertia) == (first.passes, first.DD, first.sigma, first.inertia)
+            assert np.array_equal(s.get_codebook().view(np.uint64), cb.view(np.uint64))
+    rc, levels_o, _ = oracle.learn(frames, 0.05, 256)
+    assert np.array_equal(cb.view(np.uint64), levels_o[-1]["reflections"].view(np.uint64))
+
+
 def test_incremental_switch_gives_the_same_ladder(oracle, monkeypatch):
     """ECOZ2_VQ_INCREMENTAL=0 (full accumulation every pass) and the default produce identical ladders."""
     frames = _frames(20262, 12000, classes=5)
