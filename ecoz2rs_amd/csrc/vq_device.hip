@@ -35,6 +35,23 @@ typedef const double __attribute__((address_space(4))) cdouble_k;
 
 namespace e2vq {
 
+// diagnostics (-DE2VQ_MFMA_STAMP, tools/probe/mfma_stamps.py): cycles of a k_pass_mfma wave by phase; never in the product
+#ifdef E2VQ_MFMA_STAMP
+__device__ unsigned long long g_mfma_stamps[16];
+#define E2VQ_MSTAMP_DECL unsigned long long ms_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ms_t = 0, ms_n = 0;
+#define E2VQ_MSTAMP_START ms_t = __builtin_amdgcn_s_memtime();
+#define E2VQ_MSTAMP(i)                                                   \
+    {                                                                    \
+        const unsigned long long ms_now = __builtin_amdgcn_s_memtime();  \
+        ms_acc[i] += ms_now - ms_t;                                      \
+        ms_t = ms_now;                                                   \
+    }
+#else
+#define E2VQ_MSTAMP_DECL
+#define E2VQ_MSTAMP_START
+#define E2VQ_MSTAMP(i)
+#endif
+
 __device__ __forceinline__ i64 wave_sum_i64(i64 v)
 {
 #pragma unroll
@@ -278,7 +295,9 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
     if constexpr (PREFETCH) {
         if (wave < nblocks) load_block_frames<NC>(blk, wave, lane, Bn);
     }
+    E2VQ_MSTAMP_DECL
     for (long b = wave; b < nblocks; b += nwaves) {
+        E2VQ_MSTAMP_START
         // ---- frames -> B operands (resident for the whole sweep) ---------------------------
         double Bf[4][2 * NP];
         const double* fb = blk + b * (long)(NC * 64);
@@ -336,6 +355,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             load_block_frames<NC>(blk, b, lane, Bf);
         }
 
+        E2VQ_MSTAMP(0)  // frames into registers (prefetched: a copy; else the load is issued here and waited for in the sweep)
         // ---- sweep: 16 codewords x 16 frames per MFMA, k ascending = canonical chain -------
         double best[4];
         int code[4];
@@ -403,6 +423,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             if (ct < ct1) do_tile(ct, A0, T0);
         }
 
+        E2VQ_MSTAMP(1)  // sweep
         // ---- combine the four lanes (q = 0..3) that hold one frame: min value, lowest index ---
         int idx[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -455,6 +476,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             }
         }
 
+        E2VQ_MSTAMP(2)  // combine, prefetch request, outputs
         // ---- accumulate: int32 row images [frame][2n+limb | count, d, d2] -> exact 64-bit adds ----
         if constexpr (MODE == 2 && SRC == 2) {
             // fallback of a prefiltered pass: incremental like the pass it completes (vq_accum.h)
@@ -469,15 +491,28 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
         } else if constexpr (MODE != 0)
             accumulate_block<NC, MODE, false, NFT>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2, b, T, lane,
                                                    {false, false, false, false});
+        E2VQ_MSTAMP(3)  // accumulate
+#ifdef E2VQ_MFMA_STAMP
+        ms_n += 1;
+#endif
     }
 
     if constexpr (MODE == 1 || MODE == 5) {
+        E2VQ_MSTAMP_START
         __syncthreads();
         for (int i = threadIdx.x; i < lds_cells * RS; i += TPBM) {
             const i64 v = lacc[i];
             if (v != 0) atomicAdd((u64*)&rows[i], (u64)v);
         }
+        E2VQ_MSTAMP(4)  // wait for the workgroup, flush the table
     }
+#ifdef E2VQ_MFMA_STAMP
+    if (lane == 0 && MODE != 0 && SRC == 0) {
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_mfma_stamps[k], ms_acc[k]);
+        atomicAdd(&g_mfma_stamps[8], ms_n);
+        atomicAdd(&g_mfma_stamps[9], 1ull);
+    }
+#endif
 }
 
 
@@ -1411,3 +1446,15 @@ void launch_codebook_prepare(const double* reflections, int M, int NC, double* c
 }
 
 }  // namespace e2vq
+
+#ifdef E2VQ_MFMA_STAMP
+extern "C" int e2vq_debug_mfma_stamps(unsigned long long* out16, int reset)
+{
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(e2vq::g_mfma_stamps), 16 * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(e2vq::g_mfma_stamps), z, 16 * 8) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
