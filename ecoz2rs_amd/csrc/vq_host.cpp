@@ -1886,13 +1886,6 @@ extern "C" int ecoz2_vq_learn_using_base_codebook(const char* base_codebook, dou
 // ---- vq quantize / vq classify: predictor files through the GPU with I/O, copies and sweeps overlapped ------------
 namespace {
 
-bool all_finite(const double* v, size_t n)
-{
-    for (size_t i = 0; i < n; ++i)
-        if (!(fabs(v[i]) <= DBL_MAX)) return false;
-    return true;
-}
-
 // ---- ecoz2_vq_quantize: units of at most CHUNK frames through fixed-size pinned staging ------------------------------
 // A unit is a run of consecutive frames of the corpus (file order, frame order) made of segments (file, first frame,
 // count): many short files are batched into one unit -- one upload, ONE sweep, one download for all of them (frames are
@@ -2185,62 +2178,102 @@ extern "C" int ecoz2_vq_classify(const char* const* cb_filenames, int num_codebo
         if (cbs[i].P != cbs[0].P) return e2vq_set_error("%s: prediction order differs from the first codebook", cb_filenames[i]);
     }
     const int P = cbs[0].P, NC = P + 1;
-    // all predictor files into ONE host array: uploaded once, swept once per codebook where it lies
+    // Predictor files stream through fixed-size pinned staging in units of at most ECOZ2_VQ_QUANTIZE_CHUNK frames (short
+    // files batched, long ones cut: as ecoz2_vq_quantize); every unit is uploaded ONCE and swept once per codebook where it
+    // lies.  Host and device memory stay bounded whatever the corpus (round 2 held every frame in one std::vector and one
+    // device allocation, copied with a pageable hipMemcpy).
     struct Prd {
         std::string cls;
-        int64_t T;
-        i64 off;
+        int64_t T = 0;
     };
     std::vector<Prd> prds((size_t)num_predictors);
-    std::vector<double> frames;
-    i64 total = 0;
-    for (int k = 0; k < num_predictors; ++k) {
-        char cls[96];
-        int p;
-        if (e2vq_prd_info(prd_filenames[k], cls, &p, &prds[k].T)) return 1;
-        if (p != P) return e2vq_set_error("%s: prediction order %d differs from the codebooks' %d", prd_filenames[k], p, P);
-        prds[k].cls = cls;
-        prds[k].off = total;
-        frames.resize((size_t)(total + prds[k].T) * NC);
-        if (prds[k].T > 0 && e2vq_prd_read(prd_filenames[k], frames.data() + (size_t)total * NC, prds[k].T)) return 1;
-        total += prds[k].T;
+    const i64 chunk = std::max(1024, env_int("ECOZ2_VQ_QUANTIZE_CHUNK", 1 << 17));
+    std::vector<QUnit> units;
+    {
+        QUnit cur;
+        auto flush = [&] {
+            if (!cur.segs.empty()) units.push_back(std::move(cur));
+            cur = QUnit();
+        };
+        for (int k = 0; k < num_predictors; ++k) {
+            char cls[96];
+            int p;
+            if (e2vq_prd_info(prd_filenames[k], cls, &p, &prds[k].T)) return 1;
+            if (p != P) return e2vq_set_error("%s: prediction order %d differs from the codebooks' %d", prd_filenames[k], p, P);
+            prds[k].cls = cls;
+            const i64 T = prds[k].T;
+            if (T <= chunk) {
+                if (cur.n + T > chunk) flush();
+                cur.segs.push_back(QSegment{k, 0, T, cur.n, true});
+                cur.n += T;
+            } else {
+                flush();
+                for (i64 t0 = 0; t0 < T; t0 += chunk) {
+                    const i64 n = std::min<i64>(chunk, T - t0);
+                    cur.segs.push_back(QSegment{k, t0, n, 0, false});
+                    cur.n = n;
+                    flush();
+                }
+            }
+        }
+        flush();
     }
-    if (!all_finite(frames.data(), frames.size())) return e2vq_set_error("predictor files contain NaN or infinite values");
     e2vq_session* s = nullptr;
-    if (e2vq_session_create(env_int("ECOZ2_VQ_DEVICE", 0), P, &s)) return 1;
-    std::vector<double> score((size_t)num_predictors * num_codebooks, 0.0);
+    const int device = env_int("ECOZ2_VQ_DEVICE", 0);
+    if (e2vq_session_create(device, P, &s)) return 1;
+    // sums of (dmin - 1) per (file, codebook), in frame order (units are processed in order, frames within a unit too)
+    std::vector<double> esum((size_t)num_predictors * num_codebooks, 0.0);
     int rc = 0;
-    double* d_frames = nullptr;
+    hipStream_t st = nullptr;
+    double *h_frames = nullptr, *h_dmin = nullptr, *d_frames = nullptr, *d_dmin = nullptr;
     unsigned short* d_sym = nullptr;
-    double* d_dmin = nullptr;
-    std::vector<double> dmin((size_t)total);
-    if (total > 0) {
-        if (hipMalloc(&d_frames, (size_t)total * NC * 8) != hipSuccess || hipMalloc(&d_sym, (size_t)total * 2 + 64) != hipSuccess ||
-            hipMalloc(&d_dmin, (size_t)total * 8) != hipSuccess)
-            rc = e2vq_set_error("no device memory for %lld predictor vectors", (long long)total);
-        if (!rc && hipMemcpy(d_frames, frames.data(), (size_t)total * NC * 8, hipMemcpyHostToDevice) != hipSuccess)
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = e2vq_set_error("stream creation failed");
+    if (!rc) rc = e2vq_set_stream(s, (void*)st);
+    if (!rc && (hipHostMalloc((void**)&h_frames, (size_t)chunk * NC * 8, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void**)&h_dmin, (size_t)chunk * 8, hipHostMallocDefault) != hipSuccess ||
+                hipMalloc((void**)&d_frames, (size_t)chunk * NC * 8) != hipSuccess || hipMalloc((void**)&d_dmin, (size_t)chunk * 8) != hipSuccess ||
+                hipMalloc((void**)&d_sym, (size_t)chunk * 2 + 64) != hipSuccess))
+        rc = e2vq_set_error("no memory for the classify staging (%lld frames per unit)", (long long)chunk);
+    for (size_t u = 0; u < units.size() && !rc; ++u) {
+        const QUnit& un = units[u];
+        if (un.n < 1) continue;
+        for (const QSegment& g : un.segs) {
+            if (g.n < 1) continue;
+            bool fin = true;
+            rc = e2vq_io::prd_read_range_mt(prd_filenames[g.file], P, g.t0, g.n, h_frames + (size_t)g.off * NC, e2vq_io::io_threads(), &fin);
+            if (!rc && !fin) rc = e2vq_set_error("%s: contains NaN or infinite values", prd_filenames[g.file]);
+            if (rc) break;
+        }
+        if (rc) break;
+        if (hipMemcpyAsync(d_frames, h_frames, (size_t)un.n * NC * 8, hipMemcpyHostToDevice, st) != hipSuccess)
             rc = e2vq_set_error("upload of the predictor vectors failed");
-    }
-    for (int i = 0; i < num_codebooks && !rc && total > 0; ++i) {  // codebook-major: one codebook upload per class
-        rc = e2vq_set_codebook(s, cbs[i].refl.data(), cbs[i].M);
-        const i64 CH = 1 << 24;
-        for (i64 t0 = 0; t0 < total && !rc; t0 += CH)
-            rc = e2vq_quantize_device(s, d_frames + (size_t)t0 * NC, std::min(CH, total - t0), d_sym + t0, d_dmin + t0);
-        if (!rc) rc = e2vq_synchronize(s);
-        if (!rc && hipMemcpy(dmin.data(), d_dmin, (size_t)total * 8, hipMemcpyDeviceToHost) != hipSuccess)
-            rc = e2vq_set_error("download of the distortions failed");
-        for (int k = 0; k < num_predictors && !rc; ++k) {
-            if (prds[k].T < 1) continue;
-            double e = 0.0;  // average distortion: sum of (dmin - 1) in frame order, then / T (as e2vq_avg_distortion_host)
-            for (int64_t t = 0; t < prds[k].T; ++t) e += dmin[(size_t)(prds[k].off + t)] - 1.0;
-            score[(size_t)k * num_codebooks + i] = e / (double)prds[k].T;
+        for (int i = 0; i < num_codebooks && !rc; ++i) {
+            rc = e2vq_set_codebook(s, cbs[i].refl.data(), cbs[i].M);
+            if (!rc) rc = e2vq_quantize_device(s, d_frames, un.n, d_sym, d_dmin);
+            if (!rc && hipMemcpyAsync(h_dmin, d_dmin, (size_t)un.n * 8, hipMemcpyDeviceToHost, st) != hipSuccess)
+                rc = e2vq_set_error("download of the distortions failed");
+            if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = e2vq_set_error("classify: device work failed");
+            if (rc) break;
+            for (const QSegment& g : un.segs) {
+                double e = esum[(size_t)g.file * num_codebooks + i];
+                for (i64 t = 0; t < g.n; ++t) e += h_dmin[g.off + t] - 1.0;
+                esum[(size_t)g.file * num_codebooks + i] = e;
+            }
         }
     }
+    if (st) (void)hipStreamSynchronize(st);
+    if (h_frames) (void)hipHostFree(h_frames);
+    if (h_dmin) (void)hipHostFree(h_dmin);
     if (d_frames) (void)hipFree(d_frames);
-    if (d_sym) (void)hipFree(d_sym);
     if (d_dmin) (void)hipFree(d_dmin);
+    if (d_sym) (void)hipFree(d_sym);
     e2vq_session_destroy(s);
+    if (st) (void)hipStreamDestroy(st);
     if (rc) return rc;
+    std::vector<double> score((size_t)num_predictors * num_codebooks, 0.0);
+    for (int k = 0; k < num_predictors; ++k)
+        for (int i = 0; i < num_codebooks; ++i)
+            if (prds[k].T > 0) score[(size_t)k * num_codebooks + i] = esum[(size_t)k * num_codebooks + i] / (double)prds[k].T;
     int correct = 0, total_n = 0;
     std::vector<std::string> classes;
     std::vector<int> ok_by, n_by;

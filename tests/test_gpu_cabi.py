@@ -435,6 +435,13 @@ def test_vq_classify(tmp_path, oracle, capfd):
     e.vq_classify(cb_files, prd_files + [str(bad)], show_ranked=True)
     out = capfd.readouterr().out
     assert "classified as 'C3'; ranked: C3(" in out and "90.00%" in out.split("TOTAL")[1]
+    # the same through 1 024-frame units (files batched and split: the streaming path), same report
+    os.environ["ECOZ2_VQ_QUANTIZE_CHUNK"] = "1024"
+    try:
+        e.vq_classify(cb_files, prd_files + [str(bad)], show_ranked=True)
+    finally:
+        del os.environ["ECOZ2_VQ_QUANTIZE_CHUNK"]
+    assert capfd.readouterr().out == out
 
 
 def test_large_prediction_order_generic_path(oracle):
