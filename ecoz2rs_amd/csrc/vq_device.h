@@ -21,6 +21,8 @@ inline int cb_pad(int NC) { return (NC + 7) & ~7; }
 
 bool uses_mfma(int NC);            // P = 4 .. 40: the sweep runs on the FP64 matrix pipe
 int mfma_hybrid_cells(int NC);     // cells of the hybrid accumulate's LDS table
+// generic orders (P > 40): scratch for the transposed codebook of k_pass_generic_lds, passed to launch_pass in the cbm slot
+inline long generic_scratch_doubles(int NC, int M) { return (long)NC * ((M + 7) / 8 * 8); }
 inline long cbm_doubles(int NC, int M) { return (long)((M + 15) / 16) * (((((NC + 3) / 4) + 1) / 2) * 128 + 16); }
 
 bool launch_blockify(const double* aos, long T, int NC, int FB, double* blk, long nblocks,

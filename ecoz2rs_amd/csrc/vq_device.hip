@@ -635,6 +635,120 @@ __global__ __launch_bounds__(TPB) void k_pass_generic(const double* __restrict__
     }
 }
 
+// Prediction orders beyond the MFMA instantiations (P > 40; the reference allows up to 200), round 3: the frames of a
+// block are staged ONCE in the wave's LDS ([n][64]: lane = frame, conflict-free 8-byte rows) and the codewords come
+// eight at a time from a transposed copy cbT[n][m] (8 consecutive doubles = one scalar load per coefficient), so a
+// coefficient costs one LDS read for eight FMAs -- k_pass_generic re-read every frame coefficient from global memory
+// per codeword (1 load per FMA: ~2 TFLOP/s).  Same chain: acc = +0.0, fma(r[n], c[n], acc) for ascending n; ascending
+// codeword index with strict < (padding codewords repeat codeword 0 and can never win).  One wave per workgroup; LDS =
+// 520 (P + 1) bytes, so P = 200 still fits (one workgroup per CU).
+constexpr int GEN_G = 8;    // codewords per group
+constexpr int GEN_LD = 65;  // leading dimension (doubles) of the staged block
+
+__global__ void k_transpose_codebook(const double* __restrict__ cbq, int M, int NC, int NPAD, double* __restrict__ cbT, int Mpad)
+{
+    const long total = (long)NC * Mpad;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(o / Mpad), m = (int)(o - (long)n * Mpad);
+        cbT[o] = cbq[(long)(m < M ? m : 0) * NPAD + n];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_pass_generic_lds(const double* __restrict__ blk, long T, long nblocks, int NC,
+                                                          const double* __restrict__ cbT, int M, int Mpad,
+                                                          const DevScalars* __restrict__ sc, const u64* __restrict__ l1max_bits,
+                                                          unsigned short* __restrict__ sym, double* __restrict__ dmin,
+                                                          i64* __restrict__ rows)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [n][GEN_LD]: lane = frame.  The odd leading dimension (65 doubles) lets the accumulate read ONE frame's limbs across
+    // the lanes (element e = 2 n + limb at dword (n * 65 + f) * 2 + limb: banks 2 n + 2 f + limb, distinct for 32 n)
+    constexpr int LD = GEN_LD;
+    double* fr = (double*)smem;
+    const int* fri = (const int*)smem;
+    const int RS = (2 * NC + 5 + 7) & ~7;
+    const int lane = threadIdx.x;
+    int sh_r = 0, sh_d = 0, sh_d2 = 0;
+    if (MODE != 0) {
+        sh_r = sc->sh_r;
+        const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
+        sh_d = 30 - Ed;
+        sh_d2 = 30 - 2 * Ed;
+    }
+    for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const double* fb = blk + b * (long)(NC * 64);
+        for (int n = 0; n < NC; ++n) fr[n * LD + lane] = fb[n * 64 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double best = __builtin_inf();
+        int bi = 0;
+        for (int m0 = 0; m0 < Mpad; m0 += GEN_G) {
+            double acc[GEN_G];
+#pragma unroll
+            for (int g = 0; g < GEN_G; ++g) acc[g] = 0.0;
+            const double* c = cbT + m0;  // wave-uniform: scalar loads
+#pragma unroll 4  // (four coefficients' loads in flight: one wave per SIMD has nobody else to hide their latency)
+            for (int n = 0; n < NC; ++n) {
+                const double r = fr[n * LD + lane];
+#pragma unroll
+                for (int g = 0; g < GEN_G; ++g) acc[g] = __builtin_fma(r, c[(long)n * Mpad + g], acc[g]);
+            }
+#pragma unroll
+            for (int g = 0; g < GEN_G; ++g) {
+                const bool lt = acc[g] < best;
+                best = lt ? acc[g] : best;
+                bi = lt ? m0 + g : bi;
+            }
+        }
+        const long t = b * 64 + lane;
+        const bool live = t < T;
+        if (live) {
+            if (sym) sym[t] = (unsigned short)bi;
+            if (dmin) dmin[t] = best;
+        }
+        if (MODE != 0) {
+            // every lane converts its frame's coefficients to limb pairs in place, then the wave adds frame after frame to
+            // its cell ROW-wise (lanes = consecutive row elements: 512 contiguous bytes per atomic instruction; per-lane
+            // atomics scattered over 64 rows run 17 x slower); the count and the four distortion limbs ride in lanes 0..4
+            // of one more instruction
+            for (int n = 0; n < NC; ++n) {
+                int hi, lo;
+                fix2(fr[n * LD + lane], sh_r, hi, lo);
+                *(int2*)&fr[n * LD + lane] = make_int2(hi, lo);
+            }
+            int d[4] = {0, 0, 0, 0};
+            {
+                const double e = best - 1.0;
+                fix2(e, sh_d, d[0], d[1]);
+                fix2(e * e, sh_d2, d[2], d[3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const long left = T - b * 64;
+            const int nv = left >= 64 ? 64 : (int)left;
+            for (int f = 0; f < nv; ++f) {
+                const int cell = __builtin_amdgcn_readlane(bi, f);
+                i64* row = rows + (long)cell * RS;
+                for (int e0 = 0; e0 < 2 * NC; e0 += 64) {
+                    const int e = e0 + lane;
+                    if (e < 2 * NC) atomicAdd((u64*)&row[e], (u64)(i64)fri[((e >> 1) * LD + f) * 2 + (e & 1)]);
+                }
+                const int d0 = __builtin_amdgcn_readlane(d[0], f), d1 = __builtin_amdgcn_readlane(d[1], f),
+                          d2 = __builtin_amdgcn_readlane(d[2], f), d3 = __builtin_amdgcn_readlane(d[3], f);
+                if (lane < 5) {
+                    const int v = lane == 0 ? 1 : lane == 1 ? d0 : lane == 2 ? d1 : lane == 3 ? d2 : d3;
+                    atomicAdd((u64*)&row[2 * NC + lane], (u64)(i64)v);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (the next block overwrites the staged frames)
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // per-level statistics from the (all-reduced) rows
 // ------------------------------------------------------------------------------------------
@@ -1208,6 +1322,26 @@ int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const
         E2VQ_MFMA_NC_LIST(X)
 #undef X
         default: break;
+    }
+    // generic orders (P > 40).  With a scratch buffer for the transposed codebook (generic_scratch_doubles(NC, M) doubles, handed
+    // over in the `cbm` slot) the LDS-staged kernel runs; without one, the plain kernel below
+    if (cbm && (size_t)NC * GEN_LD * 8 <= (size_t)E2VQ_LDS_BYTES - 1024) {
+        const int Mpad = (M + GEN_G - 1) / GEN_G * GEN_G;
+        double* cbT = const_cast<double*>(cbm);
+        hipLaunchKernelGGL(k_transpose_codebook, dim3(grid_for((long)NC * Mpad, 256, 1024)), dim3(256), 0, s, cbq, M, NC,
+                           (NC + 7) & ~7, cbT, Mpad);
+        const size_t lds = (size_t)NC * GEN_LD * 8;
+        const int g2 = grid_for(nblocks, 1, 256 * (int)((size_t)E2VQ_LDS_BYTES / lds > 8 ? 8 : (size_t)E2VQ_LDS_BYTES / lds));
+        if (mode == 0) {
+            (void)hipFuncSetAttribute((const void*)k_pass_generic_lds<0>, hipFuncAttributeMaxDynamicSharedMemorySize, E2VQ_LDS_BYTES);
+            hipLaunchKernelGGL((k_pass_generic_lds<0>), dim3(g2), dim3(64), lds, s, blk, T, nblocks, NC, cbT, M, Mpad, sc, l1max_bits,
+                               sym, dmin, rows);
+        } else {
+            (void)hipFuncSetAttribute((const void*)k_pass_generic_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, E2VQ_LDS_BYTES);
+            hipLaunchKernelGGL((k_pass_generic_lds<2>), dim3(g2), dim3(64), lds, s, blk, T, nblocks, NC, cbT, M, Mpad, sc, l1max_bits,
+                               sym, dmin, rows);
+        }
+        return 0;
     }
     // generic: 64 frames per block, global atomics for the accumulation
     const int grid = grid_for(nblocks, TPB / 64, 2048);

@@ -84,6 +84,7 @@ struct e2vq_session {
     double* d_refl_next = nullptr; // grow target
     double* d_cbq = nullptr;       // [M][NPAD] pre-doubled raas rows
     double* d_cbm = nullptr;       // MFMA operand layout of the same codewords (P = 36)
+    double* d_cbT = nullptr;       // P > 40: scratch for the transposed codebook of the LDS-staged generic sweep
     u64* d_l1max = nullptr;
     // shadow codebook: the centroid update of a pass is launched speculatively into these right after the
     // statistics kernel, while the host reads DD and decides; e2vq_update commits by swapping pointers
@@ -212,6 +213,10 @@ static int ensure_codebook_capacity(e2vq_session* s, int M)
     if (e2vq::uses_mfma(s->NC)) {
         HIPCHK(hipMalloc(&cbm, (size_t)e2vq::cbm_doubles(s->NC, cap) * 8));
         HIPCHK(hipMalloc(&cbm_spec, (size_t)e2vq::cbm_doubles(s->NC, cap) * 8));
+    } else {
+        if (s->d_cbT) (void)hipFree(s->d_cbT);
+        s->d_cbT = nullptr;
+        HIPCHK(hipMalloc(&s->d_cbT, (size_t)e2vq::generic_scratch_doubles(s->NC, cap) * 8));
     }
     HIPCHK(hipMalloc(&S, (size_t)cap * s->NC * 8));
     // (+ the flags k_cell_update's publishing workgroup polls: two per cell)
@@ -327,7 +332,7 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* ptrs[] = {s->sv.refl, s->sv.rows, s->sv.rows_local, s->sv.cells, s->d_rows_parent, s->d_fam, s->d_aos, s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
+    void* ptrs[] = {s->d_cbT, s->sv.refl, s->sv.rows, s->sv.rows_local, s->sv.cells, s->d_rows_parent, s->d_fam, s->d_aos, s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
                     s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg2[0], s->d_cimg2[1], s->d_ps2[0], s->d_ps2[1], s->d_ps, s->d_fblist, s->d_prev_sym, s->d_rows_local,
                     s->d_ea_q, s->d_qfimg, s->d_qfg, s->d_qfblist, s->d_qcimg};
@@ -710,7 +715,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         unsigned short* sym_out = device_sym ? (unsigned short*)device_sym : s->d_prev_sym;
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
         s->n_plain_launches++;
-        e2vq::launch_pass(s->NC, mode, s->d_blk, s->T, s->nblocks, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max, sym_out,
+        e2vq::launch_pass(s->NC, mode, s->d_blk, s->T, s->nblocks, s->d_cbq, s->d_cbm ? s->d_cbm : s->d_cbT, s->M, s->d_sc, s->d_l1max, sym_out,
                           (double*)device_dmin, rows, s->stream);
         if (s->timing) {
             HIPCHK(hipEventRecord(s->ev1, s->stream));
@@ -752,7 +757,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     } else {
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
         s->n_plain_launches++;
-        e2vq::launch_pass(s->NC, mode, s->d_blk, s->T, s->nblocks, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max,
+        e2vq::launch_pass(s->NC, mode, s->d_blk, s->T, s->nblocks, s->d_cbq, s->d_cbm ? s->d_cbm : s->d_cbT, s->M, s->d_sc, s->d_l1max,
                           record_cells ? s->d_prev_sym : (unsigned short*)device_sym, (double*)device_dmin, rows, s->stream);
         if (s->timing) {
             HIPCHK(hipEventRecord(s->ev1, s->stream));
@@ -1365,7 +1370,7 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
     }
     if (ensure_qblk(s, T)) return 1;
     e2vq::launch_blockify((const double*)device_frames, T, s->NC, s->FB, s->d_qblk, nb, nullptr, nullptr, s->stream);
-    e2vq::launch_pass(s->NC, 0, s->d_qblk, T, nb, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
+    e2vq::launch_pass(s->NC, 0, s->d_qblk, T, nb, s->d_cbq, s->d_cbm ? s->d_cbm : s->d_cbT, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                       (double*)device_dmin, nullptr, s->stream);
     HIPCHK(hipGetLastError());
     return 0;

@@ -1,15 +1,19 @@
+"""Sweep rate of the prediction orders beyond the MFMA instantiations (P > 40: k_pass_generic_lds), M = 1024."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 import ecoz2rs_amd as e
 os.environ["ECOZ2_VQ_QUIET"] = "1"
-for P in (33, 36, 35, 38, 10, 4):
-    T, M = 1 << 20, 1024
-    frames = e.synth.synth_frames(1, 20, P, 0, T)
-    s = e.VqSession(P); s.set_frames(frames); s.prepare(); s.init_codebook(); s.learn(1e9, M); s.enable_timing(True)
-    ks = []
-    for i in range(3):
-        s.run_pass(); ks.append(s.last_pass_kernel_ms())
-    k = min(ks)
-    print(f"P={P}: M={M} pass on {T} frames {k:.3f} ms = {T/k*1e-6:.3f} G frames/s, {2*M*(P+1)*T/k*1e-9:.1f} TF useful")
-    s.close()
+M, T = 1024, 1 << 18
+for P in (48, 64, 100, 200):
+    frames = e.synth.synth_frames(7, 8, P, 0, T)
+    rng = np.random.default_rng(P)
+    refl = np.zeros((M, P + 1)); refl[:, 1:] = rng.uniform(-0.3, 0.3, (M, P)) * 0.9 ** np.arange(P)
+    with e.VqSession(P) as s:
+        s.set_frames(frames); s.prepare(); s.set_codebook(refl)
+        s.enable_timing(True)
+        ts = []
+        for _ in range(4):
+            s.run_pass(); ts.append(s.last_pass_kernel_ms()); s.pass_stats(); s.update()
+        ms = min(ts)
+        print(f"P={P}: pass kernel {ms:.2f} ms on {T} frames x {M} codewords = {2 * M * (P + 1) * T / ms * 1e-9:.1f} TFLOP/s useful", flush=True)
