@@ -34,30 +34,35 @@ __host__ __device__ __forceinline__ long mfma_blk_offset(int NC, long t, int n)
 
 // The 64 frames of block b from the blocked layout into the FP64 MFMA B operands: Bf[ft][st], lane (q, j), holds
 // r[frame 16 ft + j][4 st + q]; with NC = 4k+1 every q lane holds r[NC-1] in the last slot (it is applied on the VALU).
+// (one half of the block: frames 32 u .. 32 u + 31 -> Bf[2u], Bf[2u + 1])
+template <int NC>
+__device__ __forceinline__ void load_block_frames_half(const double* __restrict__ blk, long b, int lane, int u,
+                                                       double (&Bf)[4][2 * ((((NC + 3) / 4) + 1) / 2)])
+{
+    constexpr int NS = (NC + 3) / 4, REM = NC - 4 * (NS - 1);
+    const int q = lane >> 4, j = lane & 15;
+    const double* base = blk + b * (long)(NC * 64) + u * (NC * 32);
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) {
+        const double2 v = *(const double2*)(base + (st * 64 + lane) * 2);
+        Bf[2 * u][st] = v.x;
+        Bf[2 * u + 1][st] = v.y;
+    }
+    double2 v = make_double2(0.0, 0.0);
+    if (REM == 1)  // every lane of frame j keeps r[NC-1] (the four q lanes read the same 16 B)
+        v = *(const double2*)(base + (NS - 1) * 128 + j * 2);
+    else if (q < REM)
+        v = *(const double2*)(base + (NS - 1) * 128 + (q * 16 + j) * 2);
+    Bf[2 * u][NS - 1] = v.x;
+    Bf[2 * u + 1][NS - 1] = v.y;
+}
+
 template <int NC>
 __device__ __forceinline__ void load_block_frames(const double* __restrict__ blk, long b, int lane,
                                                   double (&Bf)[4][2 * ((((NC + 3) / 4) + 1) / 2)])
 {
-    constexpr int NS = (NC + 3) / 4, REM = NC - 4 * (NS - 1);
-    const int q = lane >> 4, j = lane & 15;
-    const double* fb = blk + b * (long)(NC * 64);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const double* base = fb + u * (NC * 32);
-#pragma unroll
-        for (int st = 0; st < NS - 1; ++st) {
-            const double2 v = *(const double2*)(base + (st * 64 + lane) * 2);
-            Bf[2 * u][st] = v.x;
-            Bf[2 * u + 1][st] = v.y;
-        }
-        double2 v = make_double2(0.0, 0.0);
-        if (REM == 1)  // every lane of frame j keeps r[NC-1] (the four q lanes read the same 16 B)
-            v = *(const double2*)(base + (NS - 1) * 128 + j * 2);
-        else if (q < REM)
-            v = *(const double2*)(base + (NS - 1) * 128 + (q * 16 + j) * 2);
-        Bf[2 * u][NS - 1] = v.x;
-        Bf[2 * u + 1][NS - 1] = v.y;
-    }
+    load_block_frames_half<NC>(blk, b, lane, 0, Bf);
+    load_block_frames_half<NC>(blk, b, lane, 1, Bf);
 }
 
 // the same operands straight from the row-major .prd payload (quantize: no blocked copy is made); frames >= T read as 0
@@ -260,6 +265,184 @@ __device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((N
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
+}
+
+// ---- register accumulate (MODE 7: M <= 16, rows of at most 80 elements) ------------------------------------------------
+// The sums of a wave's frames per cell are a product (cells x frames) . (frames x row elements) with a one-hot left factor,
+// and the row elements are 32-bit integers: written as four signed byte digits they go through the i8 matrix unit exactly
+// (i32 accumulators), 32 frames x 16 elements x 16 cells per v_mfma_i32_16x16x32_i8, and the accumulators stay in registers
+// until the wave has swept all its blocks -- no atomic of any kind inside the block loop (the LDS table of MODE 1 costs 80
+// ds_add_u64 per 64 frames, two thirds of that kernel's time at M <= 16).  v = d0 + 256 d1 + 65536 d2 + 2^24 d3 with
+// d0..d2 in [-128, 127]: the bytes of (v + 0x808080) ^ 0x808080 (|v| <= 2^30, so the sum cannot wrap).  |digit sum| <=
+// 128 * frames of the wave: the caller flushes before 2^23 frames.
+// Image of a half block: img[f][RegAcc::STRIDE] ints, f = 0..31 (frame 32 u + f of the block), digits already applied;
+// cellb[f]: cell of frame f, 0xFF for padding frames (no cell: the frame's column of the one-hot factor is empty).
+template <int NC>
+struct RegAcc {
+    static constexpr int NE = 2 * NC + 5;
+    static constexpr int NET = (NE + 15) / 16;      // element tiles of 16
+    static constexpr int STRIDE = 16 * NET + 2;     // = 2 mod 16: conflict-free limb writes and digit reads
+    static constexpr int WAVE_INTS = 32 * STRIDE + 8;  // + 32 cell bytes
+    static constexpr bool OK = NE <= 80;
+};
+
+typedef int i4 __attribute__((ext_vector_type(4)));
+
+// fix2 by one multiplication whenever 2^sh is a normal double (always, for data a .prd file can hold), else by ldexp
+struct FixScale {
+    int sh;
+    double scale;
+    bool fast;
+};
+__device__ __forceinline__ FixScale fix_scale(int sh)
+{
+    FixScale f;
+    f.sh = sh;
+    f.fast = sh >= -1000 && sh <= 1000;
+    f.scale = ldexp(1.0, f.fast ? sh : 0);
+    return f;
+}
+template <bool FAST>
+__device__ __forceinline__ void fix2_by(double x, const FixScale& f, int& hi, int& lo)
+{
+    if (FAST)
+        fix2_mul(x, f.scale, hi, lo);
+    else
+        fix2(x, f.sh, hi, lo);
+}
+
+// frames 32 u .. 32 u + 31 of block b: H[h][st], lane (q, j), holds r[frame 32 u + 16 h + j][4 st + q]
+template <int NC>
+__device__ __forceinline__ void load_half_frames(const double* __restrict__ blk, long b, int u, int lane,
+                                                 double (&H)[2][2 * ((((NC + 3) / 4) + 1) / 2)])
+{
+    constexpr int NS = (NC + 3) / 4, REM = NC - 4 * (NS - 1);
+    const int q = lane >> 4, j = lane & 15;
+    const double* base = blk + b * (long)(NC * 64) + u * (NC * 32);
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) {
+        const double2 v = *(const double2*)(base + (st * 64 + lane) * 2);
+        H[0][st] = v.x;
+        H[1][st] = v.y;
+    }
+    double2 v = make_double2(0.0, 0.0);
+    if (REM == 1)
+        v = *(const double2*)(base + (NS - 1) * 128 + j * 2);
+    else if (q < REM)
+        v = *(const double2*)(base + (NS - 1) * 128 + (q * 16 + j) * 2);
+    H[0][NS - 1] = v.x;
+    H[1][NS - 1] = v.y;
+#pragma unroll
+    for (int st = NS; st < 2 * ((NS + 1) / 2); ++st) H[0][st] = H[1][st] = 0.0;
+}
+
+__device__ __forceinline__ int digit_bytes(int v) { return (v + 0x00808080) ^ 0x00808080; }
+
+// H[h][st]: lane (q, j) holds r[frame 16 h + j of the half block][4 st + q]; best / idx as in accumulate_block; t0: index of
+// the half block's first frame
+template <int NC, bool FAST>
+__device__ __forceinline__ void regacc_stage_half(const double (&H)[2][2 * ((((NC + 3) / 4) + 1) / 2)],
+                                                  const double (&best)[2], const int (&idx)[2], int* __restrict__ img,
+                                                  const FixScale& fr, const FixScale& fd, const FixScale& fd2, long t0, long T,
+                                                  int lane)
+{
+    constexpr int NS = (NC + 3) / 4, REM = NC - 4 * (NS - 1);
+    constexpr int STRIDE = RegAcc<NC>::STRIDE;
+    const int q = lane >> 4, j = lane & 15;
+    unsigned char* cellb = (unsigned char*)(img + 32 * STRIDE);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int* my = img + (16 * h + j) * STRIDE;
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            if (st < NS - 1 || q < REM) {
+                int hi, lo;
+                fix2_by<FAST>(H[h][st], fr, hi, lo);
+                *(int2*)&my[2 * (4 * st + q)] = make_int2(digit_bytes(hi), digit_bytes(lo));
+            }
+        }
+        if (q == 0) {
+            const double e = best[h] - 1.0;
+            int hi, lo;
+            my[2 * NC] = 1;
+            fix2_by<FAST>(e, fd, hi, lo);
+            my[2 * NC + 1] = digit_bytes(hi);
+            my[2 * NC + 2] = digit_bytes(lo);
+            fix2_by<FAST>(e * e, fd2, hi, lo);
+            my[2 * NC + 3] = digit_bytes(hi);
+            my[2 * NC + 4] = digit_bytes(lo);
+            cellb[16 * h + j] = (t0 + 16 * h + j < T) ? (unsigned char)idx[h] : (unsigned char)0xFF;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 0x01 in every byte of x that equals the byte c (c replicated four times in c4), 0 elsewhere
+__device__ __forceinline__ unsigned bytes_equal(unsigned x, unsigned c4)
+{
+    const unsigned y = x ^ c4;
+    const unsigned t = (y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return (~(t | y | 0x7F7F7F7Fu)) >> 7;
+}
+
+template <int NC>
+__device__ __forceinline__ void regacc_add_half(const int* __restrict__ img, int lane, i4 (&racc)[RegAcc<NC>::NET][4])
+{
+    constexpr int STRIDE = RegAcc<NC>::STRIDE, NET = RegAcc<NC>::NET;
+    const int c = lane & 15, kg = lane >> 4;
+    // one-hot factor: row = cell c, k-slots 8 kg .. 8 kg + 7 = frames 8 kg + i of the half block
+    const uint2 cb = *(const uint2*)((const unsigned char*)(img + 32 * STRIDE) + 8 * kg);
+    const unsigned c4 = (unsigned)c * 0x01010101u;
+    const long hot = (long)(((u64)bytes_equal(cb.y, c4) << 32) | (u64)bytes_equal(cb.x, c4));
+    const int* col = img + (8 * kg) * STRIDE + c;
+#pragma unroll
+    for (int et = 0; et < NET; ++et) {
+        unsigned x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = (unsigned)col[i * STRIDE + 16 * et];
+        // 4 x 4 byte transposes: plane p of frames 0..3 / 4..7 (v_perm_b32: bytes 0-3 = second operand, 4-7 = first)
+        unsigned pl[4][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const unsigned t0 = __builtin_amdgcn_perm(x[4 * m + 1], x[4 * m], 0x05010400u);
+            const unsigned t1 = __builtin_amdgcn_perm(x[4 * m + 1], x[4 * m], 0x07030602u);
+            const unsigned t2 = __builtin_amdgcn_perm(x[4 * m + 3], x[4 * m + 2], 0x05010400u);
+            const unsigned t3 = __builtin_amdgcn_perm(x[4 * m + 3], x[4 * m + 2], 0x07030602u);
+            pl[0][m] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+            pl[1][m] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+            pl[2][m] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+            pl[3][m] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const long bp = (long)(((u64)pl[p][1] << 32) | (u64)pl[p][0]);
+            racc[et][p] = __builtin_amdgcn_mfma_i32_16x16x32_i8(hot, bp, racc[et][p], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // (the next half overwrites the images)
+}
+
+// the wave's register sums into the workgroup's LDS table (rows of RS int64), registers back to zero
+template <int NC>
+__device__ __forceinline__ void regacc_flush(i4 (&racc)[RegAcc<NC>::NET][4], i64* __restrict__ lacc, int M, int lane)
+{
+    constexpr int NE = RegAcc<NC>::NE, NET = RegAcc<NC>::NET, RS = (NE + 7) & ~7;
+    const int el = lane & 15, rg = lane >> 4;
+#pragma unroll
+    for (int et = 0; et < NET; ++et) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cell = 4 * rg + i, e = 16 * et + el;
+            const i64 v = (i64)racc[et][0][i] + ((i64)racc[et][1][i] << 8) + ((i64)racc[et][2][i] << 16) +
+                          ((i64)racc[et][3][i] << 24);
+            if (cell < M && e < NE && v != 0) atomicAdd((u64*)&lacc[cell * RS + e], (u64)v);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) racc[et][p] = (i4){0, 0, 0, 0};
+    }
 }
 
 // ---- deferred accumulate (prefiltered sweep, MODE 2, A/B variant E2VQ_PRE_DEFER) -----------------------------------

@@ -516,6 +516,138 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
 }
 
 
+// ------------------------------------------------------------------------------------------
+// K1+K2 for M <= 16 (the first four levels of every ladder: 24 of the 45 passes of a 2..1024 ladder): the FP64 sweep of
+// k_pass_mfma over the ONE codeword tile, 32 frames (a half block) at a time, and the cell sums as per-wave register
+// accumulators fed by the i8 matrix unit (vq_accum.h: RegAcc) -- no atomic inside the loop.  The codeword tile stays in
+// registers for the whole kernel; the next half block is in flight while the current one is swept, staged and added.
+// ------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(512, 2) void k_pass_small(const double* __restrict__ blk, long T, long nblocks,
+                                                       const double* __restrict__ cbm, int M,
+                                                       const DevScalars* __restrict__ sc, const u64* __restrict__ l1max_bits,
+                                                       unsigned short* __restrict__ sym, double* __restrict__ dmin,
+                                                       i64* __restrict__ rows)
+{
+    constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2, REM = NC - 4 * (NS - 1);
+    constexpr bool TAILV = REM == 1;
+    constexpr int NSM = TAILV ? NS - 1 : NS;
+    constexpr int RS = (2 * NC + 5 + 7) & ~7;
+    constexpr int NET = RegAcc<NC>::NET;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4;
+    const int wib = threadIdx.x >> 6;
+    const long wave = (long)blockIdx.x * 8 + wib, nwaves = (long)gridDim.x * 8;
+
+    const FixScale fr = fix_scale(sc->sh_r);
+    const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
+    const FixScale fd = fix_scale(30 - Ed), fd2 = fix_scale(30 - 2 * Ed);
+    const bool fast = fr.fast && fd.fast && fd2.fast;
+
+    // LDS: the cell table | the codeword tile in operand order, [p][lane] pairs + the trailing coefficient of the four
+    // codewords 4 rg + q (read again for every half block: 28 registers that the accumulators need more) | per-wave images
+    i64* lacc = (i64*)smem;
+    double* ctile = (double*)(smem + (size_t)M * RS * 8);
+    int* img = (int*)(ctile + NP * 128 + 16) + wib * RegAcc<NC>::WAVE_INTS;
+    for (int i = threadIdx.x; i < M * RS; i += 512) lacc[i] = 0;
+    for (int i = threadIdx.x; i < NP * 128 + 16; i += 512)
+        ctile[i] = i < NP * 128 ? cbm[i] : (TAILV ? cbm[(long)((M + 15) / 16) * NP * 128 + (i - NP * 128)] : 0.0);
+    __syncthreads();
+
+    i4 racc[NET][4];
+#pragma unroll
+    for (int et = 0; et < NET; ++et)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) racc[et][p] = (i4){0, 0, 0, 0};
+
+    double Hn[2][2 * NP];
+    if (wave < nblocks) load_half_frames<NC>(blk, wave, 0, lane, Hn);
+    long done = 0;
+    for (long b = wave; b < nblocks; b += nwaves) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            double H[2][2 * NP];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int st = 0; st < 2 * NP; ++st) H[h][st] = Hn[h][st];
+            {
+                // (unconditional: a conditional load keeps its registers live across the branch; the last request re-reads
+                // the wave's own half)
+                const long bn = u == 0 ? b : (b + nwaves < nblocks ? b + nwaves : b);
+                load_half_frames<NC>(blk, bn, u ^ 1, lane, Hn);
+            }
+            // ---- sweep: two chains of NSM FP64 MFMAs (16 codewords x 16 frames each), k ascending ----
+            int aoff = lane * 2;
+            asm volatile("" : "+v"(aoff));  // (loop-variant as far as the compiler knows: the tile is not hoisted into registers)
+            double2 A[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) A[p] = *(const double2*)(ctile + p * 128 + aoff);
+            d4 acc[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[0].x, H[h][0], (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+#pragma unroll
+            for (int st = 1; st < NSM; ++st)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64((st & 1) ? A[st >> 1].y : A[st >> 1].x, H[h][st], acc[h], 0, 0, 0);
+            double best[2];
+            int idx[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (TAILV) {
+                    const d4 Tc = *(const d4*)(ctile + NP * 128 + (aoff >> 5) * 4);  // (aoff >> 5 = q)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) acc[h][rg] = __builtin_fma(H[h][NS - 1], Tc[rg], acc[h][rg]);
+                }
+                // lane (q, j): codewords 4 rg + q of frame j, ascending in rg; then the four q lanes of the frame
+                best[h] = acc[h][0];
+                int code = 0;
+#pragma unroll
+                for (int rg = 1; rg < 4; ++rg) {
+                    const bool lt = acc[h][rg] < best[h];
+                    code = lt ? rg : code;
+                    best[h] = lt ? acc[h][rg] : best[h];
+                }
+                idx[h] = (code << 2) + q;
+#pragma unroll
+                for (int off = 16; off <= 32; off <<= 1) {
+                    const double ob = __shfl_xor(best[h], off, 64);
+                    const int oi = __shfl_xor(idx[h], off, 64);
+                    const bool take = ob < best[h] || (ob == best[h] && oi < idx[h]);
+                    best[h] = take ? ob : best[h];
+                    idx[h] = take ? oi : idx[h];
+                }
+            }
+            // ---- outputs: lane 16 h + j (q = h < 2) owns frame t0 + lane ----
+            const long t0 = b * 64 + 32 * u;
+            {
+                const long t = t0 + lane;
+                if (lane < 32 && t < T) {
+                    if (sym) sym[t] = (unsigned short)(q == 0 ? idx[0] : idx[1]);
+                    if (dmin) dmin[t] = q == 0 ? best[0] : best[1];
+                }
+            }
+            // ---- accumulate ----
+            if (fast)  // (kernel-uniform)
+                regacc_stage_half<NC, true>(H, best, idx, img, fr, fd, fd2, t0, T, lane);
+            else
+                regacc_stage_half<NC, false>(H, best, idx, img, fr, fd, fd2, t0, T, lane);
+            regacc_add_half<NC>(img, lane, racc);
+        }
+        // digit sums stay below 2^31 for 2^24 frames per wave; flush long before
+        if ((++done & 0xFFFF) == 0) regacc_flush<NC>(racc, lacc, M, lane);
+    }
+    regacc_flush<NC>(racc, lacc, M, lane);
+    __syncthreads();
+    for (int i = threadIdx.x; i < M * RS; i += 512) {
+        const i64 v = lacc[i];
+        if (v != 0) atomicAdd((u64*)&rows[i], (u64)v);
+    }
+}
+
 // global sums for the MFMA frame layout: per-lane 64-bit accumulators for its coefficients
 // n = 4s + q, reduced over the 16 lanes (frames) that share q, one atomic per (n, limb) per wave.
 template <int NC>
@@ -1261,6 +1393,13 @@ void launch_global_sums(const double* blk, long nblocks, int NC, int FB, const D
                        stats);
 }
 
+// A/B switch: ECOZ2_VQ_SMALL_REGS=0 sends M <= 16 back to the LDS-table kernel
+static bool small_codebook_register_sums()
+{
+    static const bool on = !(getenv("ECOZ2_VQ_SMALL_REGS") && atoi(getenv("ECOZ2_VQ_SMALL_REGS")) == 0);
+    return on;
+}
+
 template <int NC>
 static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, const double* cbm, int M,
                             const DevScalars* sc, const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows,
@@ -1280,6 +1419,12 @@ static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, c
         const int grid = grid_for(nblocks, 4, 512);
         hipLaunchKernelGGL((k_pass_mfma<NC, 0, 256, 1>), dim3(grid), dim3(256), lds, s, blk, T, nblocks, cbm, MT, M, sc,
                            l1max_bits, sym, dmin, rows, 0);
+    } else if (mode == 1 && M <= 16 && RegAcc<NC>::OK && small_codebook_register_sums()) {
+        const size_t lds = (size_t)M * RS * 8 + (size_t)((((NC + 3) / 4 + 1) / 2) * 128 + 16) * 8 + (size_t)8 * RegAcc<NC>::WAVE_INTS * 4;
+        (void)hipFuncSetAttribute((const void*)k_pass_small<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, E2VQ_LDS_BYTES);
+        const int grid = grid_for(nblocks, 8, 256);
+        hipLaunchKernelGGL((k_pass_small<NC>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, M, sc, l1max_bits, sym,
+                           dmin, rows);
     } else if (mode == 1) {
         const size_t lds = (size_t)M * RS * 8 + (size_t)8 * 16 * IMG * 4;
         // every launch: the attribute is per device, and sessions may live on several devices of one process
