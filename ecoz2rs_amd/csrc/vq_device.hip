@@ -631,11 +631,15 @@ __global__ __launch_bounds__(512, 2) void k_pass_small(const double* __restrict_
                 }
             }
             // ---- accumulate ----
+#if !defined(E2VQ_SMALL_EXP) || E2VQ_SMALL_EXP < 2  // (A/B builds, tools/probe/ab: 2 = no accumulate at all, 1 = images only)
             if (fast)  // (kernel-uniform)
                 regacc_stage_half<NC, true>(H, best, idx, img, fr, fd, fd2, t0, T, lane);
             else
                 regacc_stage_half<NC, false>(H, best, idx, img, fr, fd, fd2, t0, T, lane);
+#endif
+#if !defined(E2VQ_SMALL_EXP)
             regacc_add_half<NC>(img, lane, racc);
+#endif
         }
         // digit sums stay below 2^31 for 2^24 frames per wave; flush long before
         if ((++done & 0xFFFF) == 0) regacc_flush<NC>(racc, lacc, M, lane);
