@@ -619,6 +619,54 @@ __device__ unsigned long long g_pre_stamps[32];
         }                                                                                                         \
     }
 
+// The rotated tile loop of k_pass_pre_lds (job 0 of tile 0 | job 1 of tile t, job 0 of tile t + 1 | job 1 of the last tile)
+// uses two more forms of the ordered job.  _LOADS: behind MFMA s -- the last reader of A[s] in its tile -- the same
+// register is requested for the next tile (lo_ = lane * 16, cbn_ = that tile's image), so the L2 latency of a tile's operands
+// runs under the fifteen MFMAs of the job instead of in front of the next tile.  _WAITS: MFMA s waits for exactly its own
+// operand: the vector-memory counter is in-order, NSTEP - 1 - s younger requests may still be out (anything else in flight
+// -- the previous block's atomics -- is older and only makes the wait longer, never too short).
+#define E2VQ_PRE_JOB_STEP_EPILOGUE(S, PREV, PTILE, PCB)                                                           \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
+    {                                                                                                             \
+        if (r * PK::NSTEP / 16 != (S)) continue;                                                                  \
+        const int sidx = __builtin_amdgcn_readfirstlane((PTILE) * 32 + 8 * (r >> 2) + (r & 3));                  \
+        const float v = __builtin_fmaf(PREV[0][r], 262144.f, __builtin_fmaf(PREV[1][r], 512.f, PREV[2][r]));     \
+        const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);                                     \
+        k3[PCB] = med3f(k2[PCB], k3[PCB], key);                                                                   \
+        k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                                   \
+        k1[PCB] = med3f(k1[PCB], key, ninf);                                                                      \
+    }
+#define E2VQ_PRE_JOB_LOADS(ACC, BC, PREV, PTILE, PCB)                                                              \
+    {                                                                                                             \
+        const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
+        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
+        {                                                                                                         \
+            const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \
+            const bool first = s == PK::level_first(lv);                                                         \
+            ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"                                               \
+                         : "=&v"(A[s])                                                                            \
+                         : "v"(lo_ + (unsigned)((s >> 2) * 4096)), "s"(cbn_), "n"((s & 3) * 1024)                 \
+                         : "memory");                                                                             \
+            E2VQ_PRE_JOB_STEP_EPILOGUE(s, PREV, PTILE, PCB)                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
+    }
+#define E2VQ_PRE_JOB_WAITS(ACC, BC, PREV, PTILE, PCB)                                                              \
+    {                                                                                                             \
+        const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
+        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
+        {                                                                                                         \
+            const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \
+            const bool first = s == PK::level_first(lv);                                                         \
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(A[s]) : "n"(PK::NSTEP - 1 - s) : "memory");                 \
+            ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
+            E2VQ_PRE_JOB_STEP_EPILOGUE(s, PREV, PTILE, PCB)                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
+    }
+
 // One wave = 64 frames, independent of every other wave (no LDS sharing, no barriers): the codeword tile images come
 // straight from L2 (512 KB at M = 1024; 16 B per lane and k-step) -- measured as fast as a workgroup-shared LDS ring
 // (tools/probe/pre_sweep.hip -DDIRECT_L2), and it lets the two waves of a SIMD drift apart so that one sweeps (matrix
@@ -1104,6 +1152,9 @@ __device__ __forceinline__ int pre_fresh_lane()
     return l;
 }
 
+#ifndef E2VQ_PRE_ROT
+#define E2VQ_PRE_ROT 1  // (0: the single loop with one wait per tile, for A/B builds)
+#endif
 template <int NC>
 __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restrict__ aos, long T, long nblocks,
                                                          const h8* __restrict__ fimg, const float* __restrict__ fg,
@@ -1200,6 +1251,18 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         // without a counter wait while those atomics drain; the loads of tile 1 queue behind them.  The in-loop loads
         // are inline asm with a hand-placed wait: any load the compiler can see in this loop makes it insert counter
         // waits that, at t = 0, would wait for the atomics (the counter is in-order and the number of atomics unknown).
+#if E2VQ_PRE_ROT
+        // rotated: the operands of tile t + 1 are requested register by register behind their last readers in job 1 of tile
+        // t and waited for one by one in job 0 of tile t + 1 (tile 0's came with the block's limb images: no wait at all)
+        E2VQ_PRE_JOB_ORDERED(acc0, B[0], acc1, 0xffff, 1)  // (the "previous" accumulators hold 3e38)
+        for (int t = 0; t + 1 < MT; ++t) {
+            const char* cbn_ = (const char*)cimg + (size_t)(t + 1) * TILE_IMG;
+            const unsigned lo_ = (unsigned)lane_t * 16u;
+            E2VQ_PRE_JOB_LOADS(acc1, B[1], acc0, t, 0)
+            E2VQ_PRE_JOB_WAITS(acc0, B[0], acc1, t, 1)
+        }
+        E2VQ_PRE_JOB_ORDERED(acc1, B[1], acc0, MT - 1, 0)
+#else
         for (int t = 0; t < MT; ++t) {
             if (t > 0) {
                 const char* cb_ = (const char*)cimg + (size_t)t * TILE_IMG;
@@ -1220,6 +1283,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
             if (t == 1) E2VQ_STAMP(10)  // tile 1 (its loads queue behind the previous block's atomics and this block's LDS-DMA)
 #endif
         }
+#endif
         E2VQ_PRE_EPILOGUE(acc1, MT - 1, 1)
         E2VQ_STAMP(1)  // tile loop
 
