@@ -527,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_small(const double* __restrict_
                                                        const double* __restrict__ cbm, int M,
                                                        const DevScalars* __restrict__ sc, const u64* __restrict__ l1max_bits,
                                                        unsigned short* __restrict__ sym, double* __restrict__ dmin,
-                                                       i64* __restrict__ rows)
+                                                       i64* __restrict__ rows, unsigned flush_mask)
 {
     constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2, REM = NC - 4 * (NS - 1);
     constexpr bool TAILV = REM == 1;
@@ -641,8 +641,9 @@ __global__ __launch_bounds__(512, 2) void k_pass_small(const double* __restrict_
             regacc_add_half<NC>(img, lane, racc);
 #endif
         }
-        // digit sums stay below 2^31 for 2^24 frames per wave; flush long before
-        if ((++done & 0xFFFF) == 0) regacc_flush<NC>(racc, lacc, M, lane);
+        // digit sums stay below 2^31 for 2^24 frames per wave; flush long before (flush_mask = 0xFFFF: every 2^22 frames;
+        // the tests set ECOZ2_VQ_SMALL_FLUSH_MASK=0 to take this path after every block)
+        if ((++done & flush_mask) == 0) regacc_flush<NC>(racc, lacc, M, lane);
     }
     regacc_flush<NC>(racc, lacc, M, lane);
     __syncthreads();
@@ -1427,8 +1428,9 @@ static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, c
         const size_t lds = (size_t)M * RS * 8 + (size_t)((((NC + 3) / 4 + 1) / 2) * 128 + 16) * 8 + (size_t)8 * RegAcc<NC>::WAVE_INTS * 4;
         (void)hipFuncSetAttribute((const void*)k_pass_small<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, E2VQ_LDS_BYTES);
         const int grid = grid_for(nblocks, 8, 256);
+        const unsigned flush_mask = getenv("ECOZ2_VQ_SMALL_FLUSH_MASK") ? (unsigned)atoi(getenv("ECOZ2_VQ_SMALL_FLUSH_MASK")) : 0xFFFFu;
         hipLaunchKernelGGL((k_pass_small<NC>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, M, sc, l1max_bits, sym,
-                           dmin, rows);
+                           dmin, rows, flush_mask);
     } else if (mode == 1) {
         const size_t lds = (size_t)M * RS * 8 + (size_t)8 * 16 * IMG * 4;
         // every launch: the attribute is per device, and sessions may live on several devices of one process

@@ -47,6 +47,7 @@ namespace e2vq {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 
 template <int NC>
 struct PrePack {
@@ -619,12 +620,37 @@ __device__ unsigned long long g_pre_stamps[32];
         }                                                                                                         \
     }
 
+#ifndef E2VQ_PRE_PKFMA
+#define E2VQ_PRE_PKFMA 0
+#endif
 // The rotated tile loop of k_pass_pre_lds (job 0 of tile 0 | job 1 of tile t, job 0 of tile t + 1 | job 1 of the last tile)
 // uses two more forms of the ordered job.  _LOADS: behind MFMA s -- the last reader of A[s] in its tile -- the same
 // register is requested for the next tile (lo_ = lane * 16, cbn_ = that tile's image), so the L2 latency of a tile's operands
 // runs under the fifteen MFMAs of the job instead of in front of the next tile.  _WAITS: MFMA s waits for exactly its own
 // operand: the vector-memory counter is in-order, NSTEP - 1 - s younger requests may still be out (anything else in flight
 // -- the previous block's atomics -- is older and only makes the wait longer, never too short).
+// (E2VQ_PRE_PKFMA: the two fmas that fold the three limb levels of a value are done for two values at a time --
+// v_pk_fma_f32 on the accumulators' register pairs -- at the step of the even one: five VALU operations per value, not six)
+#if E2VQ_PRE_PKFMA
+#define E2VQ_PRE_JOB_STEP_EPILOGUE(S, PREV, PTILE, PCB)                                                           \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
+    {                                                                                                             \
+        if (r * PK::NSTEP / 16 != (S)) continue;                                                                  \
+        const int sidx = __builtin_amdgcn_readfirstlane((PTILE) * 32 + 8 * (r >> 2) + (r & 3));                  \
+        if ((r & 1) == 0) {                                                                                       \
+            const f2v p0 = {PREV[0][r], PREV[0][r + 1]}, p1 = {PREV[1][r], PREV[1][r + 1]},                       \
+                      p2 = {PREV[2][r], PREV[2][r + 1]};                                                          \
+            f2v tpair;                                                                                            \
+            asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(tpair) : "v"(p1), "s"(pkc512), "v"(p2));                     \
+            asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(vpair) : "v"(p0), "s"(pkc218), "v"(tpair));                  \
+        }                                                                                                         \
+        const float v = (r & 1) ? vpair[1] : vpair[0];                                                            \
+        const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);                                     \
+        k3[PCB] = med3f(k2[PCB], k3[PCB], key);                                                                   \
+        k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                                   \
+        k1[PCB] = med3f(k1[PCB], key, ninf);                                                                      \
+    }
+#else
 #define E2VQ_PRE_JOB_STEP_EPILOGUE(S, PREV, PTILE, PCB)                                                           \
     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
     {                                                                                                             \
@@ -636,9 +662,12 @@ __device__ unsigned long long g_pre_stamps[32];
         k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                                   \
         k1[PCB] = med3f(k1[PCB], key, ninf);                                                                      \
     }
+#endif
 #define E2VQ_PRE_JOB_LOADS(ACC, BC, PREV, PTILE, PCB)                                                              \
     {                                                                                                             \
         const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
+        [[maybe_unused]] f2v vpair = {0.f, 0.f};                                                                  \
+        [[maybe_unused]] const f2v pkc512 = {512.f, 512.f}, pkc218 = {262144.f, 262144.f};                        \
         _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
         {                                                                                                         \
             const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \
@@ -656,6 +685,8 @@ __device__ unsigned long long g_pre_stamps[32];
 #define E2VQ_PRE_JOB_WAITS(ACC, BC, PREV, PTILE, PCB)                                                              \
     {                                                                                                             \
         const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
+        [[maybe_unused]] f2v vpair = {0.f, 0.f};                                                                  \
+        [[maybe_unused]] const f2v pkc512 = {512.f, 512.f}, pkc218 = {262144.f, 262144.f};                        \
         _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
         {                                                                                                         \
             const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \

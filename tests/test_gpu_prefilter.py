@@ -96,6 +96,36 @@ def _check(oracle, frames, refl, monkeypatch):
     assert oracle_lib.rows_match(rows, rows_o, P)
 
 
+@pytest.mark.parametrize("T", [1, 31, 33, 64, 65, 1000, 8191, 70001])
+@pytest.mark.parametrize("M", [2, 4, 8, 16])
+def test_small_codebook_register_sums(oracle, monkeypatch, T, M):
+    """k_pass_small (M <= 16: cell sums as per-wave register accumulators fed by the i8 matrix unit): ragged frame counts
+    (half blocks, one frame, more blocks than waves), with the accumulators flushed after every block and only at the end;
+    rows, symbols and distortions equal the oracle's."""
+    pool = _frames(20250 + M, max(T, 64))
+    refl = _codebook(oracle, pool, M, seed=3)
+    frames = np.ascontiguousarray(pool[:T])
+    sym_o, dmin_o, rows_o = _oracle_pass(oracle, frames, refl)
+    got = []
+    for flush_mask in ("65535", "0"):
+        monkeypatch.setenv("ECOZ2_VQ_SMALL_FLUSH_MASK", flush_mask)
+        sym, dmin = _DeviceBuffer(2 * T), _DeviceBuffer(8 * T)
+        with e.VqSession(P) as s:
+            s.set_frames(frames)
+            s.prepare()
+            s.set_codebook(refl)
+            s.run_pass(sym.ptr.value, dmin.ptr.value)
+            rows = s.get_rows()
+            s.synchronize()
+        assert oracle_lib.rows_match(rows, rows_o, P), flush_mask
+        assert np.array_equal(sym.to_host(np.uint16), sym_o)
+        assert np.array_equal(dmin.to_host(np.float64).view(np.uint64), dmin_o.view(np.uint64))
+        sym.free()
+        dmin.free()
+        got.append(rows)
+    assert np.array_equal(got[0], got[1])
+
+
 @pytest.mark.parametrize("T,M", [(5000, 64), (7777, 256), (20000, 1024), (9001, 2048), (6000, 4096)])
 def test_prefiltered_pass_bit_exact(oracle, monkeypatch, T, M):
     frames = _frames(20250, T)
