@@ -438,9 +438,10 @@ def main():
             exec_tf = F16_MFMA_FLOP_PER_FRAME_CODEWORD * M * frames_per_launch / (k_ms * 1e-3) / 1e12
             roofline = {
                 "bound": "mfma",
-                "kernel": "k_pass_pre<37,2,512> (exact f16-limb prefilter on v_mfma_f32_32x32x16_f16 + top-3 keys, FP64 "
-                          "evaluation of the certified top two on v_mfma_f64_16x16x4_f64, exact accumulate: full on the "
-                          "first pass of the level, incremental after); uncertified frames: k_pass_mfma<37,2,512,2>",
+                "kernel": "k_pass_pre_lds<37> (exact f16-limb prefilter on v_mfma_f32_32x32x16_f16 + top-3 keys; FP64 frames "
+                          "of the block staged in LDS, the certified top two evaluated as lane-per-frame v_fma_f64 chains; exact "
+                          "accumulate: seeded on the first pass of the level, incremental after); uncertified frames: "
+                          "k_pass_mfma<37,2,256,2>",
                 "achieved": exec_tf,
                 "peak": F16_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
