@@ -97,12 +97,12 @@ def _check(oracle, frames, refl, monkeypatch):
 
 
 @pytest.mark.parametrize("T", [1, 31, 33, 64, 65, 1000, 8191, 70001])
-@pytest.mark.parametrize("M", [2, 4, 8, 16])
+@pytest.mark.parametrize("M", [2, 4, 8, 16, 32, 64, 128])
 def test_small_codebook_register_sums(oracle, monkeypatch, T, M):
-    """k_pass_small (M <= 16: cell sums as per-wave register accumulators fed by the i8 matrix unit): ragged frame counts
-    (half blocks, one frame, more blocks than waves), with the accumulators flushed after every block and only at the end;
-    rows, symbols and distortions equal the oracle's."""
-    pool = _frames(20250 + M, max(T, 64))
+    """k_pass_small (M <= 16: cell sums as per-wave register accumulators fed by the i8 matrix unit) and, for M = 32, 64, 128,
+    the LDS-table kernel: ragged frame counts (half blocks, one frame, more blocks than waves), with the accumulators flushed
+    after every block and only at the end; rows, symbols and distortions equal the oracle's."""
+    pool = _frames(20250 + M, max(T, 256))
     refl = _codebook(oracle, pool, M, seed=3)
     frames = np.ascontiguousarray(pool[:T])
     sym_o, dmin_o, rows_o = _oracle_pass(oracle, frames, refl)
