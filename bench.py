@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefilter", action="store_true",
                     help="keep every pass on the plain FP64 sweep (A/B against the prefiltered sweep; same results)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 only: a one-rank nccl group and the all-reduce hook on every pass anyway (what the exchange's host "
+                         "side costs per pass, without a wire: DESIGN.md section 5)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL over xGMI; "
                     "gloo lets several ranks share one GPU when rehearsing the N > 1 path)")
     args = ap.parse_args()
@@ -191,6 +194,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         else:
             dist.init_process_group(args.backend)
+    elif args.force_collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local}"))
+        os.environ["ECOZ2_VQ_FORCE_ALLREDUCE"] = "1"
 
     S = args.frames_per_gpu
     lo = rank * S
@@ -199,7 +207,7 @@ def main():
     sess = e.VqSession(P, device=local)
     parallel.bind_torch_stream(sess, local)  # session kernels + RCCL collectives on one torch stream
     ar_calls = {"n": 0, "bytes": 0, "max_bytes": 0}
-    if world > 1:
+    if world > 1 or args.force_collective:
         inner = parallel.make_allreduce(local)
 
         def counted(ptr, count, op, stream):
@@ -276,6 +284,10 @@ def main():
     launches_after = sess.sweep_launch_counts()
     timed_pre, timed_plain = launches_after[0] - launches_before[0], launches_after[1] - launches_before[1]
     collective = None
+    if world == 1 and args.force_collective:
+        collective = {"backend": "nccl (one-rank group on this GPU: the host side of the exchange, no wire)", "world_size": 1,
+                      "allreduce_calls": ar_timed["n"], "allreduce_calls_per_step": ar_timed["n"] / max(1, args.steps),
+                      "bytes_per_call": ar_calls["max_bytes"], "bytes_timed_region": ar_timed["bytes"]}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
         if args.backend != "nccl":
