@@ -13,6 +13,13 @@
 // column access A[i][j] with j = lane for the forward pass, and a transposed copy AT[j][i] with i = lane for the
 // backward pass, so both are conflict-free.  Each step is a dependent chain (N fmas, N adds, one divide), so the
 // parallelism is across waves: S x K pairs for scoring, one wave per training sequence for the E-step.
+//
+// More than 64 states (the reference's -N is free; N <= 512 here): k_hmm_score_wg / k_hmm_fb_wg give a sequence a whole
+// workgroup, thread j = state j; the values of the other states travel through LDS arrays with a barrier per step, every
+// thread adds them up itself in the oracle's order (so all threads hold the same bits and take the same branches), A is
+// read from global memory, and the xi sums of a workgroup live in a global scratch table whose column j only thread j
+// ever touches (no atomics until the final flush).  Same arithmetic, same order, same bits as the wave kernels; built to
+// work, not to be fast.
 #include "hmm_device.h"
 #include "vq_fixed.h"
 
@@ -270,6 +277,194 @@ __global__ __launch_bounds__(64 * FB_WAVES) void k_hmm_fb(ModelDev md, const uns
     }
 }
 
+// ---- more than 64 states: one workgroup per sequence, thread j = state j -------------------------------------------
+// LDS: xs[N] (the values the next sum runs over), ys[N].  grid: (S, models of this launch) for scoring.
+__global__ void k_hmm_score_wg(const ModelDev* __restrict__ models, int K, int k0, const unsigned short* __restrict__ sym,
+                               const i64* __restrict__ offs, int S, double* __restrict__ mant, i64* __restrict__ exp2,
+                               int* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* als = (double*)smem;
+    const int k = k0 + (int)blockIdx.y, s = (int)blockIdx.x;
+    const ModelDev md = models[k];
+    const int N = md.N, M = md.M;
+    double* nxs = als + N;
+    const int j = threadIdx.x;
+    const bool act = j < N;
+    const int jj = act ? j : 0;
+    const i64 base = offs[s];
+    const i64 T = offs[s + 1] - base;
+    double p = 0.5;
+    i64 E = 1;
+    int st = 0;
+    for (i64 t = 0; t < T; ++t) {
+        const int o = (int)sym[base + t];
+        if (o >= M) {
+            st = 2;
+            break;
+        }
+        const double b = md.B[(size_t)jj * M + o];
+        double nx;
+        if (t == 0) {
+            nx = md.pi[jj] * b;
+        } else {
+            double acc = 0.0;
+            for (int i = 0; i < N; ++i) acc = fma(als[i], md.A[(size_t)i * N + jj], acc);
+            nx = acc * b;
+        }
+        if (act) nxs[j] = nx;
+        __syncthreads();
+        double c = 0.0;
+        for (int i = 0; i < N; ++i) c = c + nxs[i];
+        if (!(c > 0.0)) {  // (every thread holds the same c)
+            st = 1;
+            break;
+        }
+        if (act) als[j] = nx / c;
+        __syncthreads();
+        scale_step(c, p, E);
+    }
+    if (j == 0) {
+        const size_t idx = (size_t)s * K + k;
+        mant[idx] = st == 0 ? p : 0.0;
+        exp2[idx] = st == 0 ? E : 0;
+        status[idx] = st;
+    }
+}
+
+// E-step.  scratch: gridDim.x tables of 2 N^2 words (zeroed here, flushed to AN with atomics at the end).
+__global__ void k_hmm_fb_wg(ModelDev md, const unsigned short* __restrict__ sym, const i64* __restrict__ offs, int S,
+                            double* __restrict__ alpha_buf, double* __restrict__ c_buf, i64* __restrict__ acc,
+                            double* __restrict__ mant, i64* __restrict__ exp2, int* __restrict__ status,
+                            i64* __restrict__ scratch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int N = md.N, M = md.M;
+    double* xs = (double*)smem;  // alpha^ of the step (forward: of the previous step)
+    double* ys = xs + N;         // nx (forward) / u (backward)
+    const int j = threadIdx.x;
+    const bool act = j < N;
+    const int jj = act ? j : 0;
+    i64* PI = acc;
+    i64* AN = PI + 2 * N;
+    i64* AD = AN + 2 * (i64)N * N;
+    i64* BN = AD + 2 * N;
+    i64* BD = BN + 2 * (i64)N * M;
+    i64* counts = BD + 2 * N;
+    i64* ANw = scratch + (size_t)blockIdx.x * 2 * N * N;  // [i][j][hi, lo]: column j belongs to thread j
+    if (act)
+        for (int i = 0; i < N; ++i) ANw[2 * ((size_t)i * N + j)] = ANw[2 * ((size_t)i * N + j) + 1] = 0;
+    i64 ad[2] = {0, 0}, bd[2] = {0, 0}, pic[2] = {0, 0};
+    int used = 0, skipped = 0;
+    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        const i64 base = offs[s];
+        const i64 T = offs[s + 1] - base;
+        double* alpha = alpha_buf + (size_t)base * N;
+        double* cs = c_buf + base;
+        double al = 0.0, p = 0.5;
+        i64 E = 1;
+        int st = T < 1 ? 1 : 0;
+        __syncthreads();  // (the previous sequence's readers of xs / ys are done)
+        for (i64 t = 0; t < T && st == 0; ++t) {
+            const int o = (int)sym[base + t];
+            if (o >= M) {
+                st = 2;
+                break;
+            }
+            const double b = md.B[(size_t)jj * M + o];
+            double nx;
+            if (t == 0) {
+                nx = md.pi[jj] * b;
+            } else {
+                double a = 0.0;
+                for (int i = 0; i < N; ++i) a = fma(xs[i], md.A[(size_t)i * N + jj], a);
+                nx = a * b;
+            }
+            if (act) ys[j] = nx;
+            __syncthreads();
+            double c = 0.0;
+            for (int i = 0; i < N; ++i) c = c + ys[i];
+            if (!(c > 0.0)) {
+                st = 1;
+                break;
+            }
+            al = nx / c;
+            if (act) {
+                xs[j] = al;
+                alpha[(size_t)t * N + j] = al;
+            }
+            if (j == 0) cs[t] = c;
+            __syncthreads();
+            scale_step(c, p, E);
+        }
+        if (j == 0) {
+            mant[s] = st == 0 ? p : (T < 1 ? 0.5 : 0.0);
+            exp2[s] = st == 0 ? E : (T < 1 ? 1 : 0);
+            status[s] = st;
+        }
+        if (st != 0) {  // (workgroup-uniform)
+            ++skipped;
+            continue;
+        }
+        ++used;
+        // backward: al is alpha^_{T-1}(j); cs[] was written by thread 0 -- the barriers above order it for the workgroup
+        double beta = 1.0;
+        for (i64 t = T - 1; t >= 0; --t) {
+            if (t < T - 1) {
+                al = act ? alpha[(size_t)t * N + j] : 0.0;
+                const int o1 = (int)sym[base + t + 1];
+                const double c1 = cs[t + 1];
+                const double u = (md.B[(size_t)jj * M + o1] * beta) / c1;  // u_j
+                __syncthreads();  // (the previous step's readers of xs / ys are done)
+                if (act) {
+                    xs[j] = al;
+                    ys[j] = u;
+                }
+                __syncthreads();
+                if (act) {
+                    // xi_t(i, j) = (alpha^_t(i) A_ij) u_j: column j of the workgroup's table
+                    for (int i = 0; i < N; ++i) {
+                        const double x = (xs[i] * md.A[(size_t)i * N + j]) * u;
+                        int hi, lo;
+                        e2vq::fix2(x, ACC_SHIFT, hi, lo);
+                        ANw[2 * ((size_t)i * N + j)] += (i64)hi;
+                        ANw[2 * ((size_t)i * N + j) + 1] += (i64)lo;
+                    }
+                }
+                // beta^_t(j) = chain_i fma(A_ji, u_i)  (row j of A)
+                double a = 0.0;
+                for (int i = 0; i < N; ++i) a = fma(md.A[(size_t)jj * N + i], ys[i], a);
+                beta = a;
+            }
+            if (act) {
+                const double g = al * beta;
+                const int o = (int)sym[base + t];
+                if (t < T - 1) acc_local(ad, g);
+                acc_add(BN + 2 * ((i64)j * M + o), g);
+                acc_local(bd, g);
+                if (t == 0) acc_local(pic, g);
+            }
+        }
+    }
+    if (act) {
+        if (ad[0]) atomicAdd((u64*)&AD[2 * j], (u64)ad[0]);
+        if (ad[1]) atomicAdd((u64*)&AD[2 * j + 1], (u64)ad[1]);
+        if (bd[0]) atomicAdd((u64*)&BD[2 * j], (u64)bd[0]);
+        if (bd[1]) atomicAdd((u64*)&BD[2 * j + 1], (u64)bd[1]);
+        if (pic[0]) atomicAdd((u64*)&PI[2 * j], (u64)pic[0]);
+        if (pic[1]) atomicAdd((u64*)&PI[2 * j + 1], (u64)pic[1]);
+        for (int i = 0; i < N; ++i) {
+            const i64 h = ANw[2 * ((size_t)i * N + j)], l = ANw[2 * ((size_t)i * N + j) + 1];
+            if (h) atomicAdd((u64*)&AN[2 * ((size_t)i * N + j)], (u64)h);
+            if (l) atomicAdd((u64*)&AN[2 * ((size_t)i * N + j) + 1], (u64)l);
+        }
+    }
+    if (j == 0) {
+        if (used) atomicAdd((u64*)&counts[0], (u64)used);
+        if (skipped) atomicAdd((u64*)&counts[1], (u64)skipped);
+    }
+}
+
 // M-step: one thread per parameter
 __global__ void k_hmm_reestimate(int N, int M, const i64* __restrict__ acc, double* __restrict__ pi,
                                  double* __restrict__ A, double* __restrict__ B)
@@ -317,6 +512,10 @@ __global__ void k_hmm_adjustb(int N, int M, double epsilon, double* __restrict__
 // ---- launchers ------------------------------------------------------------------------------------------------
 i64 acc_words(int N, int M) { return 2 * ((i64)N + (i64)N * N + N + (i64)N * M + N) + 2; }
 
+constexpr int FB_WG_GRID = 64;  // workgroups of the big-N E-step (each owns a 2 N^2-word table of the scratch)
+
+i64 fb_scratch_words(int N) { return N > WAVE_N ? (i64)FB_WG_GRID * 2 * N * N : 0; }
+
 void launch_score(const ModelDev* models, int K, int maxN, const unsigned short* sym, const i64* offs, int S, double* mant,
                   i64* exp2, int* status, hipStream_t st)
 {
@@ -324,6 +523,15 @@ void launch_score(const ModelDev* models, int K, int maxN, const unsigned short*
     // grid.y carries the models: at most 65535 per launch (HIP's limit for that dimension), more in further launches
     for (int k0 = 0; k0 < K; k0 += 65535) {
         const int kn = K - k0 < 65535 ? K - k0 : 65535;
+        if (maxN > WAVE_N) {  // some model has more states than a wave has lanes: a workgroup per pair, for all of them
+            for (int s0 = 0; s0 < S; s0 += 1 << 20) {  // (grid.x is ample, but keep launches bounded)
+                const int sn = S - s0 < (1 << 20) ? S - s0 : (1 << 20);
+                hipLaunchKernelGGL(k_hmm_score_wg, dim3((unsigned)sn, (unsigned)kn), dim3((unsigned)((maxN + 63) & ~63)),
+                                   (size_t)2 * maxN * 8, st, models, K, k0, sym, offs + s0, sn, mant + (size_t)s0 * K,
+                                   exp2 + (size_t)s0 * K, status + (size_t)s0 * K);
+            }
+            continue;
+        }
         const dim3 grid((unsigned)((S + SCORE_WAVES - 1) / SCORE_WAVES), (unsigned)kn);
         hipLaunchKernelGGL(k_hmm_score, grid, dim3(64 * SCORE_WAVES), (size_t)maxN * maxN * 8, st, models, K, k0, sym, offs, S,
                            mant, exp2, status);
@@ -331,9 +539,15 @@ void launch_score(const ModelDev* models, int K, int maxN, const unsigned short*
 }
 
 void launch_fb(const ModelDev& md, const unsigned short* sym, const i64* offs, int S, double* alpha_buf, double* c_buf,
-               i64* acc, double* mant, i64* exp2, int* status, hipStream_t st)
+               i64* acc, double* mant, i64* exp2, int* status, hipStream_t st, i64* scratch)
 {
     if (S < 1) return;
+    if (md.N > WAVE_N) {
+        const int grid = S < FB_WG_GRID ? S : FB_WG_GRID;
+        hipLaunchKernelGGL(k_hmm_fb_wg, dim3((unsigned)grid), dim3((unsigned)((md.N + 63) & ~63)), (size_t)2 * md.N * 8, st, md,
+                           sym, offs, S, alpha_buf, c_buf, acc, mant, exp2, status, scratch);
+        return;
+    }
     const size_t lds = (size_t)md.N * md.N * (2 * 8 + 16);  // A, A^T, and the workgroup's AN limb table: 128 KB at N = 64
     // (a refusal shows up as a launch failure below, which the caller's hipGetLastError reports; say why here)
     if (hipFuncSetAttribute((const void*)k_hmm_fb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -348,7 +562,7 @@ void launch_reestimate(int N, int M, const i64* acc, double epsilon, double* pi,
 {
     const i64 total = (i64)N + (i64)N * N + (i64)N * M;
     hipLaunchKernelGGL(k_hmm_reestimate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, N, M, acc, pi, A, B);
-    if (epsilon > 0.0) hipLaunchKernelGGL(k_hmm_adjustb, dim3(1), dim3(64), 0, st, N, M, epsilon, B);
+    if (epsilon > 0.0) hipLaunchKernelGGL(k_hmm_adjustb, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, N, M, epsilon, B);
 }
 
 }  // namespace e2hmm

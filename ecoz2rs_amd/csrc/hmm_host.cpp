@@ -344,7 +344,7 @@ struct Trainer {
     i64 total;
     hipStream_t st;
     DevBuf<double> d_params, d_alpha, d_c, d_mant;
-    DevBuf<i64> d_acc, d_exp;
+    DevBuf<i64> d_acc, d_exp, d_scratch;
     DevBuf<int> d_status;
     std::vector<double> mant;
     std::vector<i64> ex;
@@ -367,6 +367,7 @@ struct Trainer {
         if (d_alpha.alloc((size_t)total * N) || d_c.alloc((size_t)total) || d_acc.alloc((size_t)W) || d_mant.alloc((size_t)S) ||
             d_exp.alloc((size_t)S) || d_status.alloc((size_t)S))
             return 1;
+        if (e2hmm::fb_scratch_words(N) > 0 && d_scratch.alloc((size_t)e2hmm::fb_scratch_words(N))) return 1;
         mant.resize((size_t)S);
         ex.resize((size_t)S);
         stat.resize((size_t)S);
@@ -377,7 +378,7 @@ struct Trainer {
     int estep_counts(const unsigned short* d_sym, const i64* d_offs, std::vector<i64>* acc_out = nullptr)
     {
         HIPCHK(hipMemsetAsync(d_acc.p, 0, (size_t)W * 8, st));
-        e2hmm::launch_fb(md, d_sym, d_offs, S, d_alpha.p, d_c.p, d_acc.p, d_mant.p, d_exp.p, d_status.p, st);
+        e2hmm::launch_fb(md, d_sym, d_offs, S, d_alpha.p, d_c.p, d_acc.p, d_mant.p, d_exp.p, d_status.p, st, d_scratch.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(mant.data(), d_mant.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(ex.data(), d_exp.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));

@@ -85,7 +85,8 @@ typedef void (*ecoz2_hmm_learn_callback_t)(char *variable, double value);
  * sum ln P drops to val_auto or max_iterations (>= 0) E+M steps ran.  hmm_epsilon > 0 floors B and renormalises.
  * Writes data/hmms/N<N>__M<M>_t<type>__a<val_auto>[_I<max>]/<class>.hmm (+ .csv with the measure per iteration).
  * use_par is accepted and ignored.
- * Limits: 1 <= N <= 64 (one lane of a wavefront per state; the reference's -N is free: larger N fail with a message).
+ * Limits: 1 <= N <= 512 (up to 64 states one lane of a wavefront per state, beyond a workgroup per sequence with a thread
+ * per state -- same arithmetic, slower; the reference's -N is free: larger N fail with a message).
  * An empty sequence is skipped by the training (no counts, not in the pi denominator) and scores P = 1 in classify.
  * ECOZ2_VQ_GPUS = W: the sequences are dealt to W workers (devices ECOZ2_VQ_DEVICE + w modulo the device count); the
  * exact int64 expected counts are summed over the workers each E-step, so the model is the single worker's bit for
@@ -118,7 +119,7 @@ int ecoz2_hmm_show(const char *hmm_filename, const char *format);
 
 /* ---- array-level entry points over the same kernels (tests, Python mirror) ---------------------------------- */
 /* initial model of `hmm learn -t`: 0 random, 1 uniform, 2 cascade-2, 3 cascade-3 (random B); uses the generator
- * seeded by ecoz2_set_random_seed.  pi[N], A[N*N], B[N*M]; N <= 64. */
+ * seeded by ecoz2_set_random_seed.  pi[N], A[N*N], B[N*M]; N <= 512. */
 int e2vq_hmm_init(int N, int M, int model_type, double *pi, double *A, double *B);
 int e2vq_hmm_save(const char *path, const char *class_name, int N, int M, const double *pi, const double *A,
                   const double *B);

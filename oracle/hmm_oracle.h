@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define E2H_MAX_N 64
+#define E2H_MAX_N 512
 #define E2H_MAX_ESTEPS 1000 /* safety cap (val_auto <= 0 with no iteration limit would never stop) */
 #define E2H_ACC_SHIFT 29 /* accumulated quantities are < 2: x ~= (hi*2^31 + lo) * 2^-(29+31) */
 

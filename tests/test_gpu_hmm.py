@@ -25,7 +25,8 @@ def _ragged(rng, M, lens):
     return [rng.integers(0, M, n).astype(np.uint16) for n in lens]
 
 
-@pytest.mark.parametrize("N,M,typ", [(1, 8, 0), (2, 16, 0), (5, 256, 3), (5, 1024, 2), (17, 64, 0), (64, 128, 3), (64, 32, 0)])
+@pytest.mark.parametrize("N,M,typ", [(1, 8, 0), (2, 16, 0), (5, 256, 3), (5, 1024, 2), (17, 64, 0), (64, 128, 3), (64, 32, 0),
+                                     (65, 32, 0), (100, 64, 3), (130, 16, 2), (257, 8, 0)])  # > 64 states: a workgroup per sequence
 def test_score_bit_exact(H, N, M, typ):
     """scaled forward pass: P(O) = mant * 2^exp2 of every (sequence, model) pair equals the oracle's, word for word"""
     H.seed(100 + N)
@@ -53,7 +54,8 @@ def test_score_status_codes(H):
     assert got["log_prob"][0, 0] == -np.inf and got["log_prob"][2, 0] == -np.inf and np.isfinite(got["log_prob"][1, 0])
 
 
-@pytest.mark.parametrize("N,M,typ", [(1, 8, 0), (3, 16, 3), (5, 64, 3), (5, 1024, 2), (16, 32, 0), (64, 16, 3)])
+@pytest.mark.parametrize("N,M,typ", [(1, 8, 0), (3, 16, 3), (5, 64, 3), (5, 1024, 2), (16, 32, 0), (64, 16, 3), (65, 16, 0), (96, 32, 3),
+                                     (130, 8, 2)])
 def test_estep_accumulators_bit_exact(H, N, M, typ):
     """Baum-Welch E-step: the exact fixed-point expected counts (PI, AN, AD, BN, BD, used / skipped) equal the oracle's"""
     H.seed(200 + N)
@@ -74,7 +76,7 @@ def test_estep_accumulators_bit_exact(H, N, M, typ):
 
 
 @pytest.mark.parametrize("N,M,typ,eps,auto,maxit", [(5, 32, 3, 1e-5, 0.3, -1), (3, 16, 0, 0.0, 0.05, -1), (8, 64, 2, 1e-4, 0.0, 6),
-                                                     (64, 16, 3, 1e-5, 0.3, 3)])
+                                                     (64, 16, 3, 1e-5, 0.3, 3), (80, 16, 3, 1e-5, 0.3, 3), (70, 8, 0, 0.0, 0.05, 2)])
 def test_training_bit_exact(H, N, M, typ, eps, auto, maxit):
     """whole Baum-Welch (E-steps, M-steps, epsilon restriction, stopping rule): parameters and the measure per
     iteration equal the oracle's bit for bit"""

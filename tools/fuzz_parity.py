@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle parity fuzz (bit-exact): random T, M, P, codebooks; one pass + update + quantize each.
 usage: tools/fuzz_parity.py [n_cases] [seed] [pre|hmm]
-`hmm`: the HMM kernels -- random N (1..64), M, model type, ragged / empty / impossible sequences: scores, E-step
+`hmm`: the HMM kernels -- random N (1..97: beyond 64 the workgroup-per-sequence kernels), M, model type, ragged / empty / impossible sequences: scores, E-step
 accumulator words and whole trainings against the oracle.
 `pre`: aim at the prefiltered sweep -- P from 12, 16, ..., 40 (mostly 36), M a multiple of 32 in 64..2048 (prefilter forced from M = 64), frames
 rescaled / zeroed / sign-flipped at random, duplicated and twinned codewords, three passes with updates in between
@@ -161,7 +161,7 @@ def fuzz_hmm(n, rng):
     H = oracle_lib.load_hmm()
     bad, t0, steps = 0, time.time(), 0
     for case in range(n):
-        N = int(rng.choice([1, 2, 3, 5, 5, 8, 16, 17, 33, 64]))
+        N = int(rng.choice([1, 2, 3, 5, 5, 8, 16, 17, 33, 64, 65, 97]))
         M = int(rng.choice([2, 8, 64, 256, 1024]))
         typ = int(rng.integers(0, 4))
         seed = int(rng.integers(0, 1 << 30))
