@@ -280,3 +280,9 @@ def test_hmm_cli_end_to_end(tmp_path):
     assert out2.split("Confusion matrix:")[1] == out.split("Confusion matrix:")[1].split("c12n.csv saved")[0]
     out = run("hmm", "show", "--hmm", "data/hmms/N4__M32_t3__a0.3_I8/C01.hmm")
     assert "className='C01', N=4, M=32" in out and out.count(" [3]: ") == 2
+    # more states than a wavefront has lanes (the reference's -N is free): same flags, the workgroup-per-sequence kernels
+    for cls in classes:
+        out = run("hmm", "learn", "-N", "70", "-M", "32", "-s", "3", "-I", "2", "--class-name", cls, "--sequences", "tt.csv")
+        assert f"class '{cls}'  N=70 M=32 type=3" in out
+    out = run("hmm", "classify", "--models", "data/hmms/N70__M32_t3__a0.3_I2", "--tt", "TEST", "-M", "32", "--sequences", "tt.csv")
+    assert "number of HMM models: 3  number of sequences: 9" in out and "Confusion matrix:" in out
