@@ -1597,6 +1597,76 @@ struct PrdSet {
     i64 T = 0;
 };
 
+// Pinned staging buffers cost page pinning both ways: ~0.2 ms per MB to make, ~0.13 ms per MB to release
+// (tools/probe/alloc_cost.hip: 2 x 78 MB = 27-35 ms + 19-22 ms -- a fifth of a warm ecoz2_vq_learn over 10 M frames, a third
+// of an ecoz2_vq_quantize).  The process keeps them for its next call instead: up to ECOZ2_VQ_PINNED_KEEP_MB (default 512; 0 =
+// allocate and free every time) stay in this pool, portable across devices; whatever is pooled when the process ends is left to
+// the operating system (the HIP runtime may already be gone when static destructors run).
+namespace {
+struct PinnedPool {
+    struct Buf {
+        void* p;
+        size_t bytes;
+    };
+    std::mutex m;
+    std::vector<Buf> idle;
+    size_t kept = 0;
+    static size_t cap()
+    {
+        static const size_t c = (size_t)(getenv("ECOZ2_VQ_PINNED_KEEP_MB") ? std::max(0, atoi(getenv("ECOZ2_VQ_PINNED_KEEP_MB"))) : 512) << 20;
+        return c;
+    }
+    // a buffer of at least `bytes` (an idle one no larger than twice that, else a new one); null on failure
+    void* acquire(size_t bytes, size_t* got)
+    {
+        // sizes in steps of 32 MB (1 MB below 16 MB): the staging buffers of learn, quantize and classify differ by a few
+        // per cent and should be able to stand in for each other
+        const size_t step = bytes >= ((size_t)16 << 20) ? (size_t)32 << 20 : (size_t)1 << 20;
+        bytes = (bytes + step - 1) / step * step;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            int best = -1;
+            for (int i = 0; i < (int)idle.size(); ++i)
+                if (idle[(size_t)i].bytes >= bytes && idle[(size_t)i].bytes <= 2 * bytes &&
+                    (best < 0 || idle[(size_t)i].bytes < idle[(size_t)best].bytes))
+                    best = i;
+            if (best >= 0) {
+                const Buf b = idle[(size_t)best];
+                idle.erase(idle.begin() + best);
+                kept -= b.bytes;
+                *got = b.bytes;
+                return b.p;
+            }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        *got = bytes;
+        return p;
+    }
+    void release(void* p, size_t bytes)
+    {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (kept + bytes <= cap()) {
+                idle.push_back(Buf{p, bytes});
+                kept += bytes;
+                return;
+            }
+        }
+        (void)hipHostFree(p);
+    }
+};
+PinnedPool& pinned_pool()
+{
+    static PinnedPool* pool = new PinnedPool();  // (never destroyed: see above)
+    return *pool;
+}
+}  // namespace
+
 static int scan_predictors(const char* const* files, int n, int P_expected, PrdSet& ps)
 {
     ps.files = files;
@@ -1630,13 +1700,15 @@ static int upload_predictors(e2vq_session* s, const PrdSet& ps, i64 lo, i64 hi)
     struct Res {
         double* d = nullptr;
         double* h[2] = {nullptr, nullptr};
+        size_t hb[2] = {0, 0};
         hipEvent_t ev[2] = {nullptr, nullptr};
         hipStream_t st = nullptr;
         ~Res()
         {
+            if (st) (void)hipStreamSynchronize(st);  // (no copy still reads a staging buffer that goes back to the pool)
             if (d) (void)hipFree(d);
             for (int k = 0; k < 2; ++k) {
-                if (h[k]) (void)hipHostFree(h[k]);
+                pinned_pool().release(h[k], hb[k]);
                 if (ev[k]) (void)hipEventDestroy(ev[k]);
             }
             if (st) (void)hipStreamDestroy(st);
@@ -1655,7 +1727,8 @@ static int upload_predictors(e2vq_session* s, const PrdSet& ps, i64 lo, i64 hi)
     HIPCHK(hipMalloc(&r.d, (size_t)T * NC * 8));
     HIPCHK(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k) {
-        HIPCHK(hipHostMalloc(&r.h[k], (size_t)CH * NC * 8, hipHostMallocDefault));
+        r.h[k] = (double*)pinned_pool().acquire((size_t)CH * NC * 8, &r.hb[k]);
+        if (!r.h[k]) return e2vq_set_error("no pinned memory for the upload staging (%zu bytes)", (size_t)CH * NC * 8);
         HIPCHK(hipEventCreateWithFlags(&r.ev[k], hipEventDisableTiming));
     }
     lap("allocations");
@@ -1986,7 +2059,8 @@ int quantize_worker(int device, QShared& sh, const double* refl)
     // one pinned and one device allocation, carved into the two slots (frames | distortions | symbols, 256-byte aligned)
     const size_t fb = ((size_t)sh.chunk * NC * 8 + 255) & ~(size_t)255, db = ((size_t)sh.chunk * 8 + 255) & ~(size_t)255,
                  sb = ((size_t)sh.chunk * 2 + 64 + 255) & ~(size_t)255, slot_bytes = fb + db + sb;
-    if (!rc && hipHostMalloc((void**)&h_block, 2 * slot_bytes, hipHostMallocDefault) != hipSuccess)
+    size_t h_block_bytes = 0;
+    if (!rc && !(h_block = (char*)pinned_pool().acquire(2 * slot_bytes, &h_block_bytes)))
         rc = e2vq_set_error("no pinned memory for the quantize staging (%zu bytes)", 2 * slot_bytes);
     if (!rc && hipMalloc((void**)&d_block, 2 * slot_bytes) != hipSuccess)
         rc = e2vq_set_error("no device memory for the quantize staging (%zu bytes)", 2 * slot_bytes);
@@ -2060,7 +2134,7 @@ int quantize_worker(int device, QShared& sh, const double* refl)
     const double t_work = now();
     for (QSlot& q : slots)
         if (q.done) (void)hipEventDestroy(q.done);
-    if (h_block) (void)hipHostFree(h_block);
+    pinned_pool().release(h_block, h_block_bytes);  // (the stream was synchronised above)
     if (d_block) (void)hipFree(d_block);
     e2vq_session_destroy(s);
     if (st) (void)hipStreamDestroy(st);
@@ -2234,8 +2308,9 @@ extern "C" int ecoz2_vq_classify(const char* const* cb_filenames, int num_codebo
     unsigned short* d_sym = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = e2vq_set_error("stream creation failed");
     if (!rc) rc = e2vq_set_stream(s, (void*)st);
-    if (!rc && (hipHostMalloc((void**)&h_frames, (size_t)chunk * NC * 8, hipHostMallocDefault) != hipSuccess ||
-                hipHostMalloc((void**)&h_dmin, (size_t)chunk * 8, hipHostMallocDefault) != hipSuccess ||
+    size_t h_frames_bytes = 0, h_dmin_bytes = 0;
+    if (!rc && (!(h_frames = (double*)pinned_pool().acquire((size_t)chunk * NC * 8, &h_frames_bytes)) ||
+                !(h_dmin = (double*)pinned_pool().acquire((size_t)chunk * 8, &h_dmin_bytes)) ||
                 hipMalloc((void**)&d_frames, (size_t)chunk * NC * 8) != hipSuccess || hipMalloc((void**)&d_dmin, (size_t)chunk * 8) != hipSuccess ||
                 hipMalloc((void**)&d_sym, (size_t)chunk * 2 + 64) != hipSuccess))
         rc = e2vq_set_error("no memory for the classify staging (%lld frames per unit)", (long long)chunk);
@@ -2267,8 +2342,8 @@ extern "C" int ecoz2_vq_classify(const char* const* cb_filenames, int num_codebo
         }
     }
     if (st) (void)hipStreamSynchronize(st);
-    if (h_frames) (void)hipHostFree(h_frames);
-    if (h_dmin) (void)hipHostFree(h_dmin);
+    pinned_pool().release(h_frames, h_frames_bytes);
+    pinned_pool().release(h_dmin, h_dmin_bytes);
     if (d_frames) (void)hipFree(d_frames);
     if (d_dmin) (void)hipFree(d_dmin);
     if (d_sym) (void)hipFree(d_sym);

@@ -102,6 +102,8 @@ int ecoz2_prd_show_file(const char *prd_filename, int show_reflections, int from
  *   ECOZ2_VQ_FAMILY             0 = the first pass of every level accumulates in full (default 1: from M = 512
  *                               -- ECOZ2_VQ_FAMILY_MIN_M -- it is seeded with the parents' sums; same rows bit for bit)
  *   ECOZ2_VQ_PRE_LDS            0 = accumulating prefiltered passes on the round-2 kernel (A/B; same results)
+ *   ECOZ2_VQ_PINNED_KEEP_MB     pinned staging buffers kept for the next call of the process (default 512 MB; 0 = none:
+ *                               making and releasing them costs ~50 ms of every learn / quantize call)
  *   ECOZ2_VQ_SMALL_REGS         0 = passes at M <= 16 on the LDS-table kernel instead of k_pass_small (A/B; same results)
  *   ECOZ2_VQ_SMALL_FLUSH_MASK   k_pass_small flushes its register sums every (mask + 1) blocks of a wave (default 65535;
  *                               0 in the tests: after every block)
