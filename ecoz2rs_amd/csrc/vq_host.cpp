@@ -381,8 +381,12 @@ static int reduce(e2vq_session* s, void* buf, i64 count, int op)
 
 // ---- training set ------------------------------------------------------------------------
 
-extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames, int64_t T)
+// adopt (optional): the caller's buffer holds at least ((T + 63) / 64) * 64 rows and may be kept -- when the session wants a
+// row-major copy of its own (the LDS-staged prefiltered pass), it takes the buffer as that copy instead of making one (3 GB less
+// to allocate, touch and copy for 10 M frames) and sets *adopt; the caller then must not free it.
+static int set_frames_device_impl(e2vq_session* s, const void* device_frames, int64_t T, bool* adopt)
 {
+    if (adopt) *adopt = false;
     if (T < 1) return e2vq_set_error("empty training set");
     // frame indices travel as 32-bit ints in the fallback lists / block tables of the kernels
     if (T > (int64_t)INT32_MAX - 64) return e2vq_set_error("%lld frames exceed the per-session limit of 2^31 - 65", (long long)T);
@@ -432,7 +436,12 @@ extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames
         // per frame; without it the pass keeps to the round-2 kernel, which reads the blocked layout)
         if (fits && e2vq::prefilter_lds_stage(s->NC)) {
             const size_t rows = (size_t)s->nblocks * 64, have = (size_t)T;
-            if (hipMalloc(&s->d_aos, rows * s->NC * 8) == hipSuccess) {
+            if (adopt) {
+                s->d_aos = (double*)const_cast<void*>(device_frames);
+                *adopt = true;
+                if (rows > have) HIPCHK(hipMemsetAsync(s->d_aos + have * s->NC, 0, (rows - have) * s->NC * 8, s->stream));
+                HIPCHK(hipMemsetAsync(s->d_fg, 0, (size_t)s->nblocks * 64 * sizeof(float), s->stream));
+            } else if (hipMalloc(&s->d_aos, rows * s->NC * 8) == hipSuccess) {
                 HIPCHK(hipMemcpyAsync(s->d_aos, device_frames, have * s->NC * 8, hipMemcpyDeviceToDevice, s->stream));
                 if (rows > have) HIPCHK(hipMemsetAsync(s->d_aos + have * s->NC, 0, (rows - have) * s->NC * 8, s->stream));
                 HIPCHK(hipMemsetAsync(s->d_fg, 0, (size_t)s->nblocks * 64 * sizeof(float), s->stream));
@@ -460,6 +469,11 @@ extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames
     // (or have written it on this stream).  They are complete when this returns, so the buffer may be reused or freed.
     HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
+}
+
+extern "C" int e2vq_set_frames_device(e2vq_session* s, const void* device_frames, int64_t T)
+{
+    return set_frames_device_impl(s, device_frames, T, nullptr);
 }
 
 extern "C" int e2vq_set_frames_host(e2vq_session* s, const double* frames, int64_t T)
@@ -1724,7 +1738,7 @@ static int upload_predictors(e2vq_session* s, const PrdSet& ps, i64 lo, i64 hi)
         tl = t1;
     };
     const i64 CH = std::min<i64>(T, 1 << 18);  // 78 MB of predictor vectors per chunk at P = 36
-    HIPCHK(hipMalloc(&r.d, (size_t)T * NC * 8));
+    HIPCHK(hipMalloc(&r.d, (size_t)((T + 63) / 64 * 64) * NC * 8));  // (whole blocks: the session may keep the buffer)
     HIPCHK(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k) {
         r.h[k] = (double*)pinned_pool().acquire((size_t)CH * NC * 8, &r.hb[k]);
@@ -1751,7 +1765,9 @@ static int upload_predictors(e2vq_session* s, const PrdSet& ps, i64 lo, i64 hi)
     }
     HIPCHK(hipStreamSynchronize(r.st));
     lap("read + H2D");
-    const int rc = e2vq_set_frames_device(s, r.d, T);  // (synchronises: the row-major copy can go)
+    bool adopted = false;
+    const int rc = set_frames_device_impl(s, r.d, T, &adopted);  // (synchronises: the row-major copy can go, unless the session kept it)
+    if (adopted) r.d = nullptr;
     lap("re-layout + images");
     return rc;
 }
