@@ -108,7 +108,7 @@ def test_product_generator_and_files_equal_the_oracle(H, typ, tmp_path):
     with pytest.raises(e.Ecoz2Error, match="Not an HMM model"):
         e.hmm.load_model(tmp_path / "bad.hmm")
     with pytest.raises(e.Ecoz2Error):
-        e.hmm.init_model(65, 8, 1)  # one wavefront lane per state: N <= 64
+        e.hmm.init_model(513, 8, 1)  # N <= 512 (up to 64 a lane per state, beyond a thread of a workgroup)
     assert e.hmm.set_random_seed(-1) > 1_600_000_000  # negative: time based (src/hmm/mod.rs:73-76)
 
 
