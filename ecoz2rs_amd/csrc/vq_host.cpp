@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <errno.h>
 #include <float.h>
 #include <math.h>
 #include <stdarg.h>
@@ -189,6 +190,7 @@ struct e2vq_session {
         unsigned short* cells = nullptr;
         int cap_M = 0;
         i64 cap_T = 0;
+        i64 nblocks = 0;  // of the training set the rows and cells were saved for
     } sv;
     // collective hook
     e2vq_allreduce_fn allreduce = nullptr;
@@ -402,6 +404,7 @@ static int set_frames_device_impl(e2vq_session* s, const void* device_frames, in
     s->maxabs_scanned = false;
     s->T = 0;
     s->nblocks = 0;
+    s->sv.valid = false;  // (rows and cells of a saved point describe the frames that are going away)
     HIPCHK(hipStreamSynchronize(s->stream));  // no kernel of this session still reads the old blocks
     if (s->d_blk) HIPCHK(hipFree(s->d_blk));
     s->d_blk = nullptr;
@@ -509,6 +512,9 @@ extern "C" int e2vq_prepare(e2vq_session* s)
     const i64 Tl = s->T;
     HIPCHK(hipMemcpyAsync(s->d_stats + 2 * s->NC + 2, &Tl, 8, hipMemcpyHostToDevice, s->stream));
     if (reduce(s, s->d_stats, 2 * s->NC + 3, 0)) return 1;
+    // every rank learns of bad data in ANY shard (the two status words as one unsigned 64-bit maximum): all of them stop
+    // here together instead of one rank leaving the others to a collective it will never join
+    if (reduce(s, s->d_flags, 1, 1)) return 1;
     e2vq::launch_finish_q(s->d_stats, s->NC, s->d_sc, s->stream);
     int flags[2];
     i64 Ttot = 0;
@@ -853,21 +859,20 @@ extern "C" int e2vq_last_pass_kernel_ms(e2vq_session* s, float* ms)
     return 0;
 }
 
-// Waits until the device has stored the current sequence number at *word (host-mapped memory; microseconds).  Safety
-// nets: the event recorded behind the kernel (a kernel that has finished without storing the number: fall back to a
-// stream synchronisation, then fail), a wall-clock limit, and the word the publishing workgroup raises when one of the
-// flags it polls never arrived (its own spin is bounded, so the kernel always ends).
+// Waits until the device has stored the current sequence number at *word (host-mapped memory; microseconds once the
+// kernel runs).  No wall-clock limit: the wait also covers the sweep kernel queued ahead, which may legitimately take
+// minutes (2^31 frames, generic prediction orders, ranks sharing a device).  What ends the wait without the number is the
+// event recorded behind the kernel (a kernel that has finished without storing it: stream synchronisation, then an error)
+// or a failed query; the publishing workgroup's own spin is bounded, so the kernel always ends, and the word it raises
+// when a flag never arrived becomes an error here.
 static int spin_for_sequence(e2vq_session* s, volatile u64* word, const char* what)
 {
-    const auto t0 = std::chrono::steady_clock::now();
     for (unsigned long spins = 0; *word != s->stats_seq; ++spins) {
         if ((spins & 0xfff) == 0xfff) {
             const hipError_t q = hipEventQuery(s->ev_stats);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) return e2vq_set_error("%s failed: %s", what, hipGetErrorString(q));
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
-                return e2vq_set_error("%s: no statistics after 30 s (sequence %llu, device reports %llu)", what,
-                                      (unsigned long long)s->stats_seq, (unsigned long long)*word);
+            (void)hipGetLastError();  // (hipErrorNotReady is sticky for hipGetLastError: nobody downstream should see it)
         }
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -1140,6 +1145,7 @@ extern "C" int e2vq_save_state(e2vq_session* s)
         HIPCHK(hipMemcpyAsync(v.rows_local, s->d_rows_local, (size_t)s->M * s->RS * 8, hipMemcpyDeviceToDevice, s->stream));
     if (s->d_prev_sym) HIPCHK(hipMemcpyAsync(v.cells, s->d_prev_sym, (size_t)s->nblocks * 64 * 2, hipMemcpyDeviceToDevice, s->stream));
     v.M = s->M;
+    v.nblocks = s->nblocks;
     v.cells_M = s->cells_M;
     v.incr_M = s->incr_M;
     v.DDprv = s->DDprv;
@@ -1155,6 +1161,7 @@ extern "C" int e2vq_restore_state(e2vq_session* s)
 {
     auto& v = s->sv;
     if (!v.valid) return e2vq_set_error("no saved state");
+    if (v.nblocks != s->nblocks) return e2vq_set_error("the saved state belongs to another training set");
     HIPCHK(hipSetDevice(s->device));
     if (ensure_codebook_capacity(s, v.M)) return 1;
     HIPCHK(hipMemcpyAsync(s->d_refl, v.refl, (size_t)v.M * s->NC * 8, hipMemcpyDeviceToDevice, s->stream));
@@ -1460,12 +1467,21 @@ struct LocalGroup {
     }
     // first failing rank's message (g_err is thread-local: the workers' text would be lost with their threads)
     std::string first_error;
+    // run once, by the first rank that fails: with RCCL it aborts every communicator of the group, so that a collective
+    // some ranks have already enqueued -- and that the failed rank will never join -- ends instead of hanging their streams
+    void (*on_fail)(void*) = nullptr;
+    void* on_fail_arg = nullptr;
     void fail()
     {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!failed) first_error = g_err;
-        failed = true;
-        cv.notify_all();
+        bool first = false;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            first = !failed;
+            if (first) first_error = g_err;
+            failed = true;
+            cv.notify_all();
+        }
+        if (first && on_fail) on_fail(on_fail_arg);
     }
 };
 
@@ -1518,12 +1534,14 @@ struct Rccl {
     typedef int (*comm_init_all_t)(void**, int, const int*);
     typedef int (*all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
     typedef int (*comm_destroy_t)(void*);
+    typedef int (*comm_abort_t)(void*);
     typedef const char* (*error_string_t)(int);
     void* handle = nullptr;
     get_version_t get_version = nullptr;
     comm_init_all_t comm_init_all = nullptr;
     all_reduce_t all_reduce = nullptr;
     comm_destroy_t comm_destroy = nullptr;
+    comm_abort_t comm_abort = nullptr;  // (optional)
     error_string_t error_string = nullptr;
     std::string why;  // why it could not be loaded
     enum { Int64 = 4, Uint64 = 5, Sum = 0, Max = 2 };  // ncclDataType_t / ncclRedOp_t values of rccl.h (stable ABI)
@@ -1549,6 +1567,7 @@ Rccl* rccl_api()
         r.comm_init_all = (Rccl::comm_init_all_t)dlsym(r.handle, "ncclCommInitAll");
         r.all_reduce = (Rccl::all_reduce_t)dlsym(r.handle, "ncclAllReduce");
         r.comm_destroy = (Rccl::comm_destroy_t)dlsym(r.handle, "ncclCommDestroy");
+        r.comm_abort = (Rccl::comm_abort_t)dlsym(r.handle, "ncclCommAbort");
         r.error_string = (Rccl::error_string_t)dlsym(r.handle, "ncclGetErrorString");
         if (!r.comm_init_all || !r.all_reduce || !r.comm_destroy) {
             r.why = "librccl.so lacks ncclCommInitAll / ncclAllReduce / ncclCommDestroy";
@@ -1566,12 +1585,40 @@ struct RcclRank {
     long calls = 0, bytes = 0;
 };
 
+// the communicators of an in-process group; abort() is the group's on_fail hook
+struct RcclComms {
+    std::vector<void*> comms;
+    std::mutex mu;
+    bool aborted = false;
+    static void abort_all(void* self_)
+    {
+        RcclComms* self = (RcclComms*)self_;
+        Rccl* api = rccl_api();
+        std::lock_guard<std::mutex> lk(self->mu);
+        if (self->aborted || !api || !api->comm_abort) return;
+        self->aborted = true;  // (ncclCommAbort releases the communicator: no ncclCommDestroy afterwards)
+        for (void*& c : self->comms)
+            if (c) {
+                (void)api->comm_abort(c);
+                c = nullptr;
+            }
+    }
+};
+
 int rccl_allreduce(void* user, void* buf, int64_t count, int op, void* stream_)
 {
     RcclRank* rr = (RcclRank*)user;
     Rccl* api = rccl_api();
     if (!api) return e2vq_set_error("RCCL is not loaded");
-    if (hipSetDevice(rr->device) != hipSuccess) return e2vq_set_error("hipSetDevice(%d) failed", rr->device);
+    if (hipSetDevice(rr->device) != hipSuccess) {
+        e2vq_set_error("hipSetDevice(%d) failed", rr->device);
+        rr->g->fail();
+        return 1;
+    }
+    // Host rendezvous: every rank of the group is alive and about to enqueue this collective.  ncclAllReduce itself only
+    // enqueues; without the rendezvous a rank that failed earlier (a read error, bad data in its shard, no memory) would
+    // leave the others with a collective that never completes -- blocked in the next stream synchronisation for good.
+    if (!rr->g->barrier()) return e2vq_set_error("in-process group: another rank failed");
     (void)hipGetLastError();  // (see ncclCommInitAll below: hipErrorNotReady of a polled event must not reach RCCL)
     const int rc = api->all_reduce(buf, buf, (size_t)count, op == 0 ? Rccl::Int64 : Rccl::Uint64, op == 0 ? Rccl::Sum : Rccl::Max,
                                    rr->comm, (hipStream_t)stream_);
@@ -1846,21 +1893,24 @@ static int learn_common(int P, double eps, const char* class_name, const double*
     g.n = world;
     g.ev_ready.assign((size_t)world, nullptr);
     g.ev_done.assign((size_t)world, nullptr);
-    std::vector<void*> comms;  // RCCL communicators, one per rank
+    RcclComms rc_comms;  // RCCL communicators, one per rank
+    std::vector<void*>& comms = rc_comms.comms;
     struct GroupCleanup {  // events and communicators are released on every return path
         LocalGroup& g;
-        std::vector<void*>& comms;
+        RcclComms& rc;
         ~GroupCleanup()
         {
             for (hipEvent_t ev : g.ev_ready)
                 if (ev) (void)hipEventDestroy(ev);
             for (hipEvent_t ev : g.ev_done)
                 if (ev) (void)hipEventDestroy(ev);
-            if (Rccl* api = comms.empty() ? nullptr : rccl_api())
-                for (void* c : comms)
+            if (g.failed) RcclComms::abort_all(&rc);  // (a failed group may hold a collective that cannot complete)
+            std::lock_guard<std::mutex> lk(rc.mu);
+            if (Rccl* api = rc.comms.empty() ? nullptr : rccl_api())
+                for (void* c : rc.comms)
                     if (c) (void)api->comm_destroy(c);
         }
-    } cleanup{g, comms};
+    } cleanup{g, rc_comms};
     std::vector<LocalRank> ranks((size_t)world);
     std::vector<int> devs((size_t)world);
     bool distinct = world <= ndev;
@@ -1892,6 +1942,8 @@ static int learn_common(int P, double eps, const char* class_name, const double*
         if (api->get_version) (void)api->get_version(&ver);
         printf("collective: RCCL %d.%d.%d, ncclAllReduce(int64 sum) per LBG iteration over %d rank(s)\n", ver / 10000, (ver / 100) % 100,
                ver % 100, world);
+        g.on_fail = RcclComms::abort_all;
+        g.on_fail_arg = &rc_comms;
         for (int r = 0; r < world; ++r) {
             rranks[r] = RcclRank{&g, comms[r], r, devs[r]};
             ctx[r] = RankCtx{&g, r, rccl_allreduce, &rranks[r], world == 1};
@@ -2003,6 +2055,7 @@ struct QFileResult {
     i64 T = 0;
     double e = 0.0;  // sum over the file's frames of (dmin - 1), frame order
     std::string cls, seq_path;
+    std::string tmp_path;  // split files are written piecewise to <seq_path>.tmp and renamed once every range is stored
     // split files: chunks fold into `e` in frame order whatever order the workers finish them in
     std::mutex mu;
     i64 next_t = 0;
@@ -2105,7 +2158,7 @@ int quantize_worker(int device, QShared& sh, const double* refl)
                 if (e2vq_seq_write(r.seq_path.c_str(), r.cls.c_str(), sh.M, q.h_sym + g.off, g.n)) return 1;
             } else {
                 quantize_fold(r, g.t0, q.h_dmin + g.off, g.n);
-                if (e2vq_io::seq_write_range(r.seq_path.c_str(), g.t0, q.h_sym + g.off, g.n)) return 1;
+                if (e2vq_io::seq_write_range(r.tmp_path.c_str(), g.t0, q.h_sym + g.off, g.n)) return 1;
             }
         }
         return 0;
@@ -2210,7 +2263,14 @@ extern "C" int ecoz2_vq_quantize(const char* nom_raas, const char* const* predic
                 cur.n += T;
             } else {  // longer than a chunk: units of its own, any worker takes them; the .seq is written piecewise
                 flush();
-                if (e2vq_io::seq_create(path, cls, M, T)) return 1;
+                // (not at the final path: a run that fails later must not leave a well-formed .seq of zeros behind, nor
+                // overwrite an earlier good one)
+                r.tmp_path = r.seq_path + ".tmp";
+                if (e2vq_io::seq_create(r.tmp_path.c_str(), cls, M, T)) {
+                    for (const QFileResult& o : sh.results)
+                        if (!o.tmp_path.empty()) (void)remove(o.tmp_path.c_str());
+                    return 1;
+                }
                 for (i64 t0 = 0; t0 < T; t0 += sh.chunk) {
                     const i64 n = std::min<i64>(sh.chunk, T - t0);
                     cur.segs.push_back(QSegment{i, t0, n, 0, false});
@@ -2236,8 +2296,13 @@ extern "C" int ecoz2_vq_quantize(const char* nom_raas, const char* const* predic
     for (int w = 0; w < W; ++w)
         if (rcs[(size_t)w]) {
             if (w > 0) snprintf(g_err, sizeof g_err, "%s", errs[(size_t)w].c_str());
+            for (const QFileResult& r : sh.results)
+                if (!r.tmp_path.empty()) (void)remove(r.tmp_path.c_str());
             return rcs[(size_t)w];
         }
+    for (const QFileResult& r : sh.results)
+        if (!r.tmp_path.empty() && rename(r.tmp_path.c_str(), r.seq_path.c_str()) != 0)
+            return e2vq_set_error("%s: cannot move the finished sequence into place: %s", r.seq_path.c_str(), strerror(errno));
     double total_e = 0.0;
     i64 total_T = 0;
     for (int i = 0; i < num_predictors; ++i) {

@@ -392,7 +392,8 @@ def test_rccl_hook_single_rank_group(tmp_path):
     assert np.array_equal(np.load(tmp_path / "cb_nccl.npy").view(np.uint64), ref.view(np.uint64))
     calls = np.load(tmp_path / "calls.npy")
     assert calls[0].tolist() == [1, 1] and calls[1].tolist() == [2 * 37 + 3, 0]  # MAX of max|x|, SUM of data stats
-    assert all(c[1] == 0 and c[0] % e.lib.e2vq_row_stride(P) == 0 for c in calls[2:])  # per-pass row all-reduces
+    assert calls[2].tolist() == [1, 1]  # MAX of the bad-data flags: a NaN in any shard stops every rank
+    assert all(c[1] == 0 and c[0] % e.lib.e2vq_row_stride(P) == 0 for c in calls[3:])  # per-pass row all-reduces
 
 
 def test_vq_classify(tmp_path, oracle, capfd):
@@ -579,7 +580,7 @@ def test_rccl_inside_the_library_single_rank_group(tmp_path):
     assert "collective: RCCL" in out and "ncclAllReduce(int64 sum)" in out
     calls = [ln for ln in out.splitlines() if "ncclAllReduce call(s)" in ln]
     # one MAX + one SUM at e2vq_prepare, then one SUM of the rows per pass
-    assert calls and int(calls[0].split("made")[1].split()[0]) >= 2 + sum(g["passes"] for g in meta["levels"])
+    assert calls and int(calls[0].split("made")[1].split()[0]) >= 3 + sum(g["passes"] for g in meta["levels"])
     seen = eval([ln for ln in out.splitlines() if ln.startswith("SEEN ")][0][5:])
     assert seen == [(g["M"], g["avg"], g["sigma"], g["inertia"]) for g in meta["levels"]]
     for g in meta["levels"]:
@@ -592,6 +593,29 @@ def test_rccl_inside_the_library_single_rank_group(tmp_path):
         assert "RCCL needs one device per rank" in out and "peer-to-peer" in out
         got = open(tmp_path / "data" / "codebooks" / "_" / "eps_0.05_M_0016.cbook", "rb").read()
         assert got == open(os.path.join(GOLD, "config1_eps_0.05_M_0016.cbook"), "rb").read()
+
+
+@pytest.mark.parametrize("collective", ["p2p", "rccl"])
+def test_bad_shard_fails_every_rank_of_a_group(tmp_path, collective):
+    """One rank of an in-process group finds NaN in ITS shard.  The bad-data flags are all-reduced at e2vq_prepare, every
+    collective starts with a host rendezvous of the group, and a failed group aborts its RCCL communicators: the call must
+    come back with the data error, not leave the healthy ranks blocked in a collective nobody else will join.  (p2p: three
+    ranks sharing the GPU; rccl: the one-rank communicator a 1-GPU box allows, or one rank per device where there are more.)
+    A subprocess with a timeout: a hang is the failure this guards against."""
+    frames = e.synth.synth_frames(71, 4, P, 0, 30000)
+    frames[29000, 7] = np.nan  # in the last rank's range
+    f = tmp_path / "data" / "predictors" / "_" / "all.prd"
+    e.formats.write_prd(str(f), "_", frames)
+    ranks = 3 if collective == "p2p" else max(1, min(3, e.lib.e2vq_device_count()))
+    env = dict(os.environ, ECOZ2_VQ_OUT_ROOT=str(tmp_path), ECOZ2_VQ_MAX_CODEBOOK_SIZE="64", ECOZ2_VQ_GPUS=str(ranks),
+               ECOZ2_VQ_COLLECTIVE=collective, ECOZ2_VQ_QUIET="1")
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import ecoz2rs_amd as e\n"
+            f"try:\n    e.vq_learn(None, {P}, 0.05, '_', [{str(f)!r}])\n    print('NO ERROR')\n"
+            "except Exception as ex:\n    print('ERROR:', ex)\n")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ERROR:" in r.stdout and "NaN or infinite" in r.stdout, r.stdout[-2000:]
+    assert not list((tmp_path / "data").glob("codebooks/_/*.cbook"))
 
 
 @pytest.mark.parametrize("chunk", [None, 4096])
