@@ -445,102 +445,4 @@ __device__ __forceinline__ void regacc_flush(i4 (&racc)[RegAcc<NC>::NET][4], i64
     }
 }
 
-// ---- deferred accumulate (prefiltered sweep, MODE 2, A/B variant E2VQ_PRE_DEFER) -----------------------------------
-// The row images of ALL 64 frames of a block are staged in LDS at the end of the block's evaluate phase; their int64
-// atomics are then issued a few at a time from inside the NEXT block's tile loop (accum_drain_group), so that the
-// memory-side atomic units drain them under the sweep instead of stalling the wave that issues them in a burst.
-// Image row of a frame (DEFER_STRIDE ints): [0 .. 2NC-1] limb pairs, [2NC] = new cell | old cell << 16 (0xFFFF in the
-// low half: frame left to the fallback sweep, contributes nothing), [2NC+1 .. 2NC+4] distortion limbs.  The count
-// element of the row (index 2NC) is implied: 1 for every staged frame that is not skipped.
-template <int NC>
-struct DeferLayout {
-    static constexpr int NE = 2 * NC + 5;
-    static constexpr int STRIDE = (NE + 1) & ~1;  // even: the limb pairs are written as 8-byte words
-    static constexpr int BYTES_PER_WAVE = 64 * STRIDE * 4;
-    // rows of 65..80 elements (one 64-lane add + one 16-lane tail per frame) that fit the CU's LDS for 8 waves: NC = 30..37
-    static constexpr bool OK = NE > 64 && NE <= 80 && 8 * BYTES_PER_WAVE <= E2VQ_LDS_BYTES;
-};
-
-template <int NC, bool INCR>
-__device__ __forceinline__ void accum_stage_block(const double (&Bf)[4][2 * ((((NC + 3) / 4) + 1) / 2)],
-                                                  const double (&best)[4], const int (&idx)[4], int* __restrict__ img,
-                                                  int sh_r, int sh_d, int sh_d2, long b, long T, int lane,
-                                                  const bool (&skip)[4], bool incr, const int (&oldidx)[4])
-{
-    constexpr int NS = (NC + 3) / 4, REM = NC - 4 * (NS - 1);
-    constexpr int STRIDE = DeferLayout<NC>::STRIDE;
-    const int q = lane >> 4, j = lane & 15;
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft) {
-        int* my = img + (16 * ft + j) * STRIDE;
-        const bool valid = b * 64 + 16 * ft + j < T && !skip[ft];
-        // incremental pass: the limbs are needed only if a frame of this tile changed cell (wave-uniform test)
-        const bool limbs = !INCR || !incr || __ballot(oldidx[ft] != idx[ft]) != 0;
-#pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            if (limbs && (st < NS - 1 || q < REM)) {
-                int hi, lo;
-                fix2(Bf[ft][st], sh_r, hi, lo);
-                *(int2*)&my[2 * (4 * st + q)] = make_int2(hi, lo);
-            }
-        }
-        if (q == 0) {
-            const double e = best[ft] - 1.0;
-            int hi, lo;
-            my[2 * NC] = valid ? ((idx[ft] & 0xffff) | (((INCR && incr) ? oldidx[ft] : idx[ft]) << 16)) : 0xffff;
-            fix2(e, sh_d, hi, lo);
-            my[2 * NC + 1] = hi;
-            my[2 * NC + 2] = lo;
-            fix2(e * e, sh_d2, hi, lo);
-            my[2 * NC + 3] = hi;
-            my[2 * NC + 4] = lo;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// atomics of the 4 staged frames 4g .. 4g+3 (g = 0 .. 15): four adds of elements 0..63 and one carrying the four row tails
-template <int NC, bool INCR>
-__device__ __forceinline__ void accum_drain_group(const int* __restrict__ img, i64* __restrict__ rows, int g, bool incr,
-                                                  int lane)
-{
-    constexpr int NE = 2 * NC + 5, RS = (NE + 7) & ~7;
-    constexpr int STRIDE = DeferLayout<NC>::STRIDE;
-    if constexpr (!DeferLayout<NC>::OK) return;  // (never called for those orders)
-    const int tq = lane >> 4, te = lane & 15;
-    int v[4], cell[4], old[4];
-    bool on[4], chg[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int* row = img + (4 * g + k) * STRIDE;
-        const int pk = __builtin_amdgcn_readfirstlane(row[2 * NC]);
-        cell[k] = pk & 0xffff;
-        old[k] = (int)((unsigned)pk >> 16);
-        on[k] = cell[k] != 0xffff;
-        chg[k] = old[k] != cell[k];
-        v[k] = row[lane];  // (2NC >= 64: the packed cell word is in the tail part)
-    }
-    const int e_t = 64 + te;  // element handled by this lane in the tail instruction
-    int tv = 0;
-    if (e_t < NE) tv = e_t == 2 * NC ? 1 : img[(4 * g + tq) * STRIDE + e_t];
-    const int tcell = tq == 0 ? cell[0] : tq == 1 ? cell[1] : tq == 2 ? cell[2] : cell[3];
-    const int told = tq == 0 ? old[0] : tq == 1 ? old[1] : tq == 2 ? old[2] : old[3];
-    const bool ton = tq == 0 ? on[0] : tq == 1 ? on[1] : tq == 2 ? on[2] : on[3];
-    const bool tchg = tq == 0 ? chg[0] : tq == 1 ? chg[1] : tq == 2 ? chg[2] : chg[3];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (!on[k]) continue;  // wave-uniform
-        // elements 0..63 are limbs: they move with the frame (INCR: only when its cell changed)
-        if (!INCR || !incr || chg[k]) atomicAdd((u64*)&rows[(long)cell[k] * RS + lane], (u64)(i64)v[k]);
-        if (INCR && incr && chg[k]) atomicAdd((u64*)&rows[(long)old[k] * RS + lane], (u64)(-(i64)v[k]));
-    }
-    if (e_t < NE && ton) {
-        const bool mov = e_t <= 2 * NC;  // limbs and count move with the frame; distortions are rebuilt every pass
-        if (!INCR || !incr || tchg || !mov) atomicAdd((u64*)&rows[(long)tcell * RS + e_t], (u64)(i64)tv);
-        if (INCR && incr && tchg && mov) atomicAdd((u64*)&rows[(long)told * RS + e_t], (u64)(-(i64)tv));
-    }
-}
-
 }  // namespace e2vq

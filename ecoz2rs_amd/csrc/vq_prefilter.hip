@@ -60,7 +60,17 @@ struct PrePack {
     // k-steps of weight level lv = frame limb + codeword limb: every pair holding a frame limb <= lv
     __host__ __device__ static constexpr int level_steps(int lv) { return (lv + 1) * G + tail_pairs_upto(lv); }
     static constexpr int NSTEP = level_steps(0) + level_steps(1) + level_steps(2);
-    static constexpr int TILE_E = NSTEP * 64;                     // h8 granules per 32-codeword tile image
+    // Unique codeword granules (round 4).  The granule a k-step needs holds codeword limb cl = lv - fl of the coefficients
+    // of its pair: for the full pairs that depends on (cl, coefficient group g) only -- the same granule serves level cl
+    // against frame limb 0, level cl + 1 against frame limb 1, ... --, so a tile image holds NL * G of those plus the tail
+    // granules of each level (those do differ by level): NU granules instead of NSTEP.  NC = 37: 9 instead of 15 -- 9 KB
+    // per codeword tile and wave through L2 and the texture path instead of 15, 36 operand registers instead of 60.
+    __host__ __device__ static constexpr int tail_base(int lv)
+    {
+        return lv == 0 ? 0 : (lv == 1 ? tail_pairs_upto(0) : tail_pairs_upto(0) + tail_pairs_upto(1));
+    }
+    static constexpr int NU = NL * G + tail_base(2) + tail_pairs_upto(2);
+    static constexpr int TILE_E = NU * 64;                        // h8 granules per 32-codeword tile image
     static constexpr int NCX = (NC + 1) & ~1;
     static_assert(NC >= 2 && 5 * NC * 65536 < (1 << 24), "partial sums must stay below 2^24");
     __host__ __device__ static constexpr int step_level(int s)
@@ -76,6 +86,84 @@ struct PrePack {
     {
         const int lv = step_level(s), k = s - level_first(lv);
         return k < (lv + 1) * G ? k : NL * G + (k - (lv + 1) * G);
+    }
+    // unique granule (index into a tile image) used by k-step s
+    __host__ __device__ static constexpr int step_unique(int s)
+    {
+        const int lv = step_level(s), pr = step_pair(s);
+        if (pr < NL * G) {
+            const int fl = pr / (G > 0 ? G : 1);
+            return (lv - fl) * G + (pr - fl * G);
+        }
+        return NL * G + tail_base(lv) + (pr - NL * G);
+    }
+    // Order of the k-steps of a job: position i -> k-step.  (Any order gives the same accumulators: the partial sums are
+    // exact integers.)  Level-major, as the steps are numbered: the accumulators of the higher levels come to life late in
+    // the job, while the previous job's accumulators die value by value under the key epilogue -- granule-major (all uses of
+    // a granule consecutive) starts all three levels at once and needs ~20 registers more, which k_pass_pre_lds does not have.
+#ifndef E2VQ_PRE_ORDER
+#define E2VQ_PRE_ORDER 0
+#endif
+    __host__ __device__ static constexpr int ord(int i)
+    {
+        if (E2VQ_PRE_ORDER == 0) return i;
+        int c = 0;
+        for (int u = 0; u < NU; ++u)
+            for (int s = 0; s < NSTEP; ++s)
+                if (step_unique(s) == u) {
+                    if (c == i) return s;
+                    ++c;
+                }
+        return -1;
+    }
+    // position of the last use of granule u in a job, and u's rank in the order of those positions: the order in which the
+    // rotating operand loads of k_pass_pre_lds are issued (each behind the last reader of its registers)
+    __host__ __device__ static constexpr int last_pos(int u)
+    {
+        int p = -1;
+        for (int i = 0; i < NSTEP; ++i)
+            if (step_unique(ord(i)) == u) p = i;
+        return p;
+    }
+    __host__ __device__ static constexpr int issue_rank(int u)
+    {
+        int r = 0;
+        for (int v = 0; v < NU; ++v)
+            if (last_pos(v) < last_pos(u)) ++r;
+        return r;
+    }
+    __host__ __device__ static constexpr bool pos_first_of_level(int i)
+    {
+        for (int j = 0; j < i; ++j)
+            if (step_level(ord(j)) == step_level(ord(i))) return false;
+        return true;
+    }
+    __host__ __device__ static constexpr bool pos_first_use(int i)
+    {
+        for (int j = 0; j < i; ++j)
+            if (step_unique(ord(j)) == step_unique(ord(i))) return false;
+        return true;
+    }
+    __host__ __device__ static constexpr bool pos_last_use(int i)
+    {
+        for (int j = i + 1; j < NSTEP; ++j)
+            if (step_unique(ord(j)) == step_unique(ord(i))) return false;
+        return true;
+    }
+    // content of unique granule u, element e of lane half h: codeword limb cl and coefficient n, or n = -1 (zero)
+    __host__ __device__ static __forceinline__ void unique_slot(int u, int h, int e, int& cl, int& n)
+    {
+        if (u < NL * G) {
+            cl = u / (G > 0 ? G : 1);
+            n = 16 * (u - cl * G) + 8 * h + e;
+        } else {
+            const int t = u - NL * G;
+            const int lv = t < tail_base(1) ? 0 : (t < tail_base(2) ? 1 : 2);
+            int fl = 0;
+            slot(NL * G + (t - tail_base(lv)), h, e, fl, n);
+            cl = lv - fl;
+            if (cl < 0 || cl > 2) n = -1;
+        }
     }
     // element e of the granule (pair p, lane half h) of a frame: limb index fl and coefficient n, or n = -1 (zero)
     __host__ __device__ static __forceinline__ void slot(int p, int h, int e, int& fl, int& n)
@@ -339,7 +427,7 @@ __global__ void k_pre_cmax(const double* __restrict__ cbq, int M, int NC, int NP
     if (threadIdx.x == 0 && smax) atomicMax(&ps->eC_biased, smax);
 }
 
-// ---- codebook image: [tile][step][h*32 + row][8 halves] ------------------------------------------------
+// ---- codebook image: [tile][unique granule][h*32 + row][8 halves] ------------------------------------------
 template <int NC>
 __global__ __launch_bounds__(256) void k_pre_codebook(const double* __restrict__ cbq, int M, int NPAD,
                                                       const int* __restrict__ ea, PreScalars* __restrict__ ps,
@@ -368,14 +456,12 @@ __global__ __launch_bounds__(256) void k_pre_codebook(const double* __restrict__
     __syncthreads();
     for (int i = threadIdx.x; i < PK::TILE_E; i += 256) {
         h8 out = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int s = i >> 6, l = i & 63, hh = l >> 5, row = l & 31;
-        const int lv = PK::step_level(s), pr = PK::step_pair(s);
+        const int u = i >> 6, l = i & 63, hh = l >> 5, row = l & 31;  // unique granule u (PrePack::step_unique)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int fl, n;
-            PK::slot(pr, hh, e, fl, n);
-            const int cl = lv - fl;  // codeword limb that meets frame limb fl at this weight
-            if (n >= 0 && cl >= 0 && cl <= 2) out[e] = (_Float16)(int)Y[cl][row][n];
+            int cl, n;
+            PK::unique_slot(u, hh, e, cl, n);
+            if (n >= 0) out[e] = (_Float16)(int)Y[cl][row][n];
         }
         cimg[(long)tile * PK::TILE_E + i] = out;
     }
@@ -543,165 +629,119 @@ __device__ unsigned long long g_pre_stamps[32];
 #define E2VQ_STAMP_DRAIN(i)
 #endif
 
-// ---- the tile loop's building blocks (shared by k_pass_pre and k_pass_pre_lds; they use the kernels' local names
-// PK, A, lane, maskv, ninf, k1, k2, k3) ------------------------------------------------------------------------------
-// one job = the NSTEP MFMAs of (tile, column block) interleaved with the key epilogue of the previous job
-// (96 VALU ops: two fmas, and_or, three med3 per value), pinned by sched_group_barrier; NC = 37: 15 MFMAs,
-// 1 MFMA (32 cycles, 8 of them blocking issue) : 6 VALU ops
-#ifdef E2VQ_PRE_VPM  // A/B knob (tools/probe/ab): VALU ops pinned behind each MFMA of a job
-#define E2VQ_PRE_VALU_PER_MFMA E2VQ_PRE_VPM
-#else
-#define E2VQ_PRE_VALU_PER_MFMA (96 / PK::NSTEP)
-#endif
-#define E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
-    {                                                                                                             \
-        const int sidx = __builtin_amdgcn_readfirstlane((PTILE) * 32 + 8 * (r >> 2) + (r & 3));                   \
-        const float v = __builtin_fmaf(PREV[0][r], 262144.f, __builtin_fmaf(PREV[1][r], 512.f, PREV[2][r]));     \
-        const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);                                     \
-        k3[PCB] = med3f(k2[PCB], k3[PCB], key);                                                                   \
-        k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                                   \
-        k1[PCB] = med3f(k1[PCB], key, ninf);                                                                      \
+// ---- the tile loop's building blocks (shared by k_pass_pre and k_pass_pre_lds) --------------------------------------
+// One *job* = the NSTEP MFMAs of (codeword tile, 32-frame column block) interleaved with the key epilogue of the
+// previous job: per value two fmas (the three weight levels -> v), v_and_or (the codeword index into the low mantissa
+// bits) and three v_med3 (running min / 2nd / 3rd of the keys): 96 VALU operations per 15 MFMAs at NC = 37 --
+// 1 MFMA (32 matrix-pipe cycles, 8 of them blocking issue) : 6 VALU operations, a balanced stream for two waves per SIMD.
+// The order is spelled out (MFMA, its share of the epilogue, sched_barrier): with the codeword tiles loaded by inline asm
+// in other basic blocks, the pipeline solver behind sched_group_barrier left whole jobs unpinned (round 3).
+//
+// The k-steps run in granule-major order (PrePack::ord): the partial sums are exact integers, so any order gives the same
+// accumulators, and this one makes every operand granule's uses consecutive.
+// the share of the previous job's key epilogue that rides behind the MFMA at position I
+template <int NC, int I>
+__device__ __forceinline__ void pre_epilogue_slice(const f16v (&PREV)[3], int ptile, float& k1, float& k2, float& k3, int maskv,
+                                                   float ninf)
+{
+    typedef PrePack<NC> PK;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (r * PK::NSTEP / 16 != I) continue;
+        // (an opaque scalar: seen as tile * 32 | constant the compiler splits the v_and_or into v_and + v_or3 -- a seventh
+        // VALU operation per value)
+        int sidx = ptile * 32 + 8 * (r >> 2) + (r & 3);
+        asm("" : "+s"(sidx));
+        const float v = __builtin_fmaf(PREV[0][r], 262144.f, __builtin_fmaf(PREV[1][r], 512.f, PREV[2][r]));
+        const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);
+        k3 = med3f(k2, k3, key);
+        k2 = med3f(k1, k2, key);
+        k1 = med3f(k1, key, ninf);
     }
-#if defined(E2VQ_PRE_NOSCHED)  // A/B: leave the interleave to the compiler
-#define E2VQ_PRE_PIN
-#elif defined(E2VQ_PRE_PAIRSCHED)  // A/B: two MFMAs, then twice the VALU ops
-#define E2VQ_PRE_PIN                                                                                              \
-    _Pragma("unroll") for (int s = 0; s < (PK::NSTEP + 1) / 2; ++s)                                               \
-    {                                                                                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                        \
-        __builtin_amdgcn_sched_group_barrier(0x002, 2 * E2VQ_PRE_VALU_PER_MFMA, 0);                                        \
+}
+// the whole epilogue of a job at once (behind the last tile of a block)
+template <int NC>
+__device__ __forceinline__ void pre_epilogue(const f16v (&PREV)[3], int ptile, float& k1, float& k2, float& k3, int maskv, float ninf)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        // (an opaque scalar: seen as tile * 32 | constant the compiler splits the v_and_or into v_and + v_or3 -- a seventh
+        // VALU operation per value)
+        int sidx = ptile * 32 + 8 * (r >> 2) + (r & 3);
+        asm("" : "+s"(sidx));
+        const float v = __builtin_fmaf(PREV[0][r], 262144.f, __builtin_fmaf(PREV[1][r], 512.f, PREV[2][r]));
+        const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);
+        k3 = med3f(k2, k3, key);
+        k2 = med3f(k1, k2, key);
+        k1 = med3f(k1, key, ninf);
     }
-#else
-#define E2VQ_PRE_PIN                                                                                              \
-    _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                         \
-    {                                                                                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                        \
-        __builtin_amdgcn_sched_group_barrier(0x002, E2VQ_PRE_VALU_PER_MFMA, 0);                                            \
-    }
-#endif
-#define E2VQ_PRE_JOB(ACC, BC, PREV, PTILE, PCB)                                                                   \
-    {                                                                                                             \
-        const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
-        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
-        {                                                                                                         \
-            const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \
-            const bool first = s == PK::level_first(lv);                                                         \
-            ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
-        }                                                                                                         \
-        E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
-        E2VQ_PRE_PIN                                                                                              \
-    }
+}
 
-// The same job with its order spelled out instead of pinned: behind MFMA s come the six key-epilogue operations of the
-// values r with r * NSTEP / 16 == s (one or two per MFMA at NSTEP = 15), then a scheduling barrier nothing may cross.
-// k_pass_pre_lds uses this form: with its codeword tiles loaded by inline asm in another basic block, the pipeline
-// solver behind sched_group_barrier left the second job of a tile unpinned (its 15 MFMAs ended up back to back behind
-// 45 epilogue operations: the tile loop ran 30 % slower).
-#define E2VQ_PRE_JOB_ORDERED(ACC, BC, PREV, PTILE, PCB)                                                            \
-    {                                                                                                             \
-        const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
-        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
-        {                                                                                                         \
-            const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \
-            const bool first = s == PK::level_first(lv);                                                         \
-            ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                        \
-            {                                                                                                     \
-                if (r * PK::NSTEP / 16 != s) continue;                                                            \
-                const int sidx = __builtin_amdgcn_readfirstlane((PTILE) * 32 + 8 * (r >> 2) + (r & 3));          \
-                const float v = __builtin_fmaf(PREV[0][r], 262144.f, __builtin_fmaf(PREV[1][r], 512.f, PREV[2][r])); \
-                const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);                             \
-                k3[PCB] = med3f(k2[PCB], k3[PCB], key);                                                           \
-                k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                           \
-                k1[PCB] = med3f(k1[PCB], key, ninf);                                                              \
-            }                                                                                                     \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-        }                                                                                                         \
+// WAIT: 0 = the tile's operands are known to be there; N > 0: granule u -- the r-th (r = PrePack::issue_rank(u)) of its
+// tile's NU operand loads, all issued by an earlier job -- is waited for in front of its first use with s_waitcnt vmcnt(N - 1 - r):
+// the vector-memory counter is in-order, so N - 1 - u younger requests may still be out (N = NU: nothing younger than the
+// tile's own loads; N = 2 NU: the next tile's NU loads as well), and anything else in flight -- the previous block's
+// atomics, the LDS-DMA of this block's frames -- is older and only makes the wait longer, never too short.
+// LOADS: behind the last use of granule u in this job -- the last reader of its registers in the tile -- the same
+// registers are requested for the tile whose image starts at `next` (uniform), lane offset `lo`.
+// (s_nop 4 in front of every asm load: the base address may have been restored from a spilled SGPR by v_readlane just
+// before -- a VALU write of an SGPR needs five wait states before a vector-memory instruction reads it, the hardware does
+// not interlock that, and the compiler's hazard recogniser does not look into inline asm: without the nops the first load
+// of a tile went to a garbage address whenever register pressure had put the tile pointer into a VGPR lane.)
+template <int NC, int WAIT, bool LOADS, int I = 0>
+__device__ __forceinline__ void pre_job(f16v (&ACC)[3], const h8 (&BC)[PrePack<NC>::PAIRS], h8 (&A)[PrePack<NC>::NU],
+                                        const f16v (&PREV)[3], int ptile, float& k1, float& k2, float& k3, int maskv, float ninf,
+                                        const char* next, unsigned lo)
+{
+    typedef PrePack<NC> PK;
+    // (a recursive template, not a generic lambda over the positions: clang rejects captured variables as asm operands)
+    if constexpr (I < PK::NSTEP) {
+        constexpr int S = PK::ord(I), LV = PK::step_level(S), PR = PK::step_pair(S), U = PK::step_unique(S);
+        constexpr bool FIRST = PK::pos_first_of_level(I);
+        const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (WAIT > 0 && PK::pos_first_use(I))
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(A[U]) : "n"(WAIT - 1 - PK::issue_rank(U)) : "memory");
+        ACC[LV] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[U], BC[PR], FIRST ? zero : ACC[LV], 0, 0, 0);
+        if constexpr (LOADS && PK::pos_last_use(I)) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3"
+                         : "=&v"(A[U])
+                         : "v"(lo), "s"(next + (U >> 2) * 4096), "n"((U & 3) * 1024)
+                         : "memory");
+        }
+        pre_epilogue_slice<NC, I>(PREV, ptile, k1, k2, k3, maskv, ninf);
+        __builtin_amdgcn_sched_barrier(0);
+        pre_job<NC, WAIT, LOADS, I + 1>(ACC, BC, A, PREV, ptile, k1, k2, k3, maskv, ninf, next, lo);
     }
+}
 
-#ifndef E2VQ_PRE_PKFMA
-#define E2VQ_PRE_PKFMA 0
-#endif
-// The rotated tile loop of k_pass_pre_lds (job 0 of tile 0 | job 1 of tile t, job 0 of tile t + 1 | job 1 of the last tile)
-// uses two more forms of the ordered job.  _LOADS: behind MFMA s -- the last reader of A[s] in its tile -- the same
-// register is requested for the next tile (lo_ = lane * 16, cbn_ = that tile's image), so the L2 latency of a tile's operands
-// runs under the fifteen MFMAs of the job instead of in front of the next tile.  _WAITS: MFMA s waits for exactly its own
-// operand: the vector-memory counter is in-order, NSTEP - 1 - s younger requests may still be out (anything else in flight
-// -- the previous block's atomics -- is older and only makes the wait longer, never too short).
-// (E2VQ_PRE_PKFMA: the two fmas that fold the three limb levels of a value are done for two values at a time --
-// v_pk_fma_f32 on the accumulators' register pairs -- at the step of the even one: five VALU operations per value, not six)
-#if E2VQ_PRE_PKFMA
-#define E2VQ_PRE_JOB_STEP_EPILOGUE(S, PREV, PTILE, PCB)                                                           \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
-    {                                                                                                             \
-        if (r * PK::NSTEP / 16 != (S)) continue;                                                                  \
-        const int sidx = __builtin_amdgcn_readfirstlane((PTILE) * 32 + 8 * (r >> 2) + (r & 3));                  \
-        if ((r & 1) == 0) {                                                                                       \
-            const f2v p0 = {PREV[0][r], PREV[0][r + 1]}, p1 = {PREV[1][r], PREV[1][r + 1]},                       \
-                      p2 = {PREV[2][r], PREV[2][r + 1]};                                                          \
-            f2v tpair;                                                                                            \
-            asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(tpair) : "v"(p1), "s"(pkc512), "v"(p2));                     \
-            asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(vpair) : "v"(p0), "s"(pkc218), "v"(tpair));                  \
-        }                                                                                                         \
-        const float v = (r & 1) ? vpair[1] : vpair[0];                                                            \
-        const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);                                     \
-        k3[PCB] = med3f(k2[PCB], k3[PCB], key);                                                                   \
-        k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                                   \
-        k1[PCB] = med3f(k1[PCB], key, ninf);                                                                      \
+// the compiler-scheduled form of a job (k_pass_pre: its operand loads are plain C++ and the interleave is pinned with
+// sched_group_barrier: one MFMA, then its share of the 96 epilogue operations)
+template <int NC>
+__device__ __forceinline__ void pre_job_pinned(f16v (&ACC)[3], const h8 (&BC)[PrePack<NC>::PAIRS], const h8 (&A)[PrePack<NC>::NU],
+                                               const f16v (&PREV)[3], int ptile, float& k1, float& k2, float& k3, int maskv,
+                                               float ninf)
+{
+    typedef PrePack<NC> PK;
+    const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < PK::NSTEP; ++s) {
+        const int lv = PK::step_level(s), pr = PK::step_pair(s);
+        const bool first = s == PK::level_first(lv);
+        ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[PK::step_unique(s)], BC[pr], first ? zero : ACC[lv], 0, 0, 0);
     }
-#else
-#define E2VQ_PRE_JOB_STEP_EPILOGUE(S, PREV, PTILE, PCB)                                                           \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
-    {                                                                                                             \
-        if (r * PK::NSTEP / 16 != (S)) continue;                                                                  \
-        const int sidx = __builtin_amdgcn_readfirstlane((PTILE) * 32 + 8 * (r >> 2) + (r & 3));                  \
-        const float v = __builtin_fmaf(PREV[0][r], 262144.f, __builtin_fmaf(PREV[1][r], 512.f, PREV[2][r]));     \
-        const float key = __int_as_float((__float_as_int(v) & maskv) | sidx);                                     \
-        k3[PCB] = med3f(k2[PCB], k3[PCB], key);                                                                   \
-        k2[PCB] = med3f(k1[PCB], k2[PCB], key);                                                                   \
-        k1[PCB] = med3f(k1[PCB], key, ninf);                                                                      \
+    pre_epilogue<NC>(PREV, ptile, k1, k2, k3, maskv, ninf);
+#pragma unroll
+    for (int s = 0; s < PK::NSTEP; ++s) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 96 / PK::NSTEP, 0);
     }
-#endif
-#define E2VQ_PRE_JOB_LOADS(ACC, BC, PREV, PTILE, PCB)                                                              \
-    {                                                                                                             \
-        const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
-        [[maybe_unused]] f2v vpair = {0.f, 0.f};                                                                  \
-        [[maybe_unused]] const f2v pkc512 = {512.f, 512.f}, pkc218 = {262144.f, 262144.f};                        \
-        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
-        {                                                                                                         \
-            const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \
-            const bool first = s == PK::level_first(lv);                                                         \
-            ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"                                               \
-                         : "=&v"(A[s])                                                                            \
-                         : "v"(lo_ + (unsigned)((s >> 2) * 4096)), "s"(cbn_), "n"((s & 3) * 1024)                 \
-                         : "memory");                                                                             \
-            E2VQ_PRE_JOB_STEP_EPILOGUE(s, PREV, PTILE, PCB)                                                       \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-        }                                                                                                         \
-    }
-#define E2VQ_PRE_JOB_WAITS(ACC, BC, PREV, PTILE, PCB)                                                              \
-    {                                                                                                             \
-        const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
-        [[maybe_unused]] f2v vpair = {0.f, 0.f};                                                                  \
-        [[maybe_unused]] const f2v pkc512 = {512.f, 512.f}, pkc218 = {262144.f, 262144.f};                        \
-        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
-        {                                                                                                         \
-            const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \
-            const bool first = s == PK::level_first(lv);                                                         \
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(A[s]) : "n"(PK::NSTEP - 1 - s) : "memory");                 \
-            ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
-            E2VQ_PRE_JOB_STEP_EPILOGUE(s, PREV, PTILE, PCB)                                                       \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-        }                                                                                                         \
-    }
+}
 
 // One wave = 64 frames, independent of every other wave (no LDS sharing, no barriers): the codeword tile images come
-// straight from L2 (512 KB at M = 1024; 16 B per lane and k-step) -- measured as fast as a workgroup-shared LDS ring
-// (tools/probe/pre_sweep.hip -DDIRECT_L2), and it lets the two waves of a SIMD drift apart so that one sweeps (matrix
-// pipe) while the other is in its latency-bound evaluate / accumulate phase.
+// straight from L2 (9 KB per 32 codewords at NC = 37; 16 B per lane and granule) -- measured as fast as a workgroup-shared
+// LDS ring (tools/probe/pre_sweep.hip -DDIRECT_L2), and it lets the two waves of a SIMD drift apart so that one sweeps
+// (matrix pipe) while the other is in its latency-bound evaluate / accumulate phase.
 template <int NC, int MODE, int TPBM>
 __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__ blk, long T, long nblocks,
                                                   const h8* __restrict__ fimg, const float* __restrict__ fg,
@@ -721,11 +761,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
     // the distortion elements of the frames (e, e^2 as limb pairs) are summed per wave in registers and added to the
     // distortion columns of one row at the end: only the column totals are ever used (level statistics), and per-frame
     // atomics on those four words were 2^23 per pass, the only ones left for a frame that keeps its cell
-#if defined(E2VQ_PRE_DEFER) || defined(E2VQ_PRE_NO_DSEP)  // (A/B: per-frame atomics on the distortion elements, as in round 1)
-    constexpr bool DSEP = false;
-#else
     constexpr bool DSEP = ACC;
-#endif
     i64 dacc[4] = {0, 0, 0, 0};
     E2VQ_STAMP_DECL
     constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2;
@@ -741,14 +777,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
     constexpr int HYB_CELLS = mfma_hyb_cells(NC);
     const int lds_cells = MODE == 5 ? HYB_CELLS : 0;
     i64* lacc = (i64*)smem;
-#ifdef E2VQ_PRE_DEFER
-    constexpr bool DEFER = MODE == 2 && DeferLayout<NC>::OK;  // deferred accumulate: the wave stages all 64 row images
-#else
-    constexpr bool DEFER = false;
-#endif
-    int* img = DEFER ? (int*)smem + wib * (DeferLayout<NC>::BYTES_PER_WAVE / 4)
-                     : (int*)(smem + (size_t)lds_cells * RS * 8) + wib * (16 * IMG);
-    bool pending = false;  // DEFER: the previous block's images wait in LDS for their atomics
+    int* img = (int*)(smem + (size_t)lds_cells * RS * 8) + wib * (16 * IMG);
     double* stage = (double*)smem + wib * (64 * NC);                       // QF: the wave's 64 row-major FP64 frames
     int* eas = (int*)((double*)smem + (TPBM >> 6) * (64 * NC));            // QF: per-coefficient scale exponents
     if constexpr (QF) {
@@ -803,55 +832,15 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[l][r] = l == 2 ? 3.0e38f : 0.f;
 
-#ifdef E2VQ_PRE_ROLL
-        // A/B knob (off: 4-7 % SLOWER on MI355X as the compiler schedules it -- the 15 loads end up bunched late in the
-        // second job and the loop head still waits for vmcnt(0), with 17 more spilled registers).  Rolling operand
-        // prefetch: the second job of a tile is the last reader of A[s]; right behind its MFMA the register takes the
-        // same granule of the NEXT tile, so that no iteration starts on an s_waitcnt
-#define E2VQ_PRE_JOB_ROLL(ACC, BC, PREV, PTILE, PCB, TNEXT)                                                       \
-    {                                                                                                             \
-        const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                        \
-        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
-        {                                                                                                         \
-            const int lv = PK::step_level(s), pr = PK::step_pair(s);                                              \
-            const bool first = s == PK::level_first(lv);                                                         \
-            ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], BC[pr], first ? zero : ACC[lv], 0, 0, 0);      \
-            A[s] = cimg[(long)(TNEXT) * PK::TILE_E + s * 64 + lane];                                              \
-        }                                                                                                         \
-        E2VQ_PRE_EPILOGUE(PREV, PTILE, PCB)                                                                       \
-        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s)                                                     \
-        {                                                                                                         \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                    \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                    \
-            __builtin_amdgcn_sched_group_barrier(0x002, E2VQ_PRE_VALU_PER_MFMA, 0);                               \
-        }                                                                                                         \
-    }
-        h8 A[PK::NSTEP];
-#pragma unroll
-        for (int s = 0; s < PK::NSTEP; ++s) A[s] = cimg[s * 64 + lane];
         for (int t = 0; t < MT; ++t) {
-            const int tn = t + 1 < MT ? t + 1 : t;  // (last tile: a harmless reload of itself)
-            E2VQ_PRE_JOB(acc0, B[0], acc1, (t - 1) & 0xffff, 1)  // (t = 0: the "previous" accumulators hold 3e38)
-            E2VQ_PRE_JOB_ROLL(acc1, B[1], acc0, t, 0, tn)
-        }
-#undef E2VQ_PRE_JOB_ROLL
-#else
-        for (int t = 0; t < MT; ++t) {
-            if constexpr (DEFER) {
-                // the 16 four-frame groups of the previous block, spread over this block's tiles
-                if (pending) {
-                    const int g0 = (16 * t) / MT, g1 = (16 * (t + 1)) / MT;
-                    for (int g = g0; g < g1; ++g) accum_drain_group<NC, true>(img, rows, g, incr != 0, lane);
-                }
-            }
-            h8 A[PK::NSTEP];
+            h8 A[PK::NU];
 #pragma unroll
-            for (int s = 0; s < PK::NSTEP; ++s) A[s] = cimg[(long)t * PK::TILE_E + s * 64 + lane];
-            E2VQ_PRE_JOB(acc0, B[0], acc1, (t - 1) & 0xffff, 1)  // (t = 0: the "previous" accumulators hold 3e38)
-            E2VQ_PRE_JOB(acc1, B[1], acc0, t, 0)
+            for (int u = 0; u < PK::NU; ++u) A[u] = cimg[(long)t * PK::TILE_E + u * 64 + lane];
+            // (t = 0: the "previous" accumulators hold 3e38)
+            pre_job_pinned<NC>(acc0, B[0], A, acc1, (t - 1) & 0xffff, k1[1], k2[1], k3[1], maskv, ninf);
+            pre_job_pinned<NC>(acc1, B[1], A, acc0, t, k1[0], k2[0], k3[0], maskv, ninf);
         }
-#endif
-        E2VQ_PRE_EPILOGUE(acc1, MT - 1, 1)
+        pre_epilogue<NC>(acc1, MT - 1, k1[1], k2[1], k3[1], maskv, ninf);
 
         E2VQ_STAMP(1)  // tile loop
         // ---- per frame: merge the two lane halves (rows 4h..4h+3 of every 8), certify the top two -------------
@@ -935,25 +924,13 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 
         E2VQ_STAMP_DRAIN(2)  // certification, cells of the previous pass
         // ---- FP64 frames (MFMA operand layout of k_pass_mfma), exact evaluation of the two candidates -----------
-#ifdef E2VQ_PRE_ABLATE_BF
-        const float t1seed = k1[0];
-#endif
         double Bf[4][2 * NP];
         if constexpr (QF)  // fused quantize: the frames are still in the wave's LDS stage
             load_block_frames_stage<NC>(stage, lane, Bf);
         else if (MODE == 0 && aos)  // quantize: the FP64 frames come straight from the row-major payload
             load_block_frames_rowmajor<NC>(aos, b, T, lane, Bf);
         else
-#ifdef E2VQ_PRE_ABLATE_BF  // diagnostics only (wrong results): what does the FP64 frame load cost?
-        {
-#pragma unroll
-            for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-                for (int st = 0; st < 2 * NP; ++st) Bf[ft][st] = (double)(lane + st) * 1e-3 + (double)t1seed;
-        }
-#else
             load_block_frames<NC>(blk, b, lane, Bf);
-#endif
         E2VQ_STAMP_DRAIN(3)  // FP64 frames
         double best[4];
         int idx[4];
@@ -975,15 +952,10 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             E2VQ_STAMP_DRAIN(4)  // gathers of the first candidates
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft) {
-#ifdef E2VQ_PRE_ABLATE_VERIFY  // diagnostics only (tools/probe): wrong results, shows what the exact evaluation costs
-                best[ft] = Bf[ft][0] + g[ft].a[0];
-#else
                 best[ft] = pre_exact<NC>(Bf[ft], g[ft], j);
-#endif
                 idx[ft] = ca[ft];
             }
             E2VQ_STAMP(5)  // exact chains of the first candidates
-#if !defined(E2VQ_PRE_ABLATE_VERIFY) && !defined(E2VQ_PRE_ABLATE_ROUND2)
             if (two[0] || two[1] || two[2] || two[3]) {
 #pragma unroll
                 for (int ft = 0; ft < 4; ++ft)
@@ -997,7 +969,6 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
                         idx[ft] = take_b ? cbx[ft] : ca[ft];
                     }
             }
-#endif
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft) idx[ft] = skip[ft] ? 0 : idx[ft];
             E2VQ_STAMP(6)  // the runners-up
@@ -1023,14 +994,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             }
         }
         E2VQ_STAMP(7)  // outputs
-        if constexpr (DEFER) {
-            // (every group of the previous block went out during this block's tile loop: the LDS rows are free)
-            accum_stage_block<NC, true>(Bf, best, idx, img, sh_r, sh_d, sh_d2, b, T, lane, skip, incr != 0, oldidx);
-            pending = true;
-            const int is = q == 0 ? idx[0] : q == 1 ? idx[1] : q == 2 ? idx[2] : idx[3];
-            const bool sk = q == 0 ? skip[0] : q == 1 ? skip[1] : q == 2 ? skip[2] : skip[3];
-            if (prev_sym && b * 64 + lane < T && !sk) prev_sym[b * 64 + lane] = (unsigned short)is;
-        } else if constexpr (ACC) {
+        if constexpr (ACC) {
             if constexpr (DSEP) {
                 if (q == 0) {
 #pragma unroll
@@ -1059,10 +1023,6 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 #ifdef E2VQ_PRE_STAMP
         st_n += 1;
 #endif
-    }
-    if constexpr (DEFER) {  // the last block's images
-        if (pending)
-            for (int g = 0; g < 16; ++g) accum_drain_group<NC, true>(img, rows, g, incr != 0, lane);
     }
     if constexpr (DSEP) {  // the wave's distortion sums -> the distortion columns of one row (any row: totals only)
 #pragma unroll
@@ -1094,25 +1054,27 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 #endif
 }
 
-// ---- k_pass_pre_lds (round 3): the accumulating prefiltered pass with the FP64 frames of a block staged in LDS ------
-// Same sweep, same keys, same certification, same bits as k_pass_pre.  What changed is everything around the tile loop,
-// because stamps (tools/probe/pre_stamps.py) showed a wave spending 40 k of its 145 k cycles per block there at M = 1024
-// -- and as much again at M = 256, where the tile loop is four times shorter:
-//   * A wave's vector-memory operations retire in order, so every load issued after the block's atomics -- a register
-//     reload from scratch, the FP64 frames of the next tile, the next block's limb images -- waits until those atomics
-//     have been performed at the memory side (thousands of cycles with every CU adding).  Here all of a block's atomics
-//     go out in ONE burst at the very end of the block, behind the loads of the next block's limb images and first
-//     codeword tile; what follows them in the queue (the LDS-DMA of the next block's FP64 frames) is not needed before
-//     the next tile loop is over.
+// ---- k_pass_pre_lds: the accumulating prefiltered pass with the FP64 frames of a block staged in LDS ------------------
+// Same sweep, same keys, same certification, same bits as k_pass_pre.  Everything around the tile loop is built on one
+// fact (round 3, stamps of tools/probe/pre_stamps.py): a wave's vector-memory operations retire IN ORDER, so every load
+// issued after a block's atomics -- a register reload from scratch, the next codeword tile, the next block's limb images
+// -- waits until those atomics have been performed at the memory side (thousands of cycles with every CU adding).
+//   * All atomics of a block go out in ONE burst at the very end of the block, behind the loads of the next block's limb
+//     images and of its first TWO codeword tiles; what follows them in the queue (the LDS-DMA of the next block's FP64
+//     frames, the operands of tile 2) is not needed before two tiles have been swept.
 //   * The FP64 frames arrive by LDS-DMA (global_load_lds_dwordx4 from a row-major resident copy: no registers, issued a
 //     whole tile loop ahead), with the tolerance terms and the cells of the previous pass behind them.
 //   * Exact evaluation: lane = frame.  Each lane runs the canonical chain acc = fma(r[n], cq[n], acc), n ascending from
 //     +0.0 -- the oracle's definition itself, which the FP64 MFMA reproduces (tools/probe/mfma64.hip) -- for both of its
-//     candidates, r from its LDS row, cq rows gathered from L2: no 16x16 FP64 MFMA tiles computed for their diagonals,
-//     no second round, no cross-lane traffic.
+//     candidates, r from its LDS row, cq rows gathered from L2.
 //   * Accumulate in place: a frame that contributes converts its own LDS row to the (hi, lo) limb pairs where the
 //     doubles were (8 bytes either way), then the wave adds the rows of those frames to their cells, four frames per
 //     step (four 64-lane adds + one carrying the four row tails and the count).  Only frames that moved are touched.
+//   * Round 4 -- the tile loop: codeword tiles are NU unique granules (PrePack: 9 instead of 15 at NC = 37) in TWO
+//     register sets (even / odd tiles).  The operands of tile t + 2 are requested granule by granule behind their last
+//     readers in job 1 of tile t and waited for one by one in job 0 of tile t + 2: a whole tile of MFMAs (two jobs of the
+//     partner wave as well) lies between a request and its use, where round 3's single set left half a tile -- and the
+//     burst of a block's atomics has two wait-free tiles to drain under instead of one.
 template <int NC>
 struct PreLds {
     static constexpr int STAGE_BYTES = 64 * NC * 8;  // the block's frames, row-major
@@ -1147,34 +1109,6 @@ __device__ __forceinline__ void pre_lds_request(const double* __restrict__ aos, 
                                          (lptr_t)(wbase + BYTES + 256), 4, 0, 0);
 }
 
-// s_waitcnt vmcnt(0) that the N granules loaded by inline asm depend on (so that nothing consuming them moves above it)
-template <int N>
-__device__ __forceinline__ void pre_wait_loaded(h8 (&A)[N])
-{
-    static_assert(N >= 6 && N <= 18, "k-steps per tile");
-    if constexpr (N == 6)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5])::"memory");
-    else if constexpr (N == 9)
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), "+v"(A[8])::"memory");
-    else if constexpr (N == 11)
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), "+v"(A[8]),
-                       "+v"(A[9]), "+v"(A[10])::"memory");
-    else if constexpr (N == 12)
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), "+v"(A[8]),
-                       "+v"(A[9]), "+v"(A[10]), "+v"(A[11])::"memory");
-    else if constexpr (N == 15)
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), "+v"(A[8]),
-                       "+v"(A[9]), "+v"(A[10]), "+v"(A[11]), "+v"(A[12]), "+v"(A[13]), "+v"(A[14])::"memory");
-    else {  // other packings: one wait per granule (cheap: the counter is already zero after the first)
-#pragma unroll
-        for (int s = 0; s < N; ++s) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[s])::"memory");
-    }
-}
-
 // the lane index straight from the hardware, in a form the compiler can neither hoist nor share between uses
 __device__ __forceinline__ int pre_fresh_lane()
 {
@@ -1183,10 +1117,34 @@ __device__ __forceinline__ int pre_fresh_lane()
     return l;
 }
 
-#ifndef E2VQ_PRE_ROT
-#define E2VQ_PRE_ROT 1  // (0: the single loop with one wait per tile, for A/B builds)
-#endif
+// a whole codeword tile requested at once by inline asm, and the wait for it (the simple tile loop of odd tile counts)
+template <int NC, int U = 0>
+__device__ __forceinline__ void pre_load_tile_issue(h8 (&A)[PrePack<NC>::NU], const char* tile, unsigned lo)
+{
+    if constexpr (U < PrePack<NC>::NU) {
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3"
+                     : "=&v"(A[U])
+                     : "v"(lo), "s"(tile + (U >> 2) * 4096), "n"((U & 3) * 1024)
+                     : "memory");
+        pre_load_tile_issue<NC, U + 1>(A, tile, lo);
+    }
+}
+template <int NC, int U = 0>
+__device__ __forceinline__ void pre_load_tile_wait(h8 (&A)[PrePack<NC>::NU])
+{
+    if constexpr (U < PrePack<NC>::NU) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[U])::"memory");  // (cheap: the counter is zero after the first)
+        pre_load_tile_wait<NC, U + 1>(A);
+    }
+}
 template <int NC>
+__device__ __forceinline__ void pre_load_tile_asm(h8 (&A)[PrePack<NC>::NU], const char* tile, unsigned lo)
+{
+    pre_load_tile_issue<NC>(A, tile, lo);
+    pre_load_tile_wait<NC>(A);
+}
+
+template <int NC, bool ROT>
 __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restrict__ aos, long T, long nblocks,
                                                          const h8* __restrict__ fimg, const float* __restrict__ fg,
                                                          const h8* __restrict__ cimg, PreScalars* __restrict__ ps,
@@ -1205,6 +1163,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
     typedef PrePack<NC> PK;
     typedef PreLds<NC> PL;
     constexpr int TPBM = 512;
+    constexpr int NU = PK::NU;
     constexpr int RS = (2 * NC + 5 + 7) & ~7, NPAD = (NC + 7) & ~7;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // (the wave's index as a scalar: everything derived from it -- block numbers, the LDS region -- stays in SGPRs)
@@ -1222,20 +1181,29 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
     const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
     const int sh_d = 30 - Ed, sh_d2 = 30 - 2 * Ed;
     const bool fast_fix = sh_r >= -1000 && sh_r <= 1000;  // fix2_mul applies (always, but for absurdly scaled data)
-    const double scale_r = ldexp(1.0, fast_fix ? sh_r : 0);
+    // (powers of two put together from their bit patterns with integer arithmetic: uniform values that stay in scalar
+    // registers -- ldexp / a float division would leave them in VGPRs for the whole kernel, i.e. spilled across the tile loop
+    // and reloaded from scratch in the middle of the phases that must not wait on the vector-memory counter)
+    auto pow2 = [](int e) { return __longlong_as_double((long long)(1023 + e) << 52); };  // |e| <= 1000
+    const double scale_r = pow2(fast_fix ? sh_r : 0);
+    const bool fast_d = sh_d >= -1000 && sh_d <= 1000 && sh_d2 >= -1000 && sh_d2 <= 1000;
+    const double scale_d = pow2(fast_d ? sh_d : 0), scale_d2 = pow2(fast_d ? sh_d2 : 0);
     const float ymax1 = __int_as_float(ps->ymax_bits);
-    const float relk = 2.0f / (float)(1u << (22 - __builtin_popcount(~idxmask)));  // 2 rho, rho = 2^-(22-idxbits)
+    const float relk = __int_as_float((127 + __builtin_popcount(~idxmask) - 21) << 23);  // 2 rho, rho = 2^-(22-idxbits)
+    // ROT: the rotating, double-buffered tile loop; it needs at least four tiles and an even count (the register set of a
+    // tile is its parity).  Any other count -- a base codebook of unusual size -- runs the instantiation with the simple
+    // loop: one set, one wait per tile (a kernel of its own, so that its register needs do not disturb this one's).
 
     // (partner waves w and w + 4 of a SIMD: half a block period apart, as in k_pass_pre)
     if (stagger && nblocks >= 2 * nwaves && wib >= 4)
         for (int i = 0; i < stagger * MT / 8; ++i) __builtin_amdgcn_s_sleep(127);
 
-    // limb images of the block and the first codeword tile: loop-carried, requested for the NEXT block before the
+    // limb images of the block and the first two codeword tiles: loop-carried, requested for the NEXT block before the
     // current block's atomics go out
     // (addresses as uniform base + 32-bit lane offset: the compiler keeps no 64-bit per-lane pointers alive -- and
     // spilled -- across the phases; a reload from scratch behind the atomics would wait for them)
     h8 B[2][PK::PAIRS];
-    h8 A[PK::NSTEP];
+    h8 A0[NU], A1[NU];
     constexpr unsigned BLOCK_IMG = 2u * PK::PAIRS * 64u * 16u;  // bytes of a block's limb image
     constexpr unsigned TILE_IMG = (unsigned)PK::TILE_E * 16u;   // bytes of a codeword tile's limb image
 #define E2VQ_LDS_LOAD_B(BLK, LN)                                                                              \
@@ -1245,15 +1213,16 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int p = 0; p < PK::PAIRS; ++p) \
             B[cb][p] = *(const h8*)(fb_ + (lo_ + (unsigned)((cb * PK::PAIRS + p) * 1024)));                   \
     }
-#define E2VQ_LDS_LOAD_A(TILE, LN)                                                                             \
+#define E2VQ_LDS_LOAD_A(ASET, TILE, LN)                                                                       \
     {                                                                                                         \
         const char* cb_ = (const char*)cimg + (size_t)(TILE) * TILE_IMG;                                      \
         const unsigned lo_ = (unsigned)(LN) * 16u;                                                            \
-        _Pragma("unroll") for (int s = 0; s < PK::NSTEP; ++s) A[s] = *(const h8*)(cb_ + (lo_ + (unsigned)(s * 1024))); \
+        _Pragma("unroll") for (int u = 0; u < NU; ++u) ASET[u] = *(const h8*)(cb_ + (lo_ + (unsigned)(u * 1024))); \
     }
     if (wave < nblocks) {
         E2VQ_LDS_LOAD_B(wave, lane)
-        E2VQ_LDS_LOAD_A(0, lane)
+        E2VQ_LDS_LOAD_A(A0, 0, lane)
+        E2VQ_LDS_LOAD_A(A1, 1, lane)  // (every codebook of this kernel has at least two tiles: M >= 64)
         pre_lds_request<NC>(aos, fg, incr ? prev_sym : nullptr, wave, lane, wbase);
     }
     // (as before every block's atomics: both ways into the block loop arrive with no register load pending, so the
@@ -1270,6 +1239,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         float ninf = -__builtin_inff();
         asm volatile("" : "+v"(ninf));
         const int lane_t = pre_fresh_lane();
+        const unsigned lo_t = (unsigned)lane_t * 16u;
         float k1[2], k2[2], k3[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) k1[cb] = k2[cb] = k3[cb] = __int_as_float(0x7f7fffff);
@@ -1278,44 +1248,40 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         for (int l = 0; l < 3; ++l)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[l][r] = l == 2 ? 3.0e38f : 0.f;
-        // Tile 0 came with the block's limb images, complete before the previous block's atomics went out: it runs
-        // without a counter wait while those atomics drain; the loads of tile 1 queue behind them.  The in-loop loads
-        // are inline asm with a hand-placed wait: any load the compiler can see in this loop makes it insert counter
-        // waits that, at t = 0, would wait for the atomics (the counter is in-order and the number of atomics unknown).
-#if E2VQ_PRE_ROT
-        // rotated: the operands of tile t + 1 are requested register by register behind their last readers in job 1 of tile
-        // t and waited for one by one in job 0 of tile t + 1 (tile 0's came with the block's limb images: no wait at all)
-        E2VQ_PRE_JOB_ORDERED(acc0, B[0], acc1, 0xffff, 1)  // (the "previous" accumulators hold 3e38)
-        for (int t = 0; t + 1 < MT; ++t) {
-            const char* cbn_ = (const char*)cimg + (size_t)(t + 1) * TILE_IMG;
-            const unsigned lo_ = (unsigned)lane_t * 16u;
-            E2VQ_PRE_JOB_LOADS(acc1, B[1], acc0, t, 0)
-            E2VQ_PRE_JOB_WAITS(acc0, B[0], acc1, t, 1)
-        }
-        E2VQ_PRE_JOB_ORDERED(acc1, B[1], acc0, MT - 1, 0)
-#else
-        for (int t = 0; t < MT; ++t) {
-            if (t > 0) {
-                const char* cb_ = (const char*)cimg + (size_t)t * TILE_IMG;
-                const unsigned lo_ = (unsigned)lane_t * 16u;
-#pragma unroll
-                for (int s = 0; s < PK::NSTEP; ++s)
-                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
-                                 : "=&v"(A[s])
-                                 : "v"(lo_ + (unsigned)((s >> 2) * 4096)), "s"(cb_), "n"((s & 3) * 1024)
-                                 : "memory");
-                static_assert(PK::NSTEP <= 18, "operand list of the wait below");
-                pre_wait_loaded<PK::NSTEP>(A);
+        // Tiles 0 and 1 came with the block's limb images, complete before the previous block's atomics went out: they run
+        // without a counter wait while those atomics drain; the loads of tile 2 queue behind them.  The in-loop loads are
+        // inline asm with hand-placed waits: any load the compiler can see in this loop makes it insert counter waits
+        // that, at t = 0, would wait for the atomics (the counter is in-order and the number of atomics unknown).
+        // One tile = job 0 (column block 0, epilogue of the previous tile's job 1) + job 1 (column block 1, epilogue of
+        // job 0); the "previous" accumulators of tile 0 hold 3e38.
+        const char* cimg_c = (const char*)cimg;
+#define E2VQ_TILE(T_, ASET, WAIT_, LOADS_)                                                                              \
+    {                                                                                                                   \
+        pre_job<NC, WAIT_, false>(acc0, B[0], ASET, acc1, ((T_) - 1) & 0xffff, k1[1], k2[1], k3[1], maskv, ninf, nullptr, 0u); \
+        pre_job<NC, 0, LOADS_>(acc1, B[1], ASET, acc0, (T_), k1[0], k2[0], k3[0], maskv, ninf,                           \
+                               cimg_c + (size_t)((T_) + 2) * TILE_IMG, lo_t);                                           \
+    }
+        if constexpr (ROT) {
+            E2VQ_TILE(0, A0, 0, true)  // (requests tile 2)
+            E2VQ_TILE(1, A1, 0, true)  // (requests tile 3)
+            for (int t = 2; t < MT - 2; t += 2) {
+                E2VQ_TILE(t, A0, 2 * NU, true)
+                E2VQ_TILE(t + 1, A1, 2 * NU, true)
             }
-            E2VQ_PRE_JOB_ORDERED(acc0, B[0], acc1, (t - 1) & 0xffff, 1)  // (t = 0: the "previous" accumulators hold 3e38)
-            E2VQ_PRE_JOB_ORDERED(acc1, B[1], acc0, t, 0)
-#if defined(E2VQ_PRE_STAMP) && E2VQ_PRE_STAMP == 3  // (stamps inside the loop cost the sweep ~30 %: a build of their own)
-            if (t == 0) E2VQ_STAMP(8)   // tile 0 (operands prefetched)
-            if (t == 1) E2VQ_STAMP(10)  // tile 1 (its loads queue behind the previous block's atomics and this block's LDS-DMA)
-#endif
+            E2VQ_TILE(MT - 2, A0, 2 * NU, false)  // (tile MT - 1's loads are the NU younger ones; none beyond the last tile
+            E2VQ_TILE(MT - 1, A1, NU, false)      //  is ever requested: nothing younger here)
+        } else {
+            E2VQ_TILE(0, A0, 0, false)
+            E2VQ_TILE(1, A1, 0, false)
+            for (int t = 2; t < MT; ++t) {
+                pre_load_tile_asm<NC>(A0, cimg_c + (size_t)t * TILE_IMG, lo_t);
+                E2VQ_TILE(t, A0, 0, false)
+            }
+            // (two tiles only: no load was waited for in the loop, and the block's LDS-DMA must have landed below)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-#endif
-        E2VQ_PRE_EPILOGUE(acc1, MT - 1, 1)
+#undef E2VQ_TILE
+        pre_epilogue<NC>(acc1, MT - 1, k1[1], k2[1], k3[1], maskv, ninf);
         E2VQ_STAMP(1)  // tile loop
 
         // Everything below recomputes its addresses from an opaque copy of the lane index: hoisted out of the block loop
@@ -1362,8 +1328,6 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         {
             // both codeword rows are requested at once (one exposed L2 latency); the frame's coefficients come from
             // its LDS row eight at a time, fenced, so that the compiler does not hoist all 37 reads above the chains
-            // (the next block's limb images are in flight in 56 registers: with everything hoisted they get spilled,
-            // which first has to wait for them)
             constexpr int NH = (NC + 1) / 2;
             const double2* r1 = (const double2*)(cbq + (long)c1 * NPAD);
             const double2* r2 = (const double2*)(cbq + (long)c2 * NPAD);
@@ -1399,15 +1363,16 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         idx = skip ? 0 : idx;
         E2VQ_STAMP(3)  // exact evaluation
 
-        // ---- the next block's limb images and first codeword tile: requested now -- behind the register-hungry chains,
-        // ahead of the outputs and the distortion sums, which cover part of their latency -- and complete before the atomics go out
+        // ---- the next block's limb images and first two codeword tiles: requested now -- behind the register-hungry
+        // chains, ahead of the outputs and the distortion sums, which cover part of their latency -- and complete before
+        // the atomics go out
         {   // (unconditional -- the wave's last block reloads its own images: a conditional load would keep the old B and A
-            // alive, 116 registers, through the evaluation above)
+            // alive through the evaluation above)
             const long bl = bn < nblocks ? bn : b;
             E2VQ_LDS_LOAD_B(bl, ln)
-            E2VQ_LDS_LOAD_A(0, ln)
+            E2VQ_LDS_LOAD_A(A0, 0, ln)
+            E2VQ_LDS_LOAD_A(A1, 1, ln)
         }
-
 
         // ---- outputs; uncertified frames go to the fallback list -----------------------------------------------------
         if (live) {
@@ -1428,8 +1393,13 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
             int h0 = 0, l0 = 0, h1 = 0, l1 = 0;
             if (live && !skip) {
                 const double e = best - 1.0;
-                fix2(e, sh_d, h0, l0);
-                fix2(e * e, sh_d2, h1, l1);
+                if (fast_d) {  // (kernel-uniform; same limbs as fix2: vq_fixed.h)
+                    fix2_mul(e, scale_d, h0, l0);
+                    fix2_mul(e * e, scale_d2, h1, l1);
+                } else {
+                    fix2(e, sh_d, h0, l0);
+                    fix2(e * e, sh_d2, h1, l1);
+                }
             }
             i64 d0 = h0, d1 = l0, d2 = h1, d3 = l1;
             for (int d = 32; d >= 1; d >>= 1) {
@@ -1475,9 +1445,9 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         E2VQ_STAMP(5)  // limb conversion (bulk)
 
         // ---- the block's atomics, four frames per step ------------------------------------------------------------------
-        // Every load of this block -- and of the next block's limb images -- has to be complete before the first atomic:
-        // nothing may wait on the vector-memory counter from here to the next tile loop.  The builtin (not inline asm) so
-        // that the compiler's own counter bookkeeping sees it and inserts no later wait for those registers.
+        // Every load of this block -- and of the next block's limb images and first tiles -- has to be complete before the
+        // first atomic: nothing may wait on the vector-memory counter from here to tile 2 of the next block.  The builtin
+        // (not inline asm) so that the compiler's own counter bookkeeping sees it and inserts no later wait for those registers.
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         {
             u64 mm = movers;
@@ -1556,6 +1526,8 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         st_n += 1;
 #endif
     }
+#undef E2VQ_LDS_LOAD_A
+#undef E2VQ_LDS_LOAD_B
 #ifdef E2VQ_PRE_STAMP
     {
         E2VQ_STAMP_START
@@ -1740,21 +1712,24 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
     } else if (accumulate && aos_resident && prefilter_lds_stage(NC)) {
         // round 3: FP64 frames staged in LDS, lane-per-frame exact evaluation, one burst of atomics per block
         if constexpr (PreLds<NC>::OK) {
-            (void)hipFuncSetAttribute((const void*)k_pass_pre_lds<NC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      E2VQ_LDS_BYTES);
-            hipLaunchKernelGGL((k_pass_pre_lds<NC>), dim3(grid), dim3(TPBM), (size_t)8 * PreLds<NC>::WAVE_BYTES, s,
-                               aos_resident, T, nblocks, (const h8*)fimg, fg, (const h8*)cimg, (PreScalars*)ps, cbq, M / 32,
-                               idxmask, sc, (const u64*)l1max_bits, sym, dmin, rows, fb_list, stagger, prev_sym,
-                               family_table ? 2 : (incremental ? 1 : 0), (i64*)family_table);
+            const int MT = M / 32;
+            auto go = [&](auto kernel) {
+                (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E2VQ_LDS_BYTES);
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(TPBM), (size_t)8 * PreLds<NC>::WAVE_BYTES, s, aos_resident, T,
+                                   nblocks, (const h8*)fimg, fg, (const h8*)cimg, (PreScalars*)ps, cbq, MT, idxmask, sc,
+                                   (const u64*)l1max_bits, sym, dmin, rows, fb_list, stagger, prev_sym,
+                                   family_table ? 2 : (incremental ? 1 : 0), (i64*)family_table);
+            };
+            static const bool simple = getenv("ECOZ2_VQ_PRE_SIMPLE_LOOP") && atoi(getenv("ECOZ2_VQ_PRE_SIMPLE_LOOP")) != 0;  // (tests)
+            if (MT >= 4 && (MT & 1) == 0 && !simple)
+                go(k_pass_pre_lds<NC, true>);
+            else
+                go(k_pass_pre_lds<NC, false>);
         }
     } else if (accumulate) {
         (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 2, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
-#ifdef E2VQ_PRE_DEFER
-        const size_t lds2 = DeferLayout<NC>::OK ? (size_t)(TPBM / 64) * DeferLayout<NC>::BYTES_PER_WAVE : lds;  // 160 KB at NC = 37
-#else
         const size_t lds2 = lds;
-#endif
         hipLaunchKernelGGL((k_pass_pre<NC, 2, TPBM>), dim3(grid), dim3(TPBM), lds2, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
                            dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0, (const double*)nullptr,

@@ -291,6 +291,15 @@ int main(int argc, char** argv)
         for (int l = 0; l < 3; ++l)
             for (size_t i = 0; i < n; ++i) {
                 const int lim = l == 0 ? 512 : 256;
+#ifndef DATA
+#define DATA 0
+#endif
+                // DATA (round 4: how much of the power-limited clock is the operands' bit activity?): 0 = the product's limbs
+                // (X1, Y1 >= 0: keys positive; the lower limbs signed), 1 = every limb unsigned, 2 = zeros, 3 = small unsigned
+                // values (0..15), 4 = signed, lower limbs sign-magnitude-sorted (no effect on the encoding: control)
+                if (DATA == 2) { v[l * n + i] = 0; (void)sm64(seed); continue; }
+                if (DATA == 3) { v[l * n + i] = (short)(sm64(seed) % 16); continue; }
+                if (DATA == 1) { v[l * n + i] = (short)(sm64(seed) % (lim + 1)); continue; }
                 v[l * n + i] = l == 0 ? (short)(sm64(seed) % (lim + 1)) : (short)((long)(sm64(seed) % (2 * lim + 1)) - lim);  // X1, Y1 >= 0: keys positive
             }
     };
