@@ -16,6 +16,14 @@ resident in HBM before the timed region.  Weak scaling: S = 2^21 frames per GPU 
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
     python bench.py --gpus N ...       (no launcher: the parent starts the N ranks itself as fresh child processes,
                                         before it has made any GPU call, and relays rank 0's JSON line)
+    python bench.py --gpus N --in-process   the N ranks as the library's OWN in-process group (e2vq_group_*: what
+                                        ecoz2_vq_learn runs for ECOZ2_VQ_GPUS=N behind the reference's single-process
+                                        caller), one host thread per rank: the exchange timed is the library's --
+                                        ncclAllReduce(int64) on RCCL loaded by the library when every rank has a GPU of its
+                                        own, its peer-to-peer kernel when ranks share one -- not torch.distributed's
+After the timed region (untimed) the line's `config.parity` is made: the same level re-run on the plain FP64 sweep must give
+the same codebook bit for bit, and the per-frame outputs of the timed kernel are checked against the strict CPU oracle on a
+32 768-frame sample; a mismatch makes the run fail.
 """
 import argparse
 import json
@@ -144,6 +152,190 @@ def self_launch(args):
         raise SystemExit(f"bench.py: rank(s) failed: {bad}")
 
 
+
+class ProcComm:
+    """one process per GPU (the driver's launch, or self_launch): ranks meet through torch.distributed"""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.args = torch, dist, args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+        self.local = local % torch.cuda.device_count()
+        torch.cuda.set_device(self.local)
+        if self.world > 1:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{self.local}"))
+            else:
+                dist.init_process_group(args.backend)
+        elif args.force_collective:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{self.local}"))
+            os.environ["ECOZ2_VQ_FORCE_ALLREDUCE"] = "1"
+        self.ar_calls = {"n": 0, "bytes": 0, "max_bytes": 0}
+
+    def attach(self, sess):
+        from ecoz2rs_amd import parallel
+
+        parallel.bind_torch_stream(sess, self.local)  # session kernels + RCCL collectives on one torch stream
+        if self.world > 1 or self.args.force_collective:
+            inner = parallel.make_allreduce(self.local)
+            ar = self.ar_calls
+
+            def counted(ptr, count, op, stream):
+                ar["n"] += 1
+                ar["bytes"] += 8 * count
+                ar["max_bytes"] = max(ar["max_bytes"], 8 * count)
+                inner(ptr, count, op, stream)
+
+            sess.set_allreduce(counted, self.rank, self.world)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=f"cuda:{self.local}")
+        if self.args.backend != "nccl":
+            t = t.cpu()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def describe(self, ar_timed):
+        if self.world == 1 and not self.args.force_collective:
+            return None
+        if self.world == 1:
+            return {"backend": "nccl (one-rank group on this GPU: the host side of the exchange, no wire)", "world_size": 1,
+                    "exchange": "torch.distributed all_reduce through the session's hook",
+                    "allreduce_calls": ar_timed["n"], "allreduce_calls_per_step": ar_timed["n"] / max(1, self.args.steps),
+                    "bytes_per_call": self.ar_calls["max_bytes"], "bytes_timed_region": ar_timed["bytes"]}
+        devs = [None] * self.world
+        self.dist.all_gather_object(devs, self.local)
+        try:
+            rccl = ".".join(str(x) for x in self.torch.cuda.nccl.version()) if self.args.backend == "nccl" else None
+        except Exception:
+            rccl = None
+        return {
+            "backend": self.args.backend + (" (RCCL over xGMI)" if self.args.backend == "nccl" else " (host-staged rehearsal)"),
+            "exchange": "torch.distributed all_reduce through the session's hook (process per GPU)",
+            "world_size": self.world,
+            "devices_per_rank": 1,
+            "device_of_rank": devs,
+            "distinct_devices": len(set(devs)),
+            "allreduce_calls": ar_timed["n"],
+            "allreduce_calls_per_step": ar_timed["n"] / max(1, self.args.steps),
+            "bytes_per_call": self.ar_calls["max_bytes"],
+            "bytes_timed_region": ar_timed["bytes"],
+            "dtype": "int64 sum (exact: any rank count gives the same bits)",
+            "rccl_version": rccl,
+        }
+
+    def counters(self):
+        return dict(self.ar_calls)
+
+    def finish(self):
+        if self.world > 1 or (self.world == 1 and self.args.force_collective):
+            try:
+                self.dist.destroy_process_group()
+            except Exception:
+                pass
+
+
+class ThreadComm:
+    """--in-process: rank r is a host thread driving its own session; the ranks meet in the library's group"""
+
+    def __init__(self, args, shared, rank):
+        import torch
+
+        self.torch, self.args, self.shared = torch, args, shared
+        self.rank, self.world = rank, args.gpus
+        self.local = shared["devices"][rank]
+        torch.cuda.set_device(self.local)  # (per thread)
+
+    def attach(self, sess):
+        self.shared["group"].bind(self.rank, sess)
+
+    def barrier(self):
+        self.shared["barrier"].wait()
+
+    def max_over_ranks(self, x):
+        sl = self.shared["slots"]
+        sl[self.rank] = x
+        self.shared["barrier"].wait()
+        m = max(sl)
+        self.shared["barrier"].wait()
+        return m
+
+    def describe(self, ar_timed):
+        g = self.shared["group"]
+        return {
+            "backend": "rccl inside the library (dlopen, ncclCommInitAll, ncclAllReduce)" if g.uses_rccl
+                       else "the library's peer-to-peer reduce-scatter + all-gather kernel (ranks share devices, or RCCL is not used)",
+            "exchange": "the library's own in-process group (e2vq_group_*): the exchange ecoz2_vq_learn runs for ECOZ2_VQ_GPUS=N",
+            "library_says": g.collective,
+            "world_size": self.world,
+            "devices_per_rank": 1,
+            "device_of_rank": list(self.shared["devices"]),
+            "distinct_devices": len(set(self.shared["devices"])),
+            "dtype": "int64 sum (exact: any rank count gives the same bits)",
+        }
+
+    def counters(self):
+        return {"n": 0, "bytes": 0, "max_bytes": 0}
+
+    def finish(self):
+        pass
+
+
+def run_in_process(args):
+    """the N ranks as threads of this process, meeting in the library's own group"""
+    import threading
+
+    import torch
+
+    # (torch first: its bundled HIP runtime must initialise before the library's first HIP call, or it finds no GPU -- the
+    # order the process-per-GPU path has always had; torch only provides the output buffers of the parity check here)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.init()
+    import ecoz2rs_amd as e
+
+    ndev = torch.cuda.device_count()
+    devices = [r % ndev for r in range(args.gpus)]
+    group = e.VqGroup(devices, args.collective or None)
+    shared = {"devices": devices, "group": group, "barrier": threading.Barrier(args.gpus), "slots": [0.0] * args.gpus}
+    errors = [None] * args.gpus
+
+    def rank_main(r):
+        try:
+            run(args, ThreadComm(args, shared, r))
+        except BaseException as ex:  # a rank that gives up releases the others from the library's rendezvous and from ours
+            errors[r] = ex
+            group.fail()
+            shared["barrier"].abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,), name=f"rank{r}") for r in range(1, args.gpus)]
+    for t in threads:
+        t.start()
+    rank_main(0)
+    for t in threads:
+        t.join()
+    group.close()
+    bad = [(r, repr(ex)) for r, ex in enumerate(errors) if ex is not None]
+    if bad:
+        raise SystemExit(f"bench.py --in-process: rank(s) failed: {bad}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,60 +355,96 @@ def main():
                          "side costs per pass, without a wire: DESIGN.md section 5)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL over xGMI; "
                     "gloo lets several ranks share one GPU when rehearsing the N > 1 path)")
+    ap.add_argument("--in-process", action="store_true",
+                    help="the N ranks as the library's own in-process group (one host thread per rank; rank r on GPU r modulo "
+                         "the device count): times the library's exchange, not torch.distributed's")
+    ap.add_argument("--collective", default="", help="--in-process: rccl | p2p (default: RCCL when every rank has a GPU of "
+                    "its own, else the library's peer-to-peer kernel)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the untimed parity section (config.parity)")
     args = ap.parse_args()
     M = args.codebook_size
-    FLOP_PER_FRAME_PASS = 2 * M * (P + 1)
     if M < 4 or M & (M - 1):
         raise SystemExit("--codebook-size must be a power of two >= 4")
-
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return self_launch(args)
     if args.no_prefilter:
         os.environ["ECOZ2_VQ_PREFILTER"] = "0"
+    if args.in_process and "WORLD_SIZE" not in os.environ:
+        return run_in_process(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    comm = ProcComm(args)
+    try:
+        run(args, comm)
+    finally:
+        comm.finish()
+
+
+def parity_section(args, comm, sess, whole_level, sym, dmin, S, lo, M):
+    """Untimed.  (1) The level just timed, re-run with the prefilter off in the same session: codebook bytes, pass count and DD
+    must be identical.  (2) One more pass of the timed kernel on the level's final codebook with per-frame outputs: symbols and
+    distortions of a 32 768-frame sample against the strict CPU oracle (the checker; it is never the thing measured), and --
+    one rank -- every cell's frame count against the symbols.  Raises on any mismatch."""
+    import hashlib
+
     import numpy as np
-    import torch
-    import torch.distributed as dist
 
     import ecoz2rs_amd as e
-    from ecoz2rs_amd import parallel
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    local = local % torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-        else:
-            dist.init_process_group(args.backend)
-    elif args.force_collective:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local}"))
-        os.environ["ECOZ2_VQ_FORCE_ALLREDUCE"] = "1"
+    lv_pre = whole_level()
+    cb_pre = sess.get_codebook()
+    prefiltered, _ = sess.last_pass_info()
+    out = {"level": M, "passes": lv_pre.passes, "DD": lv_pre.DD.hex(),
+           "codebook_sha16": hashlib.sha256(cb_pre.tobytes()).hexdigest()[:16], "timed_kernel_prefiltered": bool(prefiltered)}
+    # (2) first: the session still holds the level's last pass
+    sess.run_pass(sym, dmin)
+    sess.synchronize()
+    n = min(S, 32768)
+    sym_h = sym[:n].cpu().numpy().view(np.uint16)
+    dmin_h = dmin[:n].cpu().numpy()
+    if comm.rank == 0:
+        from tests import oracle_lib
 
+        oracle = oracle_lib.load()
+        sample = e.synth.synth_frames(SEED, N_CLASSES, P, lo, n)
+        sym_o, dmin_o = oracle.quantize(oracle.reflections_to_cq(cb_pre), sample)
+        bad = int(np.count_nonzero(sym_h != sym_o) + np.count_nonzero(dmin_h.view(np.uint64) != dmin_o.view(np.uint64)))
+        out["oracle_sample_frames"] = n
+        out["oracle_mismatches"] = bad
+        if comm.world == 1:
+            rows = sess.get_rows()
+            counts = np.bincount(sym.cpu().numpy().view(np.uint16), minlength=M)
+            out["cell_counts_match_symbols"] = bool(np.array_equal(rows[:, 2 * (P + 1)], counts))
+    # (1) the same level on the plain FP64 sweep
+    if prefiltered:
+        sess.set_prefilter(False)
+        lv_plain = whole_level()
+        cb_plain = sess.get_codebook()
+        plain_used, _ = sess.last_pass_info()
+        sess.set_prefilter(True)
+        out["equals_plain_sweep"] = bool(not plain_used and cb_plain.tobytes() == cb_pre.tobytes() and
+                                         lv_plain.passes == lv_pre.passes and lv_plain.DD.hex() == lv_pre.DD.hex())
+    else:
+        out["equals_plain_sweep"] = None  # (the timed kernel IS the plain sweep)
+    ok = out.get("oracle_mismatches", 0) == 0 and out["equals_plain_sweep"] is not False and \
+        out.get("cell_counts_match_symbols", True)
+    out["ok"] = bool(ok)
+    return out
+
+
+def run(args, comm):
+    import numpy as np
+    import torch
+
+    import ecoz2rs_amd as e
+
+    M = args.codebook_size
+    FLOP_PER_FRAME_PASS = 2 * M * (P + 1)
+    rank, world, local = comm.rank, comm.world, comm.local
     S = args.frames_per_gpu
     lo = rank * S
     frames = e.synth.synth_frames(SEED, N_CLASSES, P, lo, S)
 
     sess = e.VqSession(P, device=local)
-    parallel.bind_torch_stream(sess, local)  # session kernels + RCCL collectives on one torch stream
-    ar_calls = {"n": 0, "bytes": 0, "max_bytes": 0}
-    if world > 1 or args.force_collective:
-        inner = parallel.make_allreduce(local)
-
-        def counted(ptr, count, op, stream):
-            ar_calls["n"] += 1
-            ar_calls["bytes"] += 8 * count
-            ar_calls["max_bytes"] = max(ar_calls["max_bytes"], 8 * count)
-            inner(ptr, count, op, stream)
-
-        sess.set_allreduce(counted, rank, world)
+    comm.attach(sess)
     sess.set_frames(frames)  # H2D + blocked re-layout; resident from here on
     del frames
     sess.prepare()
@@ -224,7 +452,7 @@ def main():
     os.environ["ECOZ2_VQ_QUIET"] = "1"
     t_ladder = time.time()
     levels = sess.learn(0.05, M // 2)  # real LBG ladder 2..512 (untimed) -> realistic codebook state
-    torch.cuda.synchronize()
+    sess.synchronize()
     t_ladder = time.time() - t_ladder
     sess.save_state()  # the converged M / 2 codebook, its DD, and the rows and cells the next level's seeded first pass starts from
     sym = torch.empty(S, dtype=torch.int16, device=f"cuda:{local}")
@@ -251,10 +479,10 @@ def main():
         return st_
 
     def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        sess.synchronize()
+        torch.cuda.synchronize(local)
+        comm.barrier()
+        sess.synchronize()
 
     # warm-up: whole levels (at least one: it also tells how many passes the level takes on this data)
     lv = whole_level()
@@ -264,9 +492,10 @@ def main():
         whole_level()
         done += L
     sess.enable_timing(True)  # HIP events around the sweep kernel of every pass, summed inside the library
+    sess.enable_collective_timing(True)  # ... and around every call of the exchange
     fence()
     launches_before = sess.sweep_launch_counts()
-    ar_before = dict(ar_calls)
+    ar_before = comm.counters()
     t0 = time.perf_counter()
     steps_left = args.steps
     while steps_left >= L:
@@ -277,42 +506,28 @@ def main():
         st = leading_passes(steps_left)
     fence()
     dt = time.perf_counter() - t0
-    ar_timed = {k: ar_calls[k] - ar_before[k] for k in ("n", "bytes")}
+    ar_now = comm.counters()
+    ar_timed = {k: ar_now[k] - ar_before[k] for k in ("n", "bytes")}
     kernel_ms_total, kernel_passes = sess.timing_total()
     assert kernel_passes == args.steps, (kernel_passes, args.steps)
+    ar_ms, ar_n, ar_b = sess.collective_timing()
+    sess.enable_collective_timing(False)
     prefiltered, fallback_frames = sess.last_pass_info()
     launches_after = sess.sweep_launch_counts()
     timed_pre, timed_plain = launches_after[0] - launches_before[0], launches_after[1] - launches_before[1]
-    collective = None
-    if world == 1 and args.force_collective:
-        collective = {"backend": "nccl (one-rank group on this GPU: the host side of the exchange, no wire)", "world_size": 1,
-                      "allreduce_calls": ar_timed["n"], "allreduce_calls_per_step": ar_timed["n"] / max(1, args.steps),
-                      "bytes_per_call": ar_calls["max_bytes"], "bytes_timed_region": ar_timed["bytes"]}
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
-        if args.backend != "nccl":
-            t = t.cpu()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        devs = [None] * world
-        dist.all_gather_object(devs, local)
-        try:
-            rccl = ".".join(str(x) for x in torch.cuda.nccl.version()) if args.backend == "nccl" else None
-        except Exception:
-            rccl = None
-        collective = {
-            "backend": args.backend + (" (RCCL over xGMI)" if args.backend == "nccl" else " (host-staged rehearsal)"),
-            "world_size": world,
-            "devices_per_rank": 1,
-            "device_of_rank": devs,
-            "distinct_devices": len(set(devs)),
-            "allreduce_calls": ar_timed["n"],
-            "allreduce_calls_per_step": ar_timed["n"] / max(1, args.steps),
-            "bytes_per_call": ar_calls["max_bytes"],
-            "bytes_timed_region": ar_timed["bytes"],
-            "dtype": "int64 sum (exact: any rank count gives the same bits)",
-            "rccl_version": rccl,
-        }
+    dt = comm.max_over_ranks(dt)
+    collective = comm.describe(ar_timed)
+    if collective is not None:
+        # device time between the events the library records around its calls of the exchange (the collective's kernels and
+        # their wait for the other ranks), this rank, timed region
+        collective["allreduce_calls_timed"] = ar_n
+        collective["allreduce_bytes_per_call"] = ar_b // max(1, ar_n)
+        collective["allreduce_us_per_call"] = 1e3 * ar_ms / max(1, ar_n)
+        collective["allreduce_ms_per_step"] = ar_ms / max(1, args.steps)
+
+    parity = None
+    if not args.no_parity:
+        parity = parity_section(args, comm, sess, whole_level, sym, dmin, S, lo, M)
 
     extras = not args.no_extras
     steady_ms = steady_kernel_ms = e2e_s = q_rate = None
@@ -346,12 +561,14 @@ def main():
         m = 2
         while m <= M:
             sess.enable_timing(True)
+            sess.enable_collective_timing(collective is not None)
             fence()
             t0 = time.perf_counter()
             lvm = sess.learn(0.05, m)[0]
             fence()
             wall = time.perf_counter() - t0
             kms, kn = sess.timing_total()
+            lar_ms, lar_n, _ = sess.collective_timing()
             hbm_ms = BYTES_PER_FRAME_PASS * S / (HBM_PEAK_GBS * 1e9) * 1e3
             fp64_ms = 2.0 * m * (P + 1) * S / (FP64_PEAK_TFLOPS * 1e12) * 1e3
             f16_ms = F16_MFMA_FLOP_PER_FRAME_CODEWORD * m * S / (F16_PEAK_TFLOPS * 1e12) * 1e3
@@ -363,12 +580,16 @@ def main():
                 bound, bound_ms = "fp64 mfma (2 M (P+1) flop per frame-pass)", fp64_ms
             level_detail.append({"M": m, "passes": lvm.passes, "kernel_ms": kms / max(1, kn), "step_ms": wall / lvm.passes * 1e3,
                                  "bound": bound, "bound_ms": bound_ms, "frac_of_bound": bound_ms / (kms / max(1, kn))})
+            if collective is not None:
+                level_detail[-1]["allreduce_us_per_call"] = 1e3 * lar_ms / max(1, lar_n)
+                level_detail[-1]["allreduce_bytes"] = m * e.lib.e2vq_row_stride(P) * 8
             m *= 2
         sess.enable_timing(False)
+        sess.enable_collective_timing(False)
         if world == 1:
-            fr = torch.from_numpy(e.synth.synth_frames(SEED, N_CLASSES, P, lo, S)).cuda()
+            fr = torch.from_numpy(e.synth.synth_frames(SEED, N_CLASSES, P, lo, S)).cuda(local)
             for _ in range(3):
-                torch.cuda.synchronize()
+                torch.cuda.synchronize(local)
                 t0 = time.perf_counter()
                 sess.quantize_device(fr, S, sym, dmin)
                 sess.synchronize()
@@ -523,6 +744,7 @@ def main():
                          if prefiltered else "plain FP64 MFMA sweep",
                 "ladder_seconds_untimed": round(t_ladder, 3),
                 "final_avg_distortion": st.avg_distortion,
+                "parity": parity,
                 "timed_sweep_launches": {"prefiltered": timed_pre, "plain": timed_plain},
                 "steady_state": None if not extras else {
                     "what": "back-to-back iterations on the converged codebook (incremental accumulate nearly idle): "
@@ -562,8 +784,8 @@ def main():
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     sess.close()
-    if world > 1:
-        dist.destroy_process_group()
+    if parity is not None and not parity["ok"]:
+        raise SystemExit(f"bench.py: PARITY FAILED on rank {rank}: {parity}")
 
 
 if __name__ == "__main__":

@@ -8,6 +8,7 @@ GPU (so symbols can be inspected), every compute call raises when no HIP device 
 """
 from ._lib import lib, lib_path, Ecoz2Error, check  # noqa: F401
 from .vq import (  # noqa: F401
+    VqGroup,
     VqSession,
     LevelStats,
     vq_learn,

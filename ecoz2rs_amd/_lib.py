@@ -62,6 +62,15 @@ _sig("e2vq_session_create", C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p))
 _sig("e2vq_session_destroy", None, C.c_void_p)
 _sig("e2vq_set_stream", C.c_int, C.c_void_p, C.c_void_p)
 _sig("e2vq_set_allreduce", C.c_int, C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int)
+_sig("e2vq_enable_collective_timing", C.c_int, C.c_void_p, C.c_int)
+_sig("e2vq_collective_timing", C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+_sig("e2vq_set_prefilter", C.c_int, C.c_void_p, C.c_int)
+_sig("e2vq_group_create", C.c_int, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.POINTER(C.c_void_p))
+_sig("e2vq_group_bind", C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+_sig("e2vq_group_collective", C.c_char_p, C.c_void_p)
+_sig("e2vq_group_uses_rccl", C.c_int, C.c_void_p)
+_sig("e2vq_group_fail", None, C.c_void_p)
+_sig("e2vq_group_destroy", None, C.c_void_p)
 _sig("e2vq_set_frames_host", C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 _sig("e2vq_set_frames_device", C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 _sig("e2vq_prepare", C.c_int, C.c_void_p)

@@ -1644,15 +1644,19 @@ void launch_finish_q(const i64* stats, int NC, DevScalars* sc, hipStream_t s)
 // in-process multi-GPU exchange (reduce-scatter + all-gather in one kernel per rank): the launching rank owns words
 // [lo, hi); it reads them from every rank's buffer (peer access over xGMI), combines (64-bit integer sum or unsigned
 // max: exact, order-free) and writes the result back into every rank's buffer
+// (round 4: every word of another rank's buffer is read and written with SYSTEM-scope atomic accesses -- they bypass this
+// device's caches, so a peer device's earlier writes are seen and this kernel's results are visible to it without relying on
+// what a kernel boundary writes back or invalidates across devices; ordering between the ranks' kernels is carried by the
+// release-to-system events of local_allreduce.  Same-device ranks pay a few percent of a ~10 us kernel for it.)
 __global__ void k_reduce_slice_i64(PeerBuffers bufs, int n, long lo, long hi, int op)
 {
     for (long i = lo + (long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (long)gridDim.x * blockDim.x) {
-        i64 v = bufs.p[0][i];
+        i64 v = (i64)__hip_atomic_load((u64*)&bufs.p[0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         for (int k = 1; k < n; ++k) {
-            const i64 o = bufs.p[k][i];
-            v = op == 0 ? v + o : ((u64)o > (u64)v ? o : v);
+            const i64 o = (i64)__hip_atomic_load((u64*)&bufs.p[k][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            v = op == 0 ? (i64)((u64)v + (u64)o) : ((u64)o > (u64)v ? o : v);
         }
-        for (int k = 0; k < n; ++k) bufs.p[k][i] = v;
+        for (int k = 0; k < n; ++k) __hip_atomic_store((u64*)&bufs.p[k][i], (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -24,6 +24,7 @@
 #include <chrono>
 #include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -197,6 +198,12 @@ struct e2vq_session {
     void* ar_user = nullptr;
     int rank = 0, world = 1;
     bool ar_force = false;  // call the hook even for one rank (a 1-rank RCCL group: exercises the plumbing on one GPU)
+    // e2vq_enable_collective_timing: HIP events on the session's stream around every call of the hook
+    bool ar_timing = false;
+    struct ArTimed { hipEvent_t a, b; };
+    std::vector<ArTimed> ar_pending, ar_free;
+    double ar_ms = 0.0;
+    long ar_calls = 0, ar_bytes = 0;
 };
 
 static int ensure_codebook_capacity(e2vq_session* s, int M)
@@ -340,6 +347,11 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
                     s->d_ea_q, s->d_qfimg, s->d_qfg, s->d_qfblist, s->d_qcimg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto* list : {&s->ar_pending, &s->ar_free})
+        for (auto& ev : *list) {
+            (void)hipEventDestroy(ev.a);
+            (void)hipEventDestroy(ev.b);
+        }
     if (s->ev_stats) (void)hipEventDestroy(s->ev_stats);
     if (s->h_stats) (void)hipHostFree(s->h_stats);
     if (s->h_within) (void)hipHostFree(s->h_within);
@@ -376,8 +388,75 @@ static int reduce(e2vq_session* s, void* buf, i64 count, int op)
 {
     // ECOZ2_VQ_FORCE_ALLREDUCE: call the hook even for a single rank (tests exercise the RCCL plumbing on one GPU)
     if (!s->allreduce || (s->world <= 1 && !s->ar_force && !getenv("ECOZ2_VQ_FORCE_ALLREDUCE"))) return 0;
+    e2vq_session::ArTimed ev{nullptr, nullptr};
+    if (s->ar_timing) {
+        if (!s->ar_free.empty()) {
+            ev = s->ar_free.back();
+            s->ar_free.pop_back();
+        } else {
+            HIPCHK(hipEventCreate(&ev.a));
+            HIPCHK(hipEventCreate(&ev.b));
+        }
+        HIPCHK(hipEventRecord(ev.a, s->stream));
+    }
     const int rc = s->allreduce(s->ar_user, buf, count, op, (void*)s->stream);
     if (rc != 0) return e2vq_set_error("all-reduce hook failed (%d)", rc);
+    if (s->ar_timing) {
+        HIPCHK(hipEventRecord(ev.b, s->stream));
+        s->ar_pending.push_back(ev);
+        s->ar_calls += 1;
+        s->ar_bytes += (long)count * 8;
+    }
+    return 0;
+}
+
+// Device time of the exchange: events on the session's stream around every call of the all-reduce hook (what lies
+// between them is the collective's kernels and their wait for the other ranks).  e2vq_collective_timing synchronises the
+// stream and returns the totals since the timing was switched on.
+extern "C" int e2vq_enable_collective_timing(e2vq_session* s, int on)
+{
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (auto& ev : s->ar_pending) s->ar_free.push_back(ev);
+    s->ar_pending.clear();
+    s->ar_timing = on != 0;
+    s->ar_ms = 0.0;
+    s->ar_calls = s->ar_bytes = 0;
+    return 0;
+}
+
+extern "C" int e2vq_collective_timing(e2vq_session* s, double* total_ms, int64_t* calls, int64_t* bytes)
+{
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (auto& ev : s->ar_pending) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ev.a, ev.b));
+        s->ar_ms += ms;
+        s->ar_free.push_back(ev);
+    }
+    s->ar_pending.clear();
+    if (total_ms) *total_ms = s->ar_ms;
+    if (calls) *calls = s->ar_calls;
+    if (bytes) *bytes = s->ar_bytes;
+    return 0;
+}
+
+// Switches the prefiltered sweep off (every pass on the plain FP64 sweep) or back on for this session: same results
+// either way -- bench.py re-runs its timed level both ways in one process and compares the codebooks bit for bit.
+// (Switching it ON needs the images a session makes when it is created and given its frames with the prefilter enabled.)
+extern "C" int e2vq_set_prefilter(e2vq_session* s, int on)
+{
+    const bool want = on != 0;
+    if (want && !(s->d_ps2[0] && e2vq::prefilter_supports(s->NC, 64)))
+        return e2vq_set_error("this session has no prefilter images (created with ECOZ2_VQ_PREFILTER=0, or an unsupported order)");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->pre_enabled = want;
+    s->incr_valid = false;
+    s->fam_pending = false;
+    s->img_valid[0] = s->img_valid[1] = false;
+    s->spec_valid = false;
     return 0;
 }
 
@@ -1632,7 +1711,219 @@ int rccl_allreduce(void* user, void* buf, int64_t count, int op, void* stream_)
     return 0;
 }
 
+
+// ---- the in-process group as an object (round 4): what ecoz2_vq_learn builds for ECOZ2_VQ_GPUS > 1, exported so that a
+// host -- bench.py --in-process -- can drive one session per rank from its own threads and time the library's OWN
+// exchange (ncclAllReduce inside the library, or the peer-to-peer slice kernel), not a caller-supplied hook ----------------
+struct GroupImpl {
+    LocalGroup g;
+    int world = 0;
+    bool use_rccl = false;
+    std::vector<int> devs;
+    std::vector<LocalRank> ranks;
+    RcclComms rc_comms;
+    std::vector<RcclRank> rranks;
+    std::string what;  // one line describing the exchange
+    ~GroupImpl()
+    {
+        for (hipEvent_t ev : g.ev_ready)
+            if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : g.ev_done)
+            if (ev) (void)hipEventDestroy(ev);
+        if (g.failed) RcclComms::abort_all(&rc_comms);  // (a failed group may hold a collective that cannot complete)
+        std::lock_guard<std::mutex> lk(rc_comms.mu);
+        if (Rccl* api = rc_comms.comms.empty() ? nullptr : rccl_api())
+            for (void* c : rc_comms.comms)
+                if (c) (void)api->comm_destroy(c);
+    }
+};
+
+// more than one HIP runtime mapped into the process (a host application's bundled ROCm beside /opt/rocm's)?  An RCCL
+// initialised in that mix reports "no device" / "unhandled cuda error": say so instead of leaving the user with that.
+std::string hip_runtime_copies()
+{
+    FILE* f = fopen("/proc/self/maps", "r");
+    if (!f) return "";
+    std::vector<std::string> seen;
+    char line[4096];
+    while (fgets(line, sizeof line, f)) {
+        const char* p = strstr(line, "libamdhip64");
+        if (!p) continue;
+        const char* path = strchr(line, '/');
+        if (!path) continue;
+        std::string sp(path);
+        while (!sp.empty() && (sp.back() == '\n' || sp.back() == ' ')) sp.pop_back();
+        if (std::find(seen.begin(), seen.end(), sp) == seen.end()) seen.push_back(sp);
+    }
+    fclose(f);
+    if (seen.size() < 2) return "";
+    std::string out = "; " + std::to_string(seen.size()) + " copies of the HIP runtime are mapped into this process (";
+    for (size_t i = 0; i < seen.size(); ++i) out += (i ? ", " : "") + seen[i];
+    out += "): RCCL must be the one built against the runtime this library uses -- load the library before the other copy, "
+           "set ECOZ2_VQ_RCCL_LIB, or use ECOZ2_VQ_COLLECTIVE=p2p";
+    return out;
+}
+
+// devices[r] = HIP device of rank r.  collective: "rccl", "p2p" or "" (RCCL when every rank has a device of its own and
+// librccl.so loads, else the peer-to-peer kernel).  Returns null with the error message set.
+GroupImpl* group_create(int world, const int* devices, const std::string& coll, bool verbose)
+{
+    if (world < 1 || world > e2vq::E2VQ_MAX_LOCAL_RANKS) {
+        e2vq_set_error("%d in-process ranks: expected 1 .. %d", world, e2vq::E2VQ_MAX_LOCAL_RANKS);
+        return nullptr;
+    }
+    if (!coll.empty() && coll != "rccl" && coll != "p2p") {
+        e2vq_set_error("collective '%s': expected rccl or p2p", coll.c_str());
+        return nullptr;
+    }
+    std::unique_ptr<GroupImpl> G(new GroupImpl());
+    G->world = world;
+    G->g.n = world;
+    G->g.ev_ready.assign((size_t)world, nullptr);
+    G->g.ev_done.assign((size_t)world, nullptr);
+    G->devs.assign(devices, devices + world);
+    G->ranks.resize((size_t)world);
+    bool distinct = true;
+    for (int r = 0; r < world; ++r) {
+        G->ranks[(size_t)r] = LocalRank{&G->g, r, devices[r]};
+        for (int q = 0; q < r; ++q) distinct = distinct && devices[q] != devices[r];
+    }
+    bool use_rccl = coll == "rccl" || (coll.empty() && distinct);
+    if (use_rccl && !distinct) {
+        if (verbose) printf("collective: ranks share a device: RCCL needs one device per rank, using the peer-to-peer exchange\n");
+        use_rccl = false;
+    }
+    if (use_rccl && !rccl_api()) {
+        if (coll == "rccl") {
+            e2vq_set_error("collective rccl: librccl.so could not be loaded (dlopen failed)");
+            return nullptr;
+        }
+        if (verbose) printf("collective: librccl.so not found, using the peer-to-peer exchange\n");
+        use_rccl = false;
+    }
+    G->use_rccl = use_rccl;
+    if (use_rccl) {
+        Rccl* api = rccl_api();
+        G->rc_comms.comms.assign((size_t)world, nullptr);
+        // (RCCL reads the thread's last HIP error after some of its calls: one left behind by an earlier, handled
+        // condition -- an event polled before it completed, a probe for free memory -- would fail the initialisation)
+        (void)hipGetLastError();
+        const int rc = api->comm_init_all(G->rc_comms.comms.data(), world, G->devs.data());
+        if (rc != 0) {
+            e2vq_set_error("ncclCommInitAll over %d device(s) failed: %s%s", world, api->error_string ? api->error_string(rc) : "?",
+                           hip_runtime_copies().c_str());
+            return nullptr;
+        }
+        int ver = 0;
+        if (api->get_version) (void)api->get_version(&ver);
+        char buf[160];
+        snprintf(buf, sizeof buf, "RCCL %d.%d.%d, ncclAllReduce(int64 sum) per LBG iteration over %d rank(s)", ver / 10000,
+                 (ver / 100) % 100, ver % 100, world);
+        G->what = buf;
+        G->g.on_fail = RcclComms::abort_all;
+        G->g.on_fail_arg = &G->rc_comms;
+        G->rranks.resize((size_t)world);
+        for (int r = 0; r < world; ++r) G->rranks[(size_t)r] = RcclRank{&G->g, G->rc_comms.comms[(size_t)r], r, devices[r]};
+    } else {
+        char buf[160];
+        snprintf(buf, sizeof buf, "peer-to-peer reduce-scatter + all-gather kernel (int64 sum) per LBG iteration over %d rank(s)", world);
+        G->what = buf;
+        for (int r = 0; r < world; ++r) {
+            if (hipSetDevice(devices[r]) != hipSuccess ||
+                // (release-to-system events: a peer device waits on them before it reads this rank's words)
+                hipEventCreateWithFlags(&G->g.ev_ready[(size_t)r], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess ||
+                hipEventCreateWithFlags(&G->g.ev_done[(size_t)r], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) {
+                e2vq_set_error("in-process group: events on device %d could not be created", devices[r]);
+                return nullptr;
+            }
+        }
+        // every rank's slice kernel reads and writes every other rank's buffer: peer access between all pairs of distinct
+        // devices ("already enabled" is the only tolerated failure)
+        for (int a = 0; a < world; ++a)
+            for (int b = 0; b < world; ++b) {
+                const int from = devices[a], to = devices[b];
+                if (from == to) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, from, to) != hipSuccess || !can) {
+                    e2vq_set_error("device %d cannot access device %d (no peer path): the p2p collective needs P2P", from, to);
+                    return nullptr;
+                }
+                if (hipSetDevice(from) != hipSuccess) {
+                    e2vq_set_error("hipSetDevice(%d) failed", from);
+                    return nullptr;
+                }
+                const hipError_t pe = hipDeviceEnablePeerAccess(to, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+                    e2vq_set_error("hipDeviceEnablePeerAccess(%d -> %d) failed: %s", from, to, hipGetErrorString(pe));
+                    return nullptr;
+                }
+                (void)hipGetLastError();
+            }
+    }
+    if (verbose) printf("collective: %s\n", G->what.c_str());
+    return G.release();
+}
+
+// the exchange of rank r as a session hook
+void group_hook(GroupImpl* G, int r, e2vq_allreduce_fn* fn, void** user, bool* force)
+{
+    if (G->use_rccl) {
+        *fn = rccl_allreduce;
+        *user = &G->rranks[(size_t)r];
+    } else {
+        *fn = local_allreduce;
+        *user = &G->ranks[(size_t)r];
+    }
+    *force = G->use_rccl && G->world == 1;  // (a one-rank RCCL group exercises the plumbing on one GPU)
+}
+
 }  // namespace
+
+struct e2vq_group {
+    GroupImpl* impl;
+};
+
+extern "C" int e2vq_group_create(int num_ranks, const int* devices, const char* collective, e2vq_group** out)
+{
+    *out = nullptr;
+    if (!devices) return e2vq_set_error("e2vq_group_create: no device list");
+    const int ndev = e2vq_device_count();
+    for (int r = 0; r < num_ranks; ++r)
+        if (devices[r] < 0 || devices[r] >= ndev) return e2vq_set_error("rank %d: device %d not in [0, %d)", r, devices[r], ndev);
+    GroupImpl* G = group_create(num_ranks, devices, collective ? collective : "", false);
+    if (!G) return 1;
+    *out = new e2vq_group{G};
+    return 0;
+}
+
+extern "C" int e2vq_group_bind(e2vq_group* g, int rank, e2vq_session* s)
+{
+    if (!g || !s || rank < 0 || rank >= g->impl->world) return e2vq_set_error("e2vq_group_bind: bad arguments");
+    if (s->device != g->impl->devs[(size_t)rank])
+        return e2vq_set_error("rank %d of the group lives on device %d, the session on device %d", rank, g->impl->devs[(size_t)rank], s->device);
+    e2vq_allreduce_fn fn = nullptr;
+    void* user = nullptr;
+    bool force = false;
+    group_hook(g->impl, rank, &fn, &user, &force);
+    if (e2vq_set_allreduce(s, fn, user, rank, g->impl->world)) return 1;
+    s->ar_force = force;
+    return 0;
+}
+
+extern "C" const char* e2vq_group_collective(e2vq_group* g) { return g ? g->impl->what.c_str() : ""; }
+extern "C" int e2vq_group_uses_rccl(e2vq_group* g) { return g && g->impl->use_rccl ? 1 : 0; }
+// a rank that fails outside the library's calls (its thread gives up) releases the others from their rendezvous
+extern "C" void e2vq_group_fail(e2vq_group* g)
+{
+    if (g) g->impl->g.fail();
+}
+// every session bound to the group must have been destroyed (or have synchronised its stream) before
+extern "C" void e2vq_group_destroy(e2vq_group* g)
+{
+    if (!g) return;
+    delete g->impl;
+    delete g;
+}
 
 // ==========================================================================================
 // Part 1: the reference's entry points
@@ -1889,89 +2180,19 @@ static int learn_common(int P, double eps, const char* class_name, const double*
     // ---- in-process group: rank r on device (dev0 + r) % ndev, contiguous frame shards --------------------------
     printf("sharding over %d rank(s) on %d device(s)\n", world, ndev);
     if (world > e2vq::E2VQ_MAX_LOCAL_RANKS) return e2vq_set_error("ECOZ2_VQ_GPUS=%d exceeds %d in-process ranks", world, e2vq::E2VQ_MAX_LOCAL_RANKS);
-    LocalGroup g;
-    g.n = world;
-    g.ev_ready.assign((size_t)world, nullptr);
-    g.ev_done.assign((size_t)world, nullptr);
-    RcclComms rc_comms;  // RCCL communicators, one per rank
-    std::vector<void*>& comms = rc_comms.comms;
-    struct GroupCleanup {  // events and communicators are released on every return path
-        LocalGroup& g;
-        RcclComms& rc;
-        ~GroupCleanup()
-        {
-            for (hipEvent_t ev : g.ev_ready)
-                if (ev) (void)hipEventDestroy(ev);
-            for (hipEvent_t ev : g.ev_done)
-                if (ev) (void)hipEventDestroy(ev);
-            if (g.failed) RcclComms::abort_all(&rc);  // (a failed group may hold a collective that cannot complete)
-            std::lock_guard<std::mutex> lk(rc.mu);
-            if (Rccl* api = rc.comms.empty() ? nullptr : rccl_api())
-                for (void* c : rc.comms)
-                    if (c) (void)api->comm_destroy(c);
-        }
-    } cleanup{g, rc_comms};
-    std::vector<LocalRank> ranks((size_t)world);
     std::vector<int> devs((size_t)world);
-    bool distinct = world <= ndev;
-    for (int r = 0; r < world; ++r) {
-        ranks[r] = LocalRank{&g, r, (dev0 + r) % ndev};
-        devs[r] = ranks[r].device;
-    }
-    bool use_rccl = coll == "rccl" || (coll.empty() && distinct);
-    if (use_rccl && !distinct) {
-        printf("collective: %d ranks share %d device(s): RCCL needs one device per rank, using the peer-to-peer exchange\n", world, ndev);
-        use_rccl = false;
-    }
-    if (use_rccl && !rccl_api()) {
-        if (coll == "rccl") return e2vq_set_error("ECOZ2_VQ_COLLECTIVE=rccl: librccl.so could not be loaded (%s)", rccl_api() ? "" : "dlopen failed");
-        printf("collective: librccl.so not found, using the peer-to-peer exchange\n");
-        use_rccl = false;
-    }
-    std::vector<RcclRank> rranks((size_t)world);
+    for (int r = 0; r < world; ++r) devs[(size_t)r] = (dev0 + r) % ndev;
+    std::unique_ptr<GroupImpl> G(group_create(world, devs.data(), coll, true));  // (events and communicators go with it on every return path)
+    if (!G) return 1;
+    LocalGroup& g = G->g;
+    const bool use_rccl = G->use_rccl;
+    std::vector<LocalRank>& ranks = G->ranks;
+    std::vector<RcclRank>& rranks = G->rranks;
     std::vector<RankCtx> ctx((size_t)world);
-    if (use_rccl) {
-        Rccl* api = rccl_api();
-        comms.assign((size_t)world, nullptr);
-        // (RCCL reads the thread's last HIP error after some of its calls: one left behind by an earlier, handled
-        // condition -- an event polled before it completed, a probe for free memory -- would fail the initialisation)
-        (void)hipGetLastError();
-        const int rc = api->comm_init_all(comms.data(), world, devs.data());
-        if (rc != 0) return e2vq_set_error("ncclCommInitAll over %d device(s) failed: %s", world, api->error_string ? api->error_string(rc) : "?");
-        int ver = 0;
-        if (api->get_version) (void)api->get_version(&ver);
-        printf("collective: RCCL %d.%d.%d, ncclAllReduce(int64 sum) per LBG iteration over %d rank(s)\n", ver / 10000, (ver / 100) % 100,
-               ver % 100, world);
-        g.on_fail = RcclComms::abort_all;
-        g.on_fail_arg = &rc_comms;
-        for (int r = 0; r < world; ++r) {
-            rranks[r] = RcclRank{&g, comms[r], r, devs[r]};
-            ctx[r] = RankCtx{&g, r, rccl_allreduce, &rranks[r], world == 1};
-        }
-    } else {
-        printf("collective: peer-to-peer reduce-scatter + all-gather kernel (int64 sum) per LBG iteration over %d rank(s)\n", world);
-        for (int r = 0; r < world; ++r) {
-            HIPCHK(hipSetDevice(ranks[r].device));
-            // (release-to-system events: a peer device waits on them before it reads this rank's words)
-            HIPCHK(hipEventCreateWithFlags(&g.ev_ready[r], hipEventDisableTiming | hipEventReleaseToSystem));
-            HIPCHK(hipEventCreateWithFlags(&g.ev_done[r], hipEventDisableTiming | hipEventReleaseToSystem));
-            ctx[r] = RankCtx{&g, r, local_allreduce, &ranks[r], false};
-        }
-        // every rank's slice kernel reads and writes every other rank's buffer: peer access between all pairs of distinct
-        // devices ("already enabled" is the only tolerated failure)
-        for (int a = 0; a < world; ++a)
-            for (int b = 0; b < world; ++b) {
-                const int from = ranks[a].device, to = ranks[b].device;
-                if (from == to) continue;
-                int can = 0;
-                HIPCHK(hipDeviceCanAccessPeer(&can, from, to));
-                if (!can) return e2vq_set_error("device %d cannot access device %d (no peer path): ECOZ2_VQ_COLLECTIVE=p2p needs P2P", from, to);
-                HIPCHK(hipSetDevice(from));
-                const hipError_t pe = hipDeviceEnablePeerAccess(to, 0);
-                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
-                    return e2vq_set_error("hipDeviceEnablePeerAccess(%d -> %d) failed: %s", from, to, hipGetErrorString(pe));
-                (void)hipGetLastError();
-            }
+    for (int r = 0; r < world; ++r) {
+        ctx[(size_t)r].g = &g;
+        ctx[(size_t)r].rank = r;
+        group_hook(G.get(), r, &ctx[(size_t)r].fn, &ctx[(size_t)r].user, &ctx[(size_t)r].force);
     }
     std::vector<int> rcs((size_t)world, 0);
     std::vector<std::thread> th;

@@ -100,6 +100,37 @@ def _ptr(x):
     return int(x)
 
 
+class VqGroup:
+    """The library's in-process group (what ecoz2_vq_learn builds for ECOZ2_VQ_GPUS > 1): rank r on devices[r], the
+    exchange inside the library -- RCCL (one device per rank) or its peer-to-peer kernel.  Drive one VqSession per rank
+    from one thread per rank (ctypes releases the GIL during the calls): every rank makes the same calls."""
+
+    def __init__(self, devices, collective=None):
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        self._h = C.c_void_p()
+        check(lib.e2vq_group_create(len(self.devices), arr, collective.encode() if collective else None, C.byref(self._h)))
+
+    def bind(self, rank, session):
+        check(lib.e2vq_group_bind(self._h, int(rank), session._h))
+
+    @property
+    def collective(self):
+        return lib.e2vq_group_collective(self._h).decode()
+
+    @property
+    def uses_rccl(self):
+        return bool(lib.e2vq_group_uses_rccl(self._h))
+
+    def fail(self):
+        lib.e2vq_group_fail(self._h)
+
+    def close(self):
+        if self._h:
+            lib.e2vq_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+
 class VqSession:
     """One resident training set + codebook on one GPU (one rank of a sharded run)."""
 
@@ -142,6 +173,19 @@ class VqSession:
 
     def synchronize(self):
         check(lib.e2vq_synchronize(self._h))
+
+    def enable_collective_timing(self, on=True):
+        check(lib.e2vq_enable_collective_timing(self._h, int(on)))
+
+    def collective_timing(self):
+        """(device ms between the events around the all-reduce hook, calls, bytes) since enable_collective_timing(True)"""
+        ms, n, b = C.c_double(), C.c_int64(), C.c_int64()
+        check(lib.e2vq_collective_timing(self._h, C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, n.value, b.value
+
+    def set_prefilter(self, on):
+        """False: every pass on the plain FP64 sweep; True: the prefiltered sweep again (same results)"""
+        check(lib.e2vq_set_prefilter(self._h, int(bool(on))))
 
     # -- training set -----------------------------------------------------------------
     def set_frames(self, frames):

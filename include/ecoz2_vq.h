@@ -140,6 +140,29 @@ void e2vq_session_destroy(e2vq_session *s);
 /* use an existing hipStream_t (e.g. torch's current stream); NULL = the session's own */
 int e2vq_set_stream(e2vq_session *s, void *hip_stream);
 int e2vq_set_allreduce(e2vq_session *s, e2vq_allreduce_fn fn, void *user, int rank, int world);
+/* Device time of the exchange: HIP events on the session's stream around every call of the all-reduce hook.
+ * e2vq_collective_timing synchronises the stream and returns the totals since the timing was switched on. */
+int e2vq_enable_collective_timing(e2vq_session *s, int on);
+int e2vq_collective_timing(e2vq_session *s, double *total_ms, int64_t *calls, int64_t *bytes);
+/* 0 = every pass of this session on the plain FP64 sweep, 1 = prefiltered sweep again (same results either way: bench.py
+ * re-runs its timed level both ways in one process and compares the codebooks bit for bit).  Switching it on needs the
+ * images a session makes when it is created and given its frames with the prefilter enabled. */
+int e2vq_set_prefilter(e2vq_session *s, int on);
+
+/* In-process group: the ranks ecoz2_vq_learn runs for ECOZ2_VQ_GPUS > 1, as an object a host can drive from its own
+ * threads -- one session per rank, rank r on devices[r].  collective: "rccl" (ncclCommInitAll + ncclAllReduce(int64) inside
+ * the library, librccl.so loaded with dlopen: one device per rank), "p2p" (the library's reduce-scatter + all-gather kernel
+ * over peer-to-peer memory: ranks may share devices), or NULL / "" (RCCL when every rank has a device of its own and
+ * librccl.so loads, else p2p).  e2vq_group_bind makes the group's exchange the all-reduce of a session (which must live on
+ * the rank's device); the exchange is a rendezvous -- every rank's thread must make the same calls.  A rank that gives up
+ * calls e2vq_group_fail so that the others return with an error instead of waiting.  Destroy the sessions first. */
+typedef struct e2vq_group e2vq_group;
+int e2vq_group_create(int num_ranks, const int *devices, const char *collective, e2vq_group **out);
+int e2vq_group_bind(e2vq_group *g, int rank, e2vq_session *s);
+const char *e2vq_group_collective(e2vq_group *g); /* one line: which exchange the group uses */
+int e2vq_group_uses_rccl(e2vq_group *g);
+void e2vq_group_fail(e2vq_group *g);
+void e2vq_group_destroy(e2vq_group *g);
 
 /* training set: T x (P+1) doubles, row-major (the .prd payload), T <= 2^31 - 65. Copies / re-lays it out in HBM.
  * e2vq_set_frames_device reads `device_frames` on the session's stream: the caller must have finished writing the

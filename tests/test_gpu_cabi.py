@@ -552,6 +552,36 @@ def test_bench_starts_its_own_ranks():
     assert r.returncode != 0
 
 
+def test_bench_in_process_group_and_parity_section():
+    """`bench.py --gpus 2 --in-process`: the two ranks are host threads driving one session each through the library's OWN
+    in-process group (e2vq_group_*: what ecoz2_vq_learn runs for ECOZ2_VQ_GPUS=2) -- on this 1-GPU box both ranks share the
+    device, so the exchange is the library's peer-to-peer kernel; on a node with a GPU per rank the same command times
+    ncclAllReduce on the RCCL the library loads.  The line carries the exchange's device time per call and the untimed parity
+    section: the timed level re-run on the plain FP64 sweep gives the same codebook, and the timed kernel's per-frame outputs
+    equal the strict oracle's on a sample."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--in-process",
+                        "--steps", "6", "--frames-per-gpu", str(1 << 18), "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    c = d["config"]["collective"]
+    assert c["world_size"] == 2 and "in-process group" in c["exchange"] and "rank(s)" in c["library_says"]
+    assert c["allreduce_calls_timed"] >= 6 and c["allreduce_us_per_call"] > 0
+    assert c["allreduce_bytes_per_call"] == 1024 * e.lib.e2vq_row_stride(P) * 8
+    par = d["config"]["parity"]
+    assert par["ok"] and par["equals_plain_sweep"] is True and par["oracle_mismatches"] == 0 and par["oracle_sample_frames"] == 32768
+    # one rank, process mode: the same section, with the cell counts checked against the symbols as well
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--frames-per-gpu", str(1 << 17), "--no-extras",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    par = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["config"]["parity"]
+    assert par["ok"] and par["equals_plain_sweep"] is True and par["oracle_mismatches"] == 0 and par["cell_counts_match_symbols"] is True
+
+
 def test_rccl_inside_the_library_single_rank_group(tmp_path):
     """ECOZ2_VQ_COLLECTIVE=rccl: libecoz2vq.so loads librccl.so itself (dlopen), builds a communicator with
     ncclCommInitAll over the in-process ranks' devices and all-reduces the int64 cell sums with ncclAllReduce on the
