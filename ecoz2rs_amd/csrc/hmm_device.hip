@@ -279,6 +279,16 @@ __global__ __launch_bounds__(64 * FB_WAVES) void k_hmm_fb(ModelDev md, const uns
 
 // ---- more than 64 states: one workgroup per sequence, thread j = state j -------------------------------------------
 // LDS: xs[N] (the values the next sum runs over), ys[N].  grid: (S, models of this launch) for scoring.
+// LDSA (round 4, the E-step kernel k_hmm_fb_wg at N <= WG_LDS_N = 141): the transition matrix is staged in LDS with an odd
+// leading dimension, so that both the forward pass (fixed i, consecutive j across the threads) and the backward pass (row j:
+// stride ld across the threads) read it without bank conflicts -- one read of A per persistent workgroup instead of three
+// per symbol.  Same values, same order of operations: same bits.  (E+M step at N = 141 / 142: 182 / 277 ms per 1 024 x 300 symbols.)
+__host__ __device__ constexpr int wg_lda(int N) { return N | 1; }
+__host__ __device__ constexpr size_t wg_lds_bytes(int N, bool ldsa) { return (size_t)2 * N * 8 + (ldsa ? (size_t)N * wg_lda(N) * 8 : 0); }
+constexpr int WG_LDS_N = 141;  // 141 x 141 doubles + 2 x 141 = 161 292 B of the CU's 163 840
+
+// (k_hmm_score_wg keeps reading A from global memory / L2: staged in LDS a workgroup -- one (sequence, model) pair -- would
+// copy up to 159 KB for ~300 steps and be alone on its CU; measured at N = 141: 43 ms against 34 for 1 024 x 8 pairs)
 __global__ void k_hmm_score_wg(const ModelDev* __restrict__ models, int K, int k0, const unsigned short* __restrict__ sym,
                                const i64* __restrict__ offs, int S, double* __restrict__ mant, i64* __restrict__ exp2,
                                int* __restrict__ status)
@@ -333,6 +343,7 @@ __global__ void k_hmm_score_wg(const ModelDev* __restrict__ models, int K, int k
 }
 
 // E-step.  scratch: gridDim.x tables of 2 N^2 words (zeroed here, flushed to AN with atomics at the end).
+template <bool LDSA>
 __global__ void k_hmm_fb_wg(ModelDev md, const unsigned short* __restrict__ sym, const i64* __restrict__ offs, int S,
                             double* __restrict__ alpha_buf, double* __restrict__ c_buf, i64* __restrict__ acc,
                             double* __restrict__ mant, i64* __restrict__ exp2, int* __restrict__ status,
@@ -345,6 +356,15 @@ __global__ void k_hmm_fb_wg(ModelDev md, const unsigned short* __restrict__ sym,
     const int j = threadIdx.x;
     const bool act = j < N;
     const int jj = act ? j : 0;
+    // LDSA: the transition matrix in LDS, odd leading dimension (wg_lda)
+    const int ld = LDSA ? wg_lda(N) : N;
+    double* As = ys + N;
+    const double* Ag = md.A;
+    if constexpr (LDSA) {
+        for (int x = threadIdx.x; x < N * N; x += blockDim.x) As[(x / N) * ld + (x % N)] = md.A[x];
+        __syncthreads();
+    }
+    auto Aat = [&](int r, int c) -> double { return LDSA ? As[r * ld + c] : Ag[(size_t)r * N + c]; };
     i64* PI = acc;
     i64* AN = PI + 2 * N;
     i64* AD = AN + 2 * (i64)N * N;
@@ -377,7 +397,7 @@ __global__ void k_hmm_fb_wg(ModelDev md, const unsigned short* __restrict__ sym,
                 nx = md.pi[jj] * b;
             } else {
                 double a = 0.0;
-                for (int i = 0; i < N; ++i) a = fma(xs[i], md.A[(size_t)i * N + jj], a);
+                for (int i = 0; i < N; ++i) a = fma(xs[i], Aat(i, jj), a);
                 nx = a * b;
             }
             if (act) ys[j] = nx;
@@ -424,7 +444,7 @@ __global__ void k_hmm_fb_wg(ModelDev md, const unsigned short* __restrict__ sym,
                 if (act) {
                     // xi_t(i, j) = (alpha^_t(i) A_ij) u_j: column j of the workgroup's table
                     for (int i = 0; i < N; ++i) {
-                        const double x = (xs[i] * md.A[(size_t)i * N + j]) * u;
+                        const double x = (xs[i] * Aat(i, j)) * u;
                         int hi, lo;
                         e2vq::fix2(x, ACC_SHIFT, hi, lo);
                         ANw[2 * ((size_t)i * N + j)] += (i64)hi;
@@ -433,7 +453,7 @@ __global__ void k_hmm_fb_wg(ModelDev md, const unsigned short* __restrict__ sym,
                 }
                 // beta^_t(j) = chain_i fma(A_ji, u_i)  (row j of A)
                 double a = 0.0;
-                for (int i = 0; i < N; ++i) a = fma(md.A[(size_t)jj * N + i], ys[i], a);
+                for (int i = 0; i < N; ++i) a = fma(Aat(jj, i), ys[i], a);
                 beta = a;
             }
             if (act) {
@@ -544,8 +564,14 @@ void launch_fb(const ModelDev& md, const unsigned short* sym, const i64* offs, i
     if (S < 1) return;
     if (md.N > WAVE_N) {
         const int grid = S < FB_WG_GRID ? S : FB_WG_GRID;
-        hipLaunchKernelGGL(k_hmm_fb_wg, dim3((unsigned)grid), dim3((unsigned)((md.N + 63) & ~63)), (size_t)2 * md.N * 8, st, md,
-                           sym, offs, S, alpha_buf, c_buf, acc, mant, exp2, status, scratch);
+        if (md.N <= WG_LDS_N) {
+            (void)hipFuncSetAttribute((const void*)k_hmm_fb_wg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(k_hmm_fb_wg<true>, dim3((unsigned)grid), dim3((unsigned)((md.N + 63) & ~63)), wg_lds_bytes(md.N, true),
+                               st, md, sym, offs, S, alpha_buf, c_buf, acc, mant, exp2, status, scratch);
+        } else {
+            hipLaunchKernelGGL(k_hmm_fb_wg<false>, dim3((unsigned)grid), dim3((unsigned)((md.N + 63) & ~63)), wg_lds_bytes(md.N, false),
+                               st, md, sym, offs, S, alpha_buf, c_buf, acc, mant, exp2, status, scratch);
+        }
         return;
     }
     const size_t lds = (size_t)md.N * md.N * (2 * 8 + 16);  // A, A^T, and the workgroup's AN limb table: 128 KB at N = 64

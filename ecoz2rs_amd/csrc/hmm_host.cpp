@@ -22,6 +22,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <string>
 #include <thread>
@@ -753,82 +754,226 @@ extern "C" int ecoz2_hmm_classify_predictors(const char* const* model_filenames,
             return e2vq_set_error("%s: model has M=%d but codebook %s has M=%d", model_filenames[k], models[k].M, cb_filenames[found], cbs[found].M);
         cb_of[k] = found;
     }
-    // predictors: all frames of all files in one host array (file order = case order)
+    // predictors: headers only here (file order = case order); the frames are streamed below
     std::vector<std::string> files, classes;
     std::vector<i64> offs(1, 0);
-    std::vector<double> frames;
+    i64 max_T = 0;
     for (int f = 0; f < num_predictors; ++f) {
         char cls[96];
         int p;
         int64_t T;
         if (e2vq_prd_info(prd_filenames[f], cls, &p, &T)) return 1;
         if (p != P) return e2vq_set_error("%s: prediction order %d differs from the codebooks' %d", prd_filenames[f], p, P);
-        const size_t at = frames.size();
-        frames.resize(at + (size_t)T * (P + 1));
-        if (T > 0 && e2vq_prd_read(prd_filenames[f], frames.data() + at, T)) return 1;
         files.push_back(prd_filenames[f]);
         classes.push_back(cls);
         offs.push_back(offs.back() + T);
+        max_T = std::max<i64>(max_T, T);
     }
-    for (double v : frames)
-        if (!(fabs(v) <= 1.79769313486231570815e+308)) return e2vq_set_error("predictor files contain NaN or infinite values");
     const i64 total = offs.back();
     const int S = (int)files.size();
     printf("number of HMM models: %u  number of codebooks: %d  number of predictor files: %d (%lld vectors)\n", num_models,
            num_codebooks, S, (long long)total);
-    // device: each of the ECOZ2_VQ_GPUS workers takes a contiguous share of the files -- its frames once, symbols per
-    // codebook, scores per model (files are independent: same scores for any worker count)
+    // Bounded memory (round 4): the corpus is cut into UNITS of whole files holding at most CHUNK frames together
+    // (ECOZ2_VQ_CLASSIFY_CHUNK, default 2^18 = 78 MB at P = 36; at most 65 536 files), which the ECOZ2_VQ_GPUS workers pull
+    // from a shared counter.  A unit's frames go through one of the worker's two pinned slots to the device, are quantised
+    // against each codebook in turn and scored at once under that codebook's models: only the unit's symbols are ever
+    // resident besides its frames.  Reading unit u + 1 from the files overlaps the device's work on unit u.  A file longer
+    // than a chunk is a unit of its own: its frames stream through the slot piece by piece into the symbol buffer (once per
+    // codebook), then its one sequence is scored.  Files are independent: the same scores for any chunk size and any
+    // number of workers.
+    const char* chv = getenv("ECOZ2_VQ_CLASSIFY_CHUNK");
+    const i64 CHUNK = std::max<i64>(64, chv && *chv ? atoll(chv) : (1 << 18));
+    constexpr int MAX_UNIT_FILES = 65536;
+    struct Unit {
+        int f0, f1;
+    };
+    std::vector<Unit> units;
+    for (int f = 0; f < S;) {
+        int g = f;
+        i64 n = 0;
+        while (g < S && g - f < MAX_UNIT_FILES && (g == f || n + (offs[(size_t)g + 1] - offs[(size_t)g]) <= CHUNK)) {
+            n += offs[(size_t)g + 1] - offs[(size_t)g];
+            ++g;
+            if (n > CHUNK) break;  // (a single file longer than a chunk)
+        }
+        units.push_back(Unit{f, g});
+        f = g;
+    }
+    int max_files = 1;
+    for (const Unit& u : units) max_files = std::max(max_files, u.f1 - u.f0);
+    // which models each codebook feeds
+    struct Group {
+        int cb;
+        std::vector<const Hmm*> ms;
+        std::vector<unsigned> idx;
+    };
+    std::vector<Group> groups;
+    for (int c = 0; c < num_codebooks; ++c) {
+        Group gr;
+        gr.cb = c;
+        for (unsigned k = 0; k < num_models; ++k)
+            if (cb_of[k] == c) {
+                gr.ms.push_back(&models[k]);
+                gr.idx.push_back(k);
+            }
+        if (!gr.ms.empty()) groups.push_back(std::move(gr));
+    }
     std::vector<double> lp((size_t)S * num_models, -INFINITY);
-    const int workers = std::min(env_workers(), std::max(1, S));
+    std::atomic<int> next_unit{0};
+    std::atomic<bool> failed{false};
+    const int workers = std::min(env_workers(), std::max(1, (int)units.size()));
+    const int NC = P + 1;
     if (run_workers(workers, [&](int w) -> int {
-            int f0, f1;
-            share_of(S, workers, w, &f0, &f1);
             const int dev = workers == 1 ? device : device_of_worker(w);
             if (require_device(dev)) return 1;
-            const i64 a = offs[(size_t)f0], n_fr = offs[(size_t)f1] - a;
-            const int Sw = f1 - f0;
-            std::vector<i64> loffs;
-            for (int i = f0; i <= f1; ++i) loffs.push_back(offs[(size_t)i] - a);
-            e2vq_session* vq = nullptr;
-            if (e2vq_session_create(dev, P, &vq)) return 1;
-            struct SessionGuard {
-                e2vq_session* s;
-                ~SessionGuard() { e2vq_session_destroy(s); }
-            } guard{vq};
             Stream st;
             if (st.create()) return 1;
-            if (e2vq_set_stream(vq, (void*)st.s)) return 1;  // quantize and scoring are ordered on one stream
-            DevBuf<double> d_frames;
-            DevBuf<unsigned short> d_sym;
-            DevBuf<i64> d_offs;
-            if (d_frames.upload(frames.data() + (size_t)a * (P + 1), (size_t)n_fr * (P + 1), st.s) || d_sym.alloc((size_t)n_fr + 64) ||
-                d_offs.upload(loffs.data(), loffs.size(), st.s))
-                return 1;
-            for (int c = 0; c < num_codebooks; ++c) {
-                std::vector<const Hmm*> ms;
-                std::vector<unsigned> idx;
-                for (unsigned k = 0; k < num_models; ++k)
-                    if (cb_of[k] == c) {
-                        ms.push_back(&models[k]);
-                        idx.push_back(k);
-                    }
-                if (ms.empty()) continue;
-                if (e2vq_set_codebook(vq, cbs[c].refl.data(), cbs[c].M)) return 1;
-                const i64 CH = 1 << 24;  // frames per quantize call
-                for (i64 t0 = 0; t0 < n_fr; t0 += CH) {
-                    const i64 n = std::min(CH, n_fr - t0);
-                    if (e2vq_quantize_device(vq, d_frames.p + (size_t)t0 * (P + 1), n, d_sym.p + t0, nullptr)) return 1;
+            // one quantize session per codebook (its codeword images are built once), all on the worker's stream
+            struct Sessions {
+                std::vector<e2vq_session*> v;
+                ~Sessions()
+                {
+                    for (e2vq_session* s : v)
+                        if (s) e2vq_session_destroy(s);
                 }
-                std::vector<double> part;
-                if (score_device(ms, d_sym.p, d_offs.p, Sw, st.s, part)) return 1;
-                for (int q = 0; q < Sw; ++q)
-                    for (size_t j = 0; j < idx.size(); ++j)
-                        lp[(size_t)(f0 + q) * num_models + idx[j]] = part[(size_t)q * idx.size() + j];
+            } sessions;
+            std::vector<DevModels> dms(groups.size());
+            for (size_t g = 0; g < groups.size(); ++g) {
+                e2vq_session* vq = nullptr;
+                if (e2vq_session_create(dev, P, &vq)) return 1;
+                sessions.v.push_back(vq);
+                if (e2vq_set_stream(vq, (void*)st.s)) return 1;  // quantize and scoring are ordered on one stream
+                if (e2vq_set_codebook(vq, cbs[(size_t)groups[g].cb].refl.data(), cbs[(size_t)groups[g].cb].M)) return 1;
+                if (dms[g].upload(groups[g].ms, st.s)) return 1;
             }
-            HIPCHK(hipStreamSynchronize(st.s));  // (`loffs` is a local)
+            struct Slot {
+                double* h_frames = nullptr;
+                i64* h_offs = nullptr;
+                double* h_mant = nullptr;
+                i64* h_exp = nullptr;
+                int* h_st = nullptr;
+                DevBuf<double> d_frames, d_mant;
+                DevBuf<unsigned short> d_sym;
+                DevBuf<i64> d_offs, d_exp;
+                DevBuf<int> d_st;
+                hipEvent_t done = nullptr;
+                int unit = -1;
+                ~Slot()
+                {
+                    for (void* p : {(void*)h_frames, (void*)h_offs, (void*)h_mant, (void*)h_exp, (void*)h_st})
+                        if (p) (void)hipHostFree(p);
+                    if (done) (void)hipEventDestroy(done);
+                }
+            } slots[2];
+            const size_t res_cap = (size_t)max_files * num_models;
+            const size_t sym_cap = (size_t)std::max<i64>(CHUNK, max_T) + 64;
+            for (Slot& q : slots) {
+                HIPCHK(hipHostMalloc((void**)&q.h_frames, (size_t)CHUNK * NC * 8, hipHostMallocDefault));
+                HIPCHK(hipHostMalloc((void**)&q.h_offs, (size_t)(max_files + 1) * 8, hipHostMallocDefault));
+                HIPCHK(hipHostMalloc((void**)&q.h_mant, res_cap * 8, hipHostMallocDefault));
+                HIPCHK(hipHostMalloc((void**)&q.h_exp, res_cap * 8, hipHostMallocDefault));
+                HIPCHK(hipHostMalloc((void**)&q.h_st, res_cap * 4, hipHostMallocDefault));
+                if (q.d_frames.alloc((size_t)CHUNK * NC) || q.d_sym.alloc(sym_cap) || q.d_offs.alloc((size_t)max_files + 1) ||
+                    q.d_mant.alloc(res_cap) || q.d_exp.alloc(res_cap) || q.d_st.alloc(res_cap))
+                    return 1;
+                HIPCHK(hipEventCreateWithFlags(&q.done, hipEventDisableTiming));
+            }
+            // results of the unit in flight in a slot -> lp (layout on the device: group after group, [sequence][model of the group])
+            auto harvest = [&](Slot& q) -> int {
+                if (q.unit < 0) return 0;
+                HIPCHK(hipEventSynchronize(q.done));
+                const Unit& u = units[(size_t)q.unit];
+                const int Su = u.f1 - u.f0;
+                size_t base = 0;
+                for (const Group& gr : groups) {
+                    const size_t K = gr.idx.size();
+                    for (int sq = 0; sq < Su; ++sq)
+                        for (size_t j = 0; j < K; ++j) {
+                            const size_t o = base + (size_t)sq * K + j;
+                            lp[(size_t)(u.f0 + sq) * num_models + gr.idx[j]] =
+                                q.h_st[o] == 0 ? log_prob(q.h_mant[o], q.h_exp[o]) : -INFINITY;
+                        }
+                    base += (size_t)Su * K;
+                }
+                q.unit = -1;
+                return 0;
+            };
+            auto score_groups = [&](Slot& q, int Su, size_t g0, size_t g1, size_t base) -> int {  // groups [g0, g1) on q.d_sym
+                for (size_t g = g0; g < g1; ++g) {
+                    const int K = (int)groups[g].idx.size();
+                    e2hmm::launch_score(dms[g].table.p, K, dms[g].maxN, q.d_sym.p, q.d_offs.p, Su, q.d_mant.p + base,
+                                        q.d_exp.p + base, q.d_st.p + base, st.s);
+                    HIPCHK(hipGetLastError());
+                    base += (size_t)Su * K;
+                }
+                return 0;
+            };
+            int turn = 0;
+            while (!failed.load()) {
+                const int ui = next_unit.fetch_add(1);
+                if (ui >= (int)units.size()) break;
+                Slot& q = slots[turn & 1];
+                ++turn;
+                if (harvest(q)) return 1;
+                const Unit& u = units[(size_t)ui];
+                const int Su = u.f1 - u.f0;
+                const i64 n_fr = offs[(size_t)u.f1] - offs[(size_t)u.f0];
+                for (int f = u.f0; f <= u.f1; ++f) q.h_offs[f - u.f0] = offs[(size_t)f] - offs[(size_t)u.f0];
+                HIPCHK(hipMemcpyAsync(q.d_offs.p, q.h_offs, (size_t)(Su + 1) * 8, hipMemcpyHostToDevice, st.s));
+                size_t n_res = 0;
+                for (const Group& gr : groups) n_res += (size_t)Su * gr.idx.size();
+                if (n_fr <= CHUNK) {
+                    for (int f = u.f0; f < u.f1; ++f) {
+                        const i64 T = offs[(size_t)f + 1] - offs[(size_t)f];
+                        bool fin = true;
+                        if (T > 0 && e2vq_io::prd_read_range_mt(files[(size_t)f].c_str(), P, 0, T,
+                                                                q.h_frames + (size_t)(offs[(size_t)f] - offs[(size_t)u.f0]) * NC,
+                                                                e2vq_io::io_threads(), &fin))
+                            return 1;
+                        if (!fin) return e2vq_set_error("%s: contains NaN or infinite values", files[(size_t)f].c_str());
+                    }
+                    if (n_fr > 0) HIPCHK(hipMemcpyAsync(q.d_frames.p, q.h_frames, (size_t)n_fr * NC * 8, hipMemcpyHostToDevice, st.s));
+                    size_t base = 0;
+                    for (size_t g = 0; g < groups.size(); ++g) {
+                        if (n_fr > 0 && e2vq_quantize_device(sessions.v[g], q.d_frames.p, n_fr, q.d_sym.p, nullptr)) return 1;
+                        if (score_groups(q, Su, g, g + 1, base)) return 1;
+                        base += (size_t)Su * groups[g].idx.size();
+                    }
+                } else {
+                    // one file longer than a chunk: piece by piece into the symbol buffer, once per codebook (synchronous:
+                    // the one staging buffer is refilled for every piece)
+                    size_t base = 0;
+                    for (size_t g = 0; g < groups.size(); ++g) {
+                        for (i64 t0 = 0; t0 < n_fr; t0 += CHUNK) {
+                            const i64 n = std::min(CHUNK, n_fr - t0);
+                            bool fin = true;
+                            HIPCHK(hipStreamSynchronize(st.s));  // (the previous piece has left the staging buffer)
+                            if (e2vq_io::prd_read_range_mt(files[(size_t)u.f0].c_str(), P, t0, n, q.h_frames, e2vq_io::io_threads(), &fin))
+                                return 1;
+                            if (!fin) return e2vq_set_error("%s: contains NaN or infinite values", files[(size_t)u.f0].c_str());
+                            HIPCHK(hipMemcpyAsync(q.d_frames.p, q.h_frames, (size_t)n * NC * 8, hipMemcpyHostToDevice, st.s));
+                            if (e2vq_quantize_device(sessions.v[g], q.d_frames.p, n, q.d_sym.p + t0, nullptr)) return 1;
+                        }
+                        if (score_groups(q, Su, g, g + 1, base)) return 1;
+                        base += (size_t)Su * groups[g].idx.size();
+                    }
+                }
+                if (n_res) {
+                    HIPCHK(hipMemcpyAsync(q.h_mant, q.d_mant.p, n_res * 8, hipMemcpyDeviceToHost, st.s));
+                    HIPCHK(hipMemcpyAsync(q.h_exp, q.d_exp.p, n_res * 8, hipMemcpyDeviceToHost, st.s));
+                    HIPCHK(hipMemcpyAsync(q.h_st, q.d_st.p, n_res * 4, hipMemcpyDeviceToHost, st.s));
+                }
+                HIPCHK(hipEventRecord(q.done, st.s));
+                q.unit = ui;
+            }
+            for (int k = 0; k < 2; ++k)
+                if (harvest(slots[(turn + k) & 1])) return 1;
+            HIPCHK(hipStreamSynchronize(st.s));
             return 0;
-        }))
+        })) {
+        failed.store(true);
         return 1;
+    }
     return classify_report(models, files, classes, lp, models[0].M, show_ranked != 0, classification_filename);
 }
 

@@ -248,6 +248,21 @@ def test_hmm_workers_give_identical_models_and_reports(tmp_path, monkeypatch, ca
     assert many[1] == one[1], ".hmm bytes differ"
     assert many[2] == one[2] and many[3] == one[3] and many[4] == one[4] and many[5] == one[5]
     assert len(one[0][0]) >= 2  # (several E-steps ran)
+    # bounded memory (round 4): ecoz2_hmm_classify_predictors streams the corpus in units of whole files through fixed
+    # staging buffers -- with a chunk far below the corpus (units of a few files), and below a single file's length
+    # (the file is streamed piece by piece into the symbol buffer), CSV and report stay byte-identical
+    models = sorted(str(p) for p in hmm_dir.glob("*.hmm"))
+    strip = lambda o: o.split("Confusion matrix:")[1].split(".csv saved")[0].rsplit("\n", 1)[0]
+    lengths = [e.formats.read_prd(f)[2].shape[0] for f in test_prd]
+    for chunk in (3 * max(lengths), 64):
+        assert chunk < sum(lengths) and (chunk != 64 or min(lengths) > 64)
+        monkeypatch.setenv("ECOZ2_VQ_CLASSIFY_CHUNK", str(chunk))
+        for nw in (1, workers):
+            monkeypatch.setenv("ECOZ2_VQ_GPUS", str(nw))
+            capfd.readouterr()
+            e.hmm.hmm_classify_predictors(models, [cbook], test_prd, True, str(tmp_path / f"pc{chunk}_{nw}.csv"))
+            out_p = capfd.readouterr().out
+            assert open(tmp_path / f"pc{chunk}_{nw}.csv").read() == one[3] and strip(out_p) == one[5], (chunk, nw)
 
 
 def test_hmm_cli_end_to_end(tmp_path):
