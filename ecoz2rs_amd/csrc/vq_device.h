@@ -61,7 +61,15 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                             long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
                             hipStream_t s, const double* rowmajor_frames = nullptr, const int* ea_fused = nullptr,
-                            const double* resident_rowmajor = nullptr, long long* family_table = nullptr);
+                            const double* resident_rowmajor = nullptr, long long* family_table = nullptr,
+                            bool assign_only = false);
+// assign_only (accumulate = false, resident_rowmajor and sym given): the accumulating kernel's sweep, outputs and
+// distortion sums (into `rows`) without its cell sums; sym[t] = 0xFFFF marks a frame left to the fallback sweep.
+// launch_accumulate_ranges then adds the cell sums from the symbols, pre-aggregated per (chunk of frames, range of cells)
+// in LDS: cells_new from the sweep, cells_old (incremental) of the previous pass; only read -- swap the arrays afterwards.
+bool accumulate_ranges_supported(int NC);
+int launch_accumulate_ranges(int NC, const double* aos, long T, const unsigned short* cells_new, const unsigned short* cells_old,
+                             bool incremental, int M, const DevScalars* sc, long long* rows, hipStream_t s);
 // resident_rowmajor (accumulating passes): a row-major copy of the training frames padded with zero rows to whole
 // 64-frame blocks; with it (and prefilter_lds_stage(NC)) the pass runs k_pass_pre_lds; prev_sym must then be padded
 // by 128 bytes
@@ -74,7 +82,8 @@ void launch_prefilter_quantize_scales(const double* cbq, int M, int NC, int* ea,
 int launch_pass_fallback(int NC, bool accumulate, const double* blk, const double* cbm, int M, const DevScalars* sc,
                          const unsigned long long* l1max_bits, unsigned short* sym, double* dmin, long long* rows,
                          const int* fb_list, const int* fb_count, unsigned short* prev_sym, int incremental,
-                         hipStream_t s, bool rowmajor = false);
+                         hipStream_t s, bool rowmajor = false, unsigned short* cells_out = nullptr);
+// (cells_out: where the listed frames' new cells are recorded -- default: in place, prev_sym)
 // the seeded first pass after a split (vq_device.hip: k_seed_family): rows <- parents' sums in the even children, X <- 0;
 // after the pass (and its fallback sweep) launch_family_fixup moves the in-family arrivals X[i] from row 2 i to row 2 i + 1
 void launch_seed_family(const long long* parent, long long* rows, long long* X, int Mold, int NC, hipStream_t s);

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                                                        const int* __restrict__ fb_list = nullptr,
                                                        const int* __restrict__ fb_count = nullptr,
                                                        unsigned short* __restrict__ prev_sym = nullptr, int incr = 0,
-                                                       int list_rowmajor = 0)
+                                                       int list_rowmajor = 0, unsigned short* cells_out = nullptr)
 {
     constexpr bool AOS = SRC == 1;
     // frame tiles (of 16) per wave: the fallback list is short, so its waves take one tile each -- four times as
@@ -487,7 +487,13 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             const int oldidx[4] = {(incr && t >= 0) ? (incr == 2 ? 2 : 1) * (int)prev_sym[t] : 0, 0, 0, 0};
             accumulate_block<NC, MODE, false, NFT, true>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2, b, T,
                                                          lane, {false, false, false, false}, incr != 0, oldidx);
-            if (prev_sym && q == 0 && t >= 0) prev_sym[t] = (unsigned short)idx[0];
+            // (the new cell goes to cells_out when the caller keeps two cell arrays and swaps them: k_accum_ranges)
+            if (q == 0 && t >= 0) {
+                if (cells_out)
+                    cells_out[t] = (unsigned short)idx[0];
+                else if (prev_sym)
+                    prev_sym[t] = (unsigned short)idx[0];
+            }
         } else if constexpr (MODE != 0)
             accumulate_block<NC, MODE, false, NFT>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2, b, T, lane,
                                                    {false, false, false, false});
@@ -1508,7 +1514,8 @@ int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const
 // full FP64 sweep of the frames a prefiltered pass could not certify (vq_prefilter.hip): fb_list[0 .. *fb_count)
 int launch_pass_fallback(int NC, bool accumulate, const double* blk, const double* cbm, int M, const DevScalars* sc,
                          const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows, const int* fb_list,
-                         const int* fb_count, unsigned short* prev_sym, int incremental, hipStream_t s, bool rowmajor)
+                         const int* fb_count, unsigned short* prev_sym, int incremental, hipStream_t s, bool rowmajor,
+                         unsigned short* cells_out)
 {
     const int MT = (M + 15) / 16;
     switch (NC) {
@@ -1519,7 +1526,7 @@ int launch_pass_fallback(int NC, bool accumulate, const double* blk, const doubl
         if (accumulate)                                                                                                \
             hipLaunchKernelGGL((k_pass_mfma<N, 2, 256, 2>), dim3(1024), dim3(256), lds, s, blk, 0L, 0L, cbm, MT, M, sc, \
                                l1max_bits, sym, dmin, rows, 0, fb_list, fb_count, prev_sym, incremental,              \
-                               rowmajor ? 1 : 0);                                                                      \
+                               rowmajor ? 1 : 0, cells_out);                                                           \
         else                                                                                                           \
             hipLaunchKernelGGL((k_pass_mfma<N, 0, 256, 2>), dim3(1024), dim3(256), lds, s, blk, 0L, 0L, cbm, MT, M, sc, \
                                l1max_bits, sym, dmin, rows, 0, fb_list, fb_count, (unsigned short*)nullptr, 0,          \

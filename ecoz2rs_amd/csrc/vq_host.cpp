@@ -166,6 +166,15 @@ struct e2vq_session {
     bool plain_first = true;  // first (full) pass of the smallest prefiltered levels on the plain hybrid kernel
     int incr_M = 0;
     unsigned short* d_prev_sym = nullptr;
+    // round 4: passes up to split_max_M codewords run as an assignment-only sweep + k_accum_ranges (cell sums pre-aggregated
+    // in LDS per chunk of frames and range of cells: vq_prefilter.hip); the sweep writes the new cells here, the accumulate
+    // reads both arrays, then they are swapped
+    unsigned short* d_cells_new = nullptr;
+    // ECOZ2_VQ_SPLIT_ACC_MAX_M (0 = never).  Measured on 2^21 frames (profiles/r04_split_accumulate.txt): the assignment-only
+    // sweep takes 0.37 / 0.55 / 0.93 ms at M = 256 / 512 / 1024 where the accumulating kernel takes 0.60-0.77 / 0.70-0.80 /
+    // 1.06-1.11, but k_accum_ranges costs 0.17-0.42 / 0.21-0.46 / 0.29-0.55 ms on top (a workgroup per chunk and cell
+    // range: its cost follows the number of ranges, not the number of movers): a gain at M = 256 only
+    int split_max_M = 256;
     i64* d_rows_local = nullptr;  // world > 1: the un-reduced rows (d_rows holds the all-reduced copy)
     int rows_local_cap = 0;
     // the seeded first pass of a level (vq_device.hip: k_seed_family): the rank's own rows of the last pass at the previous
@@ -205,6 +214,8 @@ struct e2vq_session {
     double ar_ms = 0.0;
     long ar_calls = 0, ar_bytes = 0;
 };
+
+static bool split_accumulate(const e2vq_session* s, int M);
 
 static int ensure_codebook_capacity(e2vq_session* s, int M)
 {
@@ -297,6 +308,7 @@ static int session_init(e2vq_session* s)
     if (const char* pf1 = getenv("ECOZ2_VQ_PLAIN_FIRST")) s->plain_first = atoi(pf1) != 0;
     if (const char* fm = getenv("ECOZ2_VQ_FAMILY")) s->fam_enabled = atoi(fm) != 0;
     if (const char* fm = getenv("ECOZ2_VQ_FAMILY_MIN_M")) s->fam_min_M = std::max(64, atoi(fm));
+    if (const char* sm = getenv("ECOZ2_VQ_SPLIT_ACC_MAX_M")) s->split_max_M = std::max(0, atoi(sm));
     if (s->pre_enabled) {
         HIPCHK(hipMalloc(&s->d_colmax, (size_t)s->NC * 8));
         HIPCHK(hipMalloc(&s->d_ea, (size_t)s->NC * sizeof(int)));
@@ -343,7 +355,7 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     void* ptrs[] = {s->d_cbT, s->sv.refl, s->sv.rows, s->sv.rows_local, s->sv.cells, s->d_rows_parent, s->d_fam, s->d_aos, s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
-                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg2[0], s->d_cimg2[1], s->d_ps2[0], s->d_ps2[1], s->d_ps, s->d_fblist, s->d_prev_sym, s->d_rows_local,
+                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg2[0], s->d_cimg2[1], s->d_ps2[0], s->d_ps2[1], s->d_ps, s->d_fblist, s->d_prev_sym, s->d_cells_new, s->d_rows_local,
                     s->d_ea_q, s->d_qfimg, s->d_qfg, s->d_qfblist, s->d_qcimg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -501,9 +513,11 @@ static int set_frames_device_impl(e2vq_session* s, const void* device_frames, in
         if (s->d_fg) HIPCHK(hipFree(s->d_fg));
         if (s->d_fblist) HIPCHK(hipFree(s->d_fblist));
         if (s->d_prev_sym) HIPCHK(hipFree(s->d_prev_sym));
+        if (s->d_cells_new) HIPCHK(hipFree(s->d_cells_new));
         if (s->d_aos) HIPCHK(hipFree(s->d_aos));
         s->d_aos = nullptr;
         s->d_prev_sym = nullptr;
+        s->d_cells_new = nullptr;
         s->d_fimg = nullptr;
         s->d_fg = nullptr;
         s->d_fblist = nullptr;
@@ -513,7 +527,8 @@ static int set_frames_device_impl(e2vq_session* s, const void* device_frames, in
         const bool fits = hipMalloc(&s->d_fimg, e2vq::prefilter_frame_image_bytes(s->NC, s->nblocks)) == hipSuccess &&
                           hipMalloc(&s->d_fg, (size_t)s->nblocks * 64 * sizeof(float)) == hipSuccess &&
                           hipMalloc(&s->d_fblist, (size_t)s->nblocks * 64 * sizeof(int)) == hipSuccess &&
-                          hipMalloc(&s->d_prev_sym, (size_t)s->nblocks * 64 * sizeof(unsigned short) + 256) == hipSuccess;
+                          hipMalloc(&s->d_prev_sym, (size_t)s->nblocks * 64 * sizeof(unsigned short) + 256) == hipSuccess &&
+                          hipMalloc(&s->d_cells_new, (size_t)s->nblocks * 64 * sizeof(unsigned short) + 256) == hipSuccess;
         // the accumulating prefiltered pass stages the FP64 frames of a block in LDS from a row-major copy (another 296 B
         // per frame; without it the pass keeps to the round-2 kernel, which reads the blocked layout)
         if (fits && e2vq::prefilter_lds_stage(s->NC)) {
@@ -538,7 +553,7 @@ static int set_frames_device_impl(e2vq_session* s, const void* device_frames, in
             HIPCHK(hipGetLastError());
         } else {
             (void)hipGetLastError();  // clear the out-of-memory status
-            for (void** p : {(void**)&s->d_fimg, (void**)&s->d_fg, (void**)&s->d_fblist, (void**)&s->d_prev_sym, (void**)&s->d_aos}) {
+            for (void** p : {(void**)&s->d_fimg, (void**)&s->d_fg, (void**)&s->d_fblist, (void**)&s->d_prev_sym, (void**)&s->d_cells_new, (void**)&s->d_aos}) {
                 if (*p) (void)hipFree(*p);
                 *p = nullptr;
             }
@@ -678,7 +693,7 @@ extern "C" int e2vq_grow(e2vq_session* s)
     const bool seed = s->fam_enabled && s->pre_enabled && s->d_aos && s->d_prev_sym && s->rows_fresh && s->rows_are_local &&
                       s->cells_M == s->M && 2 * s->M >= s->pre_min_M && 2 * s->M >= s->fam_min_M &&
                       e2vq::prefilter_supports(s->NC, 2 * s->M) &&
-                      e2vq::prefilter_lds_stage(s->NC) && s->incr_enabled;
+                      e2vq::prefilter_lds_stage(s->NC) && s->incr_enabled && !split_accumulate(s, 2 * s->M);
     if (seed) {
         if (s->fam_cap < s->M) {
             for (i64** p : {&s->d_rows_parent, &s->d_fam}) {
@@ -737,6 +752,14 @@ static bool use_prefilter(const e2vq_session* s, int mode)
            e2vq::prefilter_supports(s->NC, s->M);
 }
 
+// assignment-only sweep + k_accum_ranges for accumulating prefiltered passes at this codebook size?
+static bool split_accumulate(const e2vq_session* s, int M)
+{
+    return s->pre_enabled && s->incr_enabled && s->d_aos && s->d_cells_new && s->d_prev_sym && M <= s->split_max_M &&
+           M >= s->pre_min_M && e2vq::prefilter_supports(s->NC, M) && e2vq::prefilter_lds_stage(s->NC) &&
+           e2vq::accumulate_ranges_supported(s->NC);
+}
+
 static int ensure_codebook_image(e2vq_session* s)
 {
     if (s->M <= s->cimg_cap) return 0;
@@ -776,13 +799,15 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         rows = s->d_rows_local;
     }
     const bool incremental = keep && s->incr_valid && s->incr_M == s->M;
+    // round 4: the sweep only assigns, k_accum_ranges adds the cell sums (full or incremental) through LDS tables
+    const bool split = keep && split_accumulate(s, s->M);
     // the first pass after a split, seeded with the parents' sums (e2vq_grow stashed them): k_seed_family
-    const bool family = s->fam_pending && keep && !incremental && s->d_aos && 2 * s->fam_M == s->M && mode != 0;
+    const bool family = s->fam_pending && keep && !incremental && !split && s->d_aos && 2 * s->fam_M == s->M && mode != 0;
     s->fam_pending = false;
     // The first pass of a level accumulates in full.  For the smallest prefiltered sizes that is cheaper on the plain
     // FP64 sweep with its workgroup-local LDS table (hybrid accumulate: 0.92 vs 1.5 ms at M = 256, where 2^21 frames
     // hammer 256 rows with global atomics); it records the cells for the incremental passes that follow.
-    const bool plain_first = s->plain_first && keep && !incremental && !family && mode == 5 && s->M <= 384;
+    const bool plain_first = s->plain_first && keep && !incremental && !family && !split && mode == 5 && s->M <= 384;
     if (s->last_prefiltered && !plain_first && ensure_codebook_image(s)) return 1;
     {
         // one prologue launch: the rows (all of them, or the distortion columns of an incremental pass), the fallback
@@ -838,6 +863,29 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         void* const d_ps = s->d_ps2[k];
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
         s->n_pre_launches++;
+        if (split) {
+            // cells: into the caller's array when there is one (the fallback sweep then replaces the 0xFFFF marks there), else
+            // into the session's second cell array
+            unsigned short* cells = device_sym ? (unsigned short*)device_sym : s->d_cells_new;
+            if (e2vq::launch_pass_prefiltered(s->NC, false, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, d_cimg, d_ps, s->d_cbq,
+                                              s->M, s->d_sc, s->d_l1max, cells, (double*)device_dmin, rows, s->d_fblist, nullptr,
+                                              false, false, s->stream, nullptr, nullptr, s->d_aos, nullptr, /*assign_only=*/true))
+                return e2vq_set_error("assignment-only prefiltered sweep: unsupported configuration");
+            if (e2vq::launch_accumulate_ranges(s->NC, s->d_aos, s->T, cells, s->d_prev_sym, incremental, s->M, s->d_sc, rows, s->stream))
+                return e2vq_set_error("k_accum_ranges: unsupported prediction order");
+            if (s->timing) {  // (the pass's two kernels together: what the one accumulating kernel is elsewhere)
+                HIPCHK(hipEventRecord(s->ev1, s->stream));
+                s->timed = true;
+                s->timing_pending = true;
+            }
+            e2vq::launch_pass_fallback(s->NC, true, s->d_blk, s->d_cbm, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
+                                       (double*)device_dmin, rows, s->d_fblist, e2vq::prefilter_fallback_count(d_ps), s->d_prev_sym,
+                                       incremental ? 1 : 0, s->stream, false, /*cells_out=*/cells);
+            if (device_sym)
+                HIPCHK(hipMemcpyAsync(s->d_prev_sym, device_sym, (size_t)s->T * sizeof(unsigned short), hipMemcpyDeviceToDevice, s->stream));
+            else
+                std::swap(s->d_prev_sym, s->d_cells_new);
+        } else {
         e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, d_cimg, d_ps,
                                       s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                                       (double*)device_dmin, rows, s->d_fblist, keep ? s->d_prev_sym : nullptr,
@@ -853,6 +901,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
                                    e2vq::prefilter_fallback_count(d_ps), keep ? s->d_prev_sym : nullptr,
                                    family ? 2 : (incremental ? 1 : 0), s->stream);
         if (family) e2vq::launch_family_fixup(rows, s->d_fam, s->fam_M, s->NC, s->stream);
+        }  // !split
     } else {
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
         s->n_plain_launches++;

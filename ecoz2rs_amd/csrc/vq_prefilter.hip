@@ -1144,7 +1144,7 @@ __device__ __forceinline__ void pre_load_tile_asm(h8 (&A)[PrePack<NC>::NU], cons
     pre_load_tile_wait<NC>(A);
 }
 
-template <int NC, bool ROT>
+template <int NC, bool ROT, bool ACCUM>
 __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restrict__ aos, long T, long nblocks,
                                                          const h8* __restrict__ fimg, const float* __restrict__ fg,
                                                          const h8* __restrict__ cimg, PreScalars* __restrict__ ps,
@@ -1160,6 +1160,9 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
     // cell are moved); 2 = the seeded first pass of a level (vq_device.hip, k_seed_family): a frame's old cell is the even
     // child 2 * prev_sym of the cell it had at the previous size; one that lands in the odd child 2 * prev_sym + 1 adds its
     // limbs to row prev_sym of the side table `fam` and nothing else
+    // ACCUM = false (round 4): the pass only assigns -- `sym` receives every frame's cell, 0xFFFF for a frame left to the
+    // fallback sweep -- and adds the distortion sums; k_accum_ranges does the cell sums from the symbols (incr, prev_sym and
+    // fam are not used)
     typedef PrePack<NC> PK;
     typedef PreLds<NC> PL;
     constexpr int TPBM = 512;
@@ -1223,7 +1226,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         E2VQ_LDS_LOAD_B(wave, lane)
         E2VQ_LDS_LOAD_A(A0, 0, lane)
         E2VQ_LDS_LOAD_A(A1, 1, lane)  // (every codebook of this kernel has at least two tiles: M >= 64)
-        pre_lds_request<NC>(aos, fg, incr ? prev_sym : nullptr, wave, lane, wbase);
+        pre_lds_request<NC>(aos, fg, (ACCUM && incr) ? prev_sym : nullptr, wave, lane, wbase);
     }
     // (as before every block's atomics: both ways into the block loop arrive with no register load pending, so the
     // compiler puts no counter wait in front of tile 0)
@@ -1319,7 +1322,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         const bool cert = t1 >= 1.0e-30f && t1 < 1.0e37f && w3 > t1 + tau;
         const bool amb = !(u2 > t1 + tau);  // the runner-up is within reach: it needs the exact evaluation too
         const int c1 = __float_as_int(t1) & ~idxmask, c2 = __float_as_int(u2) & ~idxmask;
-        const int old = incr ? (incr == 2 ? 2 : 1) * (int)prevs[ln] : 0;
+        const int old = (ACCUM && incr) ? (incr == 2 ? 2 : 1) * (int)prevs[ln] : 0;
         E2VQ_STAMP(2)  // merge, certification
 
         // ---- exact evaluation of both candidates: the canonical chain, one frame per ln ---------------------------
@@ -1378,6 +1381,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         if (live) {
             if (skip) {
                 fb_list[atomicAdd(&ps->fb_count, 1)] = (int)t;
+                if (!ACCUM) sym[t] = (unsigned short)0xFFFF;  // (k_accum_ranges leaves this frame to the fallback sweep)
             } else {
                 if (sym) sym[t] = (unsigned short)idx;
                 if (dmin) dmin[t] = best;
@@ -1412,13 +1416,16 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         }
         E2VQ_STAMP(4)  // outputs
 
+        u64 movers = 0;
+        bool bulk = false;
+        if constexpr (ACCUM) {
         // ---- frames that contribute: all of a full pass, the movers of an incremental one ---------------------------------
         const bool mov = live && !skip && (!incr || old != idx);
         // Many contributors (a full pass; the first incremental pass of a level): every contributing lane converts its own
         // row to limb pairs in place -- 37 conversions per lane, whatever the number of contributors.  Few: the lanes of
         // each atomic convert just the value they add (below) -- one conversion per lane and contributor.
-        const u64 movers = __ballot(mov);
-        const bool bulk = __builtin_popcountll(movers) > 28;  // wave-uniform
+        movers = __ballot(mov);
+        bulk = __builtin_popcountll(movers) > 28;  // wave-uniform
         if (bulk) {
             if (mov) {
                 double* fr = stage + ln * NC;
@@ -1442,6 +1449,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        }  // ACCUM
         E2VQ_STAMP(5)  // limb conversion (bulk)
 
         // ---- the block's atomics, four frames per step ------------------------------------------------------------------
@@ -1449,7 +1457,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         // first atomic: nothing may wait on the vector-memory counter from here to tile 2 of the next block.  The builtin
         // (not inline asm) so that the compiler's own counter bookkeeping sees it and inserts no later wait for those registers.
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        {
+        if constexpr (ACCUM) {
             u64 mm = movers;
             const int tq = ln >> 4, te = ln & 15;
             constexpr int NE = PL::NE;            // limb pairs + count
@@ -1514,13 +1522,13 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
             }
         }
         if (ln < 4 && dsum != 0) atomicAdd((u64*)&rows[(long)(b % (32 * MT)) * RS + 2 * NC + 1 + ln], (u64)dsum);
-        if (prev_sym && live && !skip) prev_sym[t] = (unsigned short)idx;
+        if (ACCUM && prev_sym && live && !skip) prev_sym[t] = (unsigned short)idx;
         E2VQ_STAMP(6)  // atomics (issue)
 
         // ---- the next block's frames: the LDS rows are free once this block's reads are done ---------------------------
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (bn < nblocks) pre_lds_request<NC>(aos, fg, incr ? prev_sym : nullptr, bn, ln, wbase);
+        if (bn < nblocks) pre_lds_request<NC>(aos, fg, (ACCUM && incr) ? prev_sym : nullptr, bn, ln, wbase);
         E2VQ_STAMP(7)
 #ifdef E2VQ_PRE_STAMP
         st_n += 1;
@@ -1540,6 +1548,128 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         }
     }
 #endif
+}
+
+// ---- k_accum_ranges (round 4): the accumulate of a prefiltered pass as a kernel of its own, pre-aggregated in LDS --------
+// What bounds the accumulate inside the sweep kernel is the memory side: every frame that contributes costs 600 B of int64
+// atomic traffic (1 200 B for a mover of an incremental pass), the chip retires ~1.3 TB/s of it, and a wave's burst sits in
+// its in-order vector-memory queue in front of the next block's operands.  Here the sweep only ASSIGNS (k_pass_pre_lds<.., false>:
+// symbols out, 0xFFFF for a frame it could not certify); this kernel then adds the frames to their cells through a table
+// in LDS and touches global memory once per (chunk of frames, cell) instead of once per (frame, cell):
+//   grid = chunks x ranges.  A workgroup owns the cells [lo, hi) of one range (at most ACC_RANGE_CELLS: the table fills the
+//   CU's LDS) and one contiguous chunk of frames; it reads the chunk's new and old cells (2 + 2 B per frame), and for every
+//   frame that adds to a cell of its range (full pass: new cell in range; incremental: moved INTO the range) or leaves one
+//   (incremental: moved OUT of it) loads the frame's row (296 B, coalesced), converts it to limbs and ds_add's them --
+//   negated for a leaver -- into the table; at the end the non-zero words go to the global rows as one atomic each.
+// Exact 64-bit integers throughout: the rows equal those of any other order of accumulation bit for bit.
+// Atomic traffic of an M = 256 pass over 2^21 frames: 42 MB (256 chunks x 256 cells x 640 B) instead of 450-600 MB.
+// The cells of the previous pass are only READ here (several workgroups look at the same frame): the caller swaps the two
+// cell arrays afterwards; frames with the 0xFFFF mark are the fallback sweep's business (it accumulates them itself).
+constexpr int ACC_RANGE_CELLS = 120;  // x 640 B (NC = 37) = 77 KB: two workgroups per CU
+constexpr int ACC_TPB = 1024;         // 16 waves per workgroup: the row loads of one wave hide under the others' LDS adds
+constexpr int ACC_BATCH = 8;          // rows requested together by a wave (the loads of a batch are all in flight at once)
+
+template <int NC>
+__global__ __launch_bounds__(ACC_TPB, 2) void k_accum_ranges(const double* __restrict__ aos, long T, long chunk_frames,
+                                                          const unsigned short* __restrict__ cells_new,
+                                                          const unsigned short* __restrict__ cells_old, int incremental,
+                                                          int M, int range_cells, const DevScalars* __restrict__ sc,
+                                                          i64* __restrict__ rows)
+{
+    constexpr int RS = (2 * NC + 5 + 7) & ~7;
+    constexpr int NE = 2 * NC + 1;       // limb pairs + count
+    constexpr bool TAIL = NE > 64;
+    constexpr int NT = TAIL ? NE - 64 : 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    i64* table = (i64*)smem;
+    const int nranges = (M + range_cells - 1) / range_cells;
+    const int g = (int)(blockIdx.x % (unsigned)nranges);
+    const long chunk = (long)(blockIdx.x / (unsigned)nranges);
+    const int lo = g * range_cells, hi = lo + range_cells < M ? lo + range_cells : M;
+    const int ncell = hi - lo;
+    for (int i = threadIdx.x; i < ncell * RS; i += ACC_TPB) table[i] = 0;
+    __syncthreads();
+    const int sh_r = sc->sh_r;
+    const bool fast_fix = sh_r >= -1000 && sh_r <= 1000;
+    const double scale_r = __longlong_as_double((long long)(1023 + (fast_fix ? sh_r : 0)) << 52);
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int tq = lane >> 4, te = lane & 15;
+    const long t_begin = chunk * chunk_frames, t_end = t_begin + chunk_frames < T ? t_begin + chunk_frames : T;
+    auto limb = [&](double x, int odd) -> int {
+        int h, l;
+        if (fast_fix)
+            fix2_mul(x, scale_r, h, l);
+        else
+            fix2(x, sh_r, h, l);
+        return odd ? l : h;
+    };
+    constexpr long STEP = 64L * (ACC_TPB / 64);
+    // the cells of the wave's next 64 frames are requested while the current ones are worked on
+    auto fetch = [&](long t0, int& cn, int& co) {
+        const long t = t0 + lane;
+        const bool live = t0 < t_end && t < t_end;
+        cn = live ? (int)cells_new[t] : 0xFFFF;
+        co = (live && incremental) ? (int)cells_old[t] : -1;
+    };
+    int cn_next, co_next;
+    fetch(t_begin + 64L * wib, cn_next, co_next);
+    for (long t0 = t_begin + 64L * wib; t0 < t_end; t0 += STEP) {
+        const int cn = cn_next, co = co_next;
+        fetch(t0 + STEP, cn_next, co_next);
+        const bool counts = cn != 0xFFFF && (!incremental || cn != co);  // contributes at all (frames beyond the chunk: 0xFFFF)
+        const bool add = counts && cn >= lo && cn < hi;
+        const bool sub = counts && incremental && co >= lo && co < hi;
+        // contributions of this wave's 64 frames: bit f of `adds` / `subs`, walked ACC_BATCH at a time (adds first)
+        u64 adds = __ballot(add), subs = __ballot(sub);
+        while ((adds | subs) != 0) {
+            int f[ACC_BATCH], cell[ACC_BATCH], sgn[ACC_BATCH];
+            bool on[ACC_BATCH];
+            double x[ACC_BATCH], xt[ACC_BATCH / 4];
+#pragma unroll
+            for (int k = 0; k < ACC_BATCH; ++k) {
+                const bool from_add = adds != 0;
+                u64& mm = from_add ? adds : subs;
+                on[k] = mm != 0;  // wave-uniform
+                f[k] = on[k] ? (int)__builtin_ctzll(mm) : 0;
+                mm = on[k] ? (mm & (mm - 1)) : mm;
+                sgn[k] = from_add ? 1 : -1;
+                cell[k] = __builtin_amdgcn_readlane(from_add ? cn : co, f[k]) - lo;
+                // lane e: element e = 2 n + limb of the frame's row (pairs of lanes read the same double: 296 contiguous bytes)
+                x[k] = (on[k] && lane < 2 * NC) ? aos[(t0 + f[k]) * NC + (lane >> 1)] : 0.0;
+            }
+            if constexpr (TAIL) {  // the row tails of four frames per instruction: 16 lanes each
+#pragma unroll
+                for (int q = 0; q < ACC_BATCH / 4; ++q) {
+                    const int tf = tq == 0 ? f[4 * q] : tq == 1 ? f[4 * q + 1] : tq == 2 ? f[4 * q + 2] : f[4 * q + 3];
+                    const bool ton = (tq == 0 ? on[4 * q] : tq == 1 ? on[4 * q + 1] : tq == 2 ? on[4 * q + 2] : on[4 * q + 3]);
+                    const int et = 64 + te;  // (te < NT - 1: a limb; te == NT - 1: the count)
+                    xt[q] = (ton && te < NT - 1) ? aos[(t0 + tf) * NC + (et >> 1)] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < ACC_BATCH; ++k) {
+                if (!on[k]) continue;  // wave-uniform
+                const int v = lane >= 2 * NC ? 1 : limb(x[k], lane & 1);  // (lane == 2 NC, short rows only: the count)
+                if (TAIL || lane < NE) atomicAdd((u64*)&table[cell[k] * RS + lane], (u64)((i64)sgn[k] * (i64)v));
+            }
+            if constexpr (TAIL) {
+#pragma unroll
+                for (int q = 0; q < ACC_BATCH / 4; ++q) {
+                    if (!on[4 * q]) continue;  // wave-uniform (the batch is filled in order)
+                    const bool ton = (tq == 0 ? on[4 * q] : tq == 1 ? on[4 * q + 1] : tq == 2 ? on[4 * q + 2] : on[4 * q + 3]) && te < NT;
+                    const int tcell = tq == 0 ? cell[4 * q] : tq == 1 ? cell[4 * q + 1] : tq == 2 ? cell[4 * q + 2] : cell[4 * q + 3];
+                    const int tsgn = tq == 0 ? sgn[4 * q] : tq == 1 ? sgn[4 * q + 1] : tq == 2 ? sgn[4 * q + 2] : sgn[4 * q + 3];
+                    const int tv = te >= NT - 1 ? 1 : limb(xt[q], (64 + te) & 1);
+                    if (ton) atomicAdd((u64*)&table[tcell * RS + 64 + te], (u64)((i64)tsgn * (i64)tv));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncell * RS; i += ACC_TPB) {
+        const i64 v = table[i];
+        if (v != 0) atomicAdd((u64*)&rows[(long)lo * RS + i], (u64)v);
+    }
 }
 
 // ---- launch wrappers ---------------------------------------------------------------------------------------
@@ -1692,7 +1822,7 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                                      const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym,
                                      double* dmin, long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental,
                                      bool hybrid_table, hipStream_t s, const double* aos, const int* ea_fused,
-                                     const double* aos_resident, long long* family_table)
+                                     const double* aos_resident, long long* family_table, bool assign_only)
 {
     constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
     constexpr int TPBM = 512;  // 8 waves = 2 per SIMD, one persistent workgroup per CU
@@ -1709,7 +1839,7 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
         hipLaunchKernelGGL((k_pass_pre<NC, 5, TPBM>), dim3(grid), dim3(TPBM), lds5, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
                            dmin, rows, fb_list, stagger, prev_sym, 0, (const double*)nullptr, (const int*)nullptr);
-    } else if (accumulate && aos_resident && prefilter_lds_stage(NC)) {
+    } else if ((accumulate || assign_only) && aos_resident && prefilter_lds_stage(NC)) {
         // round 3: FP64 frames staged in LDS, lane-per-frame exact evaluation, one burst of atomics per block
         if constexpr (PreLds<NC>::OK) {
             const int MT = M / 32;
@@ -1721,10 +1851,17 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                                    family_table ? 2 : (incremental ? 1 : 0), (i64*)family_table);
             };
             static const bool simple = getenv("ECOZ2_VQ_PRE_SIMPLE_LOOP") && atoi(getenv("ECOZ2_VQ_PRE_SIMPLE_LOOP")) != 0;  // (tests)
-            if (MT >= 4 && (MT & 1) == 0 && !simple)
-                go(k_pass_pre_lds<NC, true>);
-            else
-                go(k_pass_pre_lds<NC, false>);
+            const bool rot = MT >= 4 && (MT & 1) == 0 && !simple;
+            if (assign_only) {  // (the cell sums follow in launch_accumulate_ranges)
+                if (rot)
+                    go(k_pass_pre_lds<NC, true, false>);
+                else
+                    go(k_pass_pre_lds<NC, false, false>);
+            } else if (rot) {
+                go(k_pass_pre_lds<NC, true, true>);
+            } else {
+                go(k_pass_pre_lds<NC, false, true>);
+            }
         }
     } else if (accumulate) {
         (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 2, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1761,9 +1898,11 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                             long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
                             hipStream_t s, const double* rowmajor_frames, const int* ea_fused, const double* resident_rowmajor,
-                            long long* family_table)
+                            long long* family_table, bool assign_only)
 {
     if (family_table && (!accumulate || hybrid_table || incremental || !resident_rowmajor || !prefilter_lds_stage(NC))) return 1;
+    // assign_only: the accumulating kernel's sweep and distortion sums without its cell sums (k_accum_ranges follows)
+    if (assign_only && (accumulate || !sym || !rows || !resident_rowmajor || !prefilter_lds_stage(NC) || ea_fused)) return 1;
     if (!prefilter_supports(NC, M) || (hybrid_table && incremental)) return 1;
     if (ea_fused && (accumulate || !rowmajor_frames || !prefilter_fused_quantize(NC))) return 1;
     switch (NC) {
@@ -1771,7 +1910,39 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
     case N:                                                                                                           \
         return launch_pass_prefiltered_t<N>(accumulate, blk, T, nblocks, fimg, fg, cimg, ps, cbq, M, sc, l1max_bits, sym, \
                                             dmin, rows, fb_list, prev_sym, incremental, hybrid_table, s, rowmajor_frames, \
-                                            ea_fused, resident_rowmajor, family_table);
+                                            ea_fused, resident_rowmajor, family_table, assign_only);
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        default: return 1;
+    }
+}
+
+// the cell sums of a pass whose sweep only assigned (k_pass_pre_lds<.., false>): cells_new[t] = the frame's cell (0xFFFF: left
+// to the fallback sweep), cells_old (incremental != 0) = its cell of the previous pass; adds into `rows` (which the caller
+// zeroed for a full pass)
+bool accumulate_ranges_supported(int NC) { return pre_has_nc(NC) && 2 * NC + 1 <= 80; }
+int launch_accumulate_ranges(int NC, const double* aos, long T, const unsigned short* cells_new, const unsigned short* cells_old,
+                             bool incremental, int M, const DevScalars* sc, long long* rows, hipStream_t s)
+{
+    const int RS = (2 * NC + 5 + 7) & ~7;
+    const int max_cells = (E2VQ_LDS_BYTES - 2048) / (RS * 8) < ACC_RANGE_CELLS ? (E2VQ_LDS_BYTES - 2048) / (RS * 8) : ACC_RANGE_CELLS;
+    const int nranges = (M + max_cells - 1) / max_cells;
+    const int range_cells = (M + nranges - 1) / nranges;
+    const long nchunks = T >= 256L * 1024 ? 256 : (T + 1023) / 1024;  // one chunk per CU, at least 1 024 frames each
+    const long chunk_frames = ((T + nchunks - 1) / nchunks + 63) / 64 * 64;
+    const long used_chunks = (T + chunk_frames - 1) / chunk_frames;
+    const size_t lds = (size_t)range_cells * RS * 8;
+    switch (NC) {
+#define X(N)                                                                                                          \
+    case N:                                                                                                           \
+        if constexpr (2 * N + 1 <= 80) {                                                                              \
+            (void)hipFuncSetAttribute((const void*)k_accum_ranges<N>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                      E2VQ_LDS_BYTES);                                                                \
+            hipLaunchKernelGGL((k_accum_ranges<N>), dim3((unsigned)(used_chunks * nranges)), dim3(ACC_TPB), lds, s, aos, T, \
+                               chunk_frames, cells_new, cells_old, incremental ? 1 : 0, M, range_cells, sc, (i64*)rows); \
+            return 0;                                                                                                 \
+        }                                                                                                             \
+        return 1;
         E2VQ_PRE_NC_LIST(X)
 #undef X
         default: return 1;

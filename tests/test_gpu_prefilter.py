@@ -218,6 +218,9 @@ def test_incremental_rows_match_a_full_accumulation_every_pass(oracle, monkeypat
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER", "1" if prefilter else "0")
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
     monkeypatch.setenv("ECOZ2_VQ_PLAIN_FIRST", "1" if plain_first else "0")  # first pass on the plain hybrid kernel?
+    # (round 4: up to M = 256 the default pass is an assignment-only sweep + k_accum_ranges, full or incremental, and the
+    # plain first pass is not used; with plain_first the one-kernel paths of round 3 are exercised instead)
+    monkeypatch.setenv("ECOZ2_VQ_SPLIT_ACC_MAX_M", "0" if plain_first else "512")
     if collective:
         monkeypatch.setenv("ECOZ2_VQ_FORCE_ALLREDUCE", "1")
     frames = _frames(20257, 9000)
@@ -244,16 +247,21 @@ def test_incremental_rows_match_a_full_accumulation_every_pass(oracle, monkeypat
     assert bool(calls) == collective
 
 
+@pytest.mark.parametrize("split_max_m", [0, 128, 4096])
 @pytest.mark.parametrize("collective", [False, True])
 @pytest.mark.parametrize("min_m", [64, 256])
-def test_seeded_first_pass_after_a_split_equals_a_full_accumulation(oracle, monkeypatch, min_m, collective):
+def test_seeded_first_pass_after_a_split_equals_a_full_accumulation(oracle, monkeypatch, min_m, collective, split_max_m):
     """The first pass of a level is seeded with the parents' exact sums (rows[2 i] = parent i, frames landing in 2 i + 1
     add once to a side table, only frames leaving their family are moved; k_seed_family / k_family_fixup): rows after that
     pass -- and after the incremental passes that build on it -- must equal the oracle's full accumulation bit for bit.
     Levels 32 -> 64 (parent on the plain sweep, which records the cells) up to 512, through grow / pass / update; with
-    `collective` the parent rows come from the rank's own copy."""
+    `collective` the parent rows come from the rank's own copy.
+    split_max_m (round 4): up to that size the pass is an assignment-only sweep + k_accum_ranges (cell sums through LDS
+    tables, full on the first pass of a level and incremental after; two cell arrays swapped per pass) instead -- 0: seeded
+    passes everywhere; 128: the two kinds of level follow each other; 4096: no seeded pass at all."""
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", str(min_m))
     monkeypatch.setenv("ECOZ2_VQ_FAMILY_MIN_M", str(min_m))  # (default 512: below, the plain first pass is faster)
+    monkeypatch.setenv("ECOZ2_VQ_SPLIT_ACC_MAX_M", str(split_max_m))
     monkeypatch.setenv("ECOZ2_VQ_QUIET", "1")
     if collective:
         monkeypatch.setenv("ECOZ2_VQ_FORCE_ALLREDUCE", "1")

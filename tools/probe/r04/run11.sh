@@ -1,0 +1,15 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+export ECOZ2_VQ_QUIET=1
+timeout -k 10 600 python -m pytest tests/test_gpu_prefilter.py -x -q -k "incremental or seeded or prefiltered_pass" > gpurun_out/r11_tests.log 2>&1; rc=$?
+tail -4 gpurun_out/r11_tests.log
+grep -q "Memory access fault" gpurun_out/r11_tests.log && exit 1
+[ $rc -ne 0 ] && exit $rc
+for m in 0 512 4096 0 512 4096; do echo "== ECOZ2_VQ_SPLIT_ACC_MAX_M=$m"; ECOZ2_VQ_SPLIT_ACC_MAX_M=$m timeout -k 10 200 python tools/probe/ladder_real.py 2>&1 | tail -2; done
+R=$GRAFT_REPO_ROOT
+export ECOZ2_VQ_SPLIT_ACC_MAX_M=4096
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r11_kt -- python3 $R/tools/probe/ladder_real.py > $R/gpurun_out/r11.log 2>&1
+cd $R
+f=$(ls -S gpurun_out/r11_kt/*/*kernel_trace.csv | head -1)
+python3 tools/trace_gaps.py $f | grep -E "k_accum_ranges|k_pass_pre_lds" | tail -18
