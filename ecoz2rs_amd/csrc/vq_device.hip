@@ -161,9 +161,6 @@ constexpr int TPB = 256;
 //   codebook: cbm[tile][p][lane][2] = cq[16*tile + j][4*(2p+e) + q], zero beyond n = P,
 //            codewords beyond M are copies of codeword 0 (they can never win a tie)
 // ------------------------------------------------------------------------------------------
-#ifndef E2VQ_PRIO
-#define E2VQ_PRIO 1
-#endif
 
 // (also scans max |x| and non-finite values on the way: the data statistics need no separate pass)
 __global__ void k_blockify_mfma(const double* __restrict__ aos, long T, int NC, double* __restrict__ blk,
@@ -240,7 +237,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
     // NS k-steps of 4 cover n < 4*NS; with NC = 4*NSF + 1 the last coefficient (n = NC-1) is not padded to
     // a fifth MFMA k-step but applied as one VALU fma after the MFMA chain: same ascending order, same roundings.
     constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2, REM = NC - 4 * (NS - 1);
-    constexpr bool PRIO = E2VQ_PRIO;
+    constexpr bool PRIO = true;  // (s_setprio 1 around the MFMA cluster: -3.5 % on the plain sweep)
     constexpr bool TAILV = REM == 1;           // single trailing coefficient -> VALU
     constexpr int NSM = TAILV ? NS - 1 : NS;   // k-steps run on the matrix pipe
     constexpr int RS = (2 * NC + 5 + 7) & ~7;
@@ -637,15 +634,11 @@ __global__ __launch_bounds__(512, 2) void k_pass_small(const double* __restrict_
                 }
             }
             // ---- accumulate ----
-#if !defined(E2VQ_SMALL_EXP) || E2VQ_SMALL_EXP < 2  // (A/B builds, tools/probe/ab: 2 = no accumulate at all, 1 = images only)
             if (fast)  // (kernel-uniform)
                 regacc_stage_half<NC, true>(H, best, idx, img, fr, fd, fd2, t0, T, lane);
             else
                 regacc_stage_half<NC, false>(H, best, idx, img, fr, fd, fd2, t0, T, lane);
-#endif
-#if !defined(E2VQ_SMALL_EXP)
             regacc_add_half<NC>(img, lane, racc);
-#endif
         }
         // digit sums stay below 2^31 for 2^24 frames per wave; flush long before (flush_mask = 0xFFFF: every 2^22 frames;
         // the tests set ECOZ2_VQ_SMALL_FLUSH_MASK=0 to take this path after every block)
@@ -1098,9 +1091,6 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
             *pub.h_seq = pub.seq;
             __threadfence_system();
         }
-#ifdef E2VQ_CU_NOLATE  // A/B (tools/probe/ab): no second publication
-        return;
-#endif
         late = false;
         for (int i = threadIdx.x; i < M; i += blockDim.x) {
             int spins = 0;
@@ -1169,11 +1159,7 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
         bool have_a = false;                  // a[] already holds the step-up of the final reflections
         bool fresh = false;
 
-#ifdef E2VQ_CU_NOLEV  // A/B: no recursion (every cell keeps its codeword)
-        if (false) {
-#else
         if (rows && cnt != 0) {  // wave-uniform
-#endif
             // ---- lpca_r (src/lpc/lpca_r_rs.rs:8-43) on S ------------------------------------------------
             const double r0 = lane_bcast(S, 0);
             int status = 0;
@@ -1201,14 +1187,12 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
                 atomicAdd((u64*)&ls[5], 1ull);
             }
         }
-#ifndef E2VQ_CU_NOLATE
         if (pub.flags && rows) {  // whether this cell's recursion failed is known (and counted)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0)
                 __hip_atomic_store(&pub.flags[M + m], (unsigned int)pub.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-#endif
 
         if (!fresh) rcn = act ? src[lane] : 0.0;  // keep the codeword
         if (lane == 0) rcn = 0.0;

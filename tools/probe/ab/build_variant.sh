@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds an A/B variant of libecoz2vq.so into tools/probe/ab/<name>/ (the product library is untouched):
-#   tools/probe/ab/build_variant.sh <name> '<extra hipcc flags, e.g. -DE2VQ_PRE_VPM=5>'
+#   tools/probe/ab/build_variant.sh <name> '<extra hipcc flags, e.g. -DE2VQ_PRE_STAMP=1>'
 # Run with ECOZ2VQ_LIB=tools/probe/ab/<name>/libecoz2vq.so python bench.py ...
 set -e
 NAME=$1; FLAGS=$2
