@@ -249,14 +249,20 @@ __device__ __forceinline__ void accumulate_block(const double (&Bf)[4][2 * ((((N
                             if (incr && chg && mov) atomicAdd((u64*)&orow[e], (u64)(-(i64)im[e]));
                         }
                     }
-                } else if (cell < lds_cells) {  // wave-uniform
+                } else if (cell < lds_cells) {  // wave-uniform (two branches: an LDS and a global address are not mixed in one pointer)
                     i64* row = lacc + cell * RS;
-                    if (lane < NE) atomicAdd((u64*)&row[lane], (u64)(i64)im[lane]);
-                    if (NE > 64 && lane < NE - 64) atomicAdd((u64*)&row[64 + lane], (u64)(i64)im[64 + lane]);
+#pragma unroll
+                    for (int e0 = 0; e0 < NE; e0 += 64) {  // (rows of any length: P = 80 has 167 elements)
+                        const int e = e0 + lane;
+                        if (e < NE) atomicAdd((u64*)&row[e], (u64)(i64)im[e]);
+                    }
                 } else {
                     i64* row = rows + (long)cell * RS;
-                    if (lane < NE) atomicAdd((u64*)&row[lane], (u64)(i64)im[lane]);
-                    if (NE > 64 && lane < NE - 64) atomicAdd((u64*)&row[64 + lane], (u64)(i64)im[64 + lane]);
+#pragma unroll
+                    for (int e0 = 0; e0 < NE; e0 += 64) {
+                        const int e = e0 + lane;
+                        if (e < NE) atomicAdd((u64*)&row[e], (u64)(i64)im[e]);
+                    }
                 }
             }
         }

@@ -19,7 +19,8 @@ struct DevScalars {
 inline int row_stride(int NC) { return (2 * NC + 5 + 7) & ~7; }
 inline int cb_pad(int NC) { return (NC + 7) & ~7; }
 
-bool uses_mfma(int NC);            // P = 4 .. 40: the sweep runs on the FP64 matrix pipe
+bool uses_mfma(int NC);            // P = 4 .. 80: the sweep runs on the FP64 matrix pipe
+bool mfma_is_wide(int NC);         // P = 41 .. 80: half blocks per wave; no LDS-table accumulate, no row-major quantize sweep
 int mfma_hybrid_cells(int NC);     // cells of the hybrid accumulate's LDS table
 // generic orders (P > 40): scratch for the transposed codebook of k_pass_generic_lds, passed to launch_pass in the cbm slot
 inline long generic_scratch_doubles(int NC, int M) { return (long)NC * ((M + 7) / 8 * 8); }

@@ -224,9 +224,14 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
 {
     constexpr bool AOS = SRC == 1;
     // frame tiles (of 16) per wave: the fallback list is short, so its waves take one tile each -- four times as
-    // many waves, each a quarter of the latency of a full 64-frame sweep
-    constexpr int NFT = SRC == 2 ? 1 : 4;
+    // many waves, each a quarter of the latency of a full 64-frame sweep.  Prediction orders 41 .. 80 (round 4): two
+    // tiles -- a wave takes one 32-frame half of a block, whose operands (up to 88 registers) fit beside two sets of
+    // codeword-tile operands where those of four tiles would not
+    constexpr bool WIDE = NC > 41;
+    constexpr int NFT = SRC == 2 ? 1 : (WIDE ? 2 : 4);
     constexpr int FPB = 16 * NFT;
+    static_assert(!WIDE || (SRC == 0 && (MODE == 0 || MODE == 2)), "wide orders: assignment and global-atomic accumulate only");
+    if constexpr (WIDE) nblocks *= 2;  // (half blocks; frames beyond T in the last one are zero padding, as ever)
     // ... and the waves of a workgroup split the codebook of ONE tile between them (the list is latency-bound: a
     // single wave walking all M / 16 codeword tiles takes ~50 us at M = 1024), then combine through LDS
     constexpr int SPLIT = SRC == 2 ? TPBM / 64 : 1;
@@ -347,6 +352,15 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                     // (list_rowmajor: the listed frames are rows of the row-major .prd payload -- quantize)
                     Bf[ft][st] = (t >= 0 && n >= 0) ? blk[list_rowmajor ? t * NC + n : mfma_blk_offset(NC, t, n)] : 0.0;
                 }
+            }
+        } else if constexpr (WIDE) {
+            double Hf[2][2 * NP];
+            load_half_frames<NC>(blk, b >> 1, (int)(b & 1), lane, Hf);
+#pragma unroll
+            for (int st = 0; st < 2 * NP; ++st) {
+                Bf[0][st] = Hf[0][st];
+                Bf[1][st] = Hf[1][st];
+                Bf[2][st] = Bf[3][st] = 0.0;
             }
         } else {
             load_block_frames<NC>(blk, b, lane, Bf);
@@ -1345,7 +1359,12 @@ static inline int grid_for(long work_items, int per_block, int cap)
 #define E2VQ_MFMA_NC_LIST(X) \
     X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) \
     X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41)
-bool uses_mfma(int NC) { return NC >= 5 && NC <= 41; }
+// ... and, round 4, P = 41 .. 80 (NC = 42 .. 81) with half blocks per wave (assignment and global-atomic accumulate)
+#define E2VQ_MFMA_WIDE_NC_LIST(X) \
+    X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) \
+    X(62) X(63) X(64) X(65) X(66) X(67) X(68) X(69) X(70) X(71) X(72) X(73) X(74) X(75) X(76) X(77) X(78) X(79) X(80) X(81)
+bool uses_mfma(int NC) { return NC >= 5 && NC <= 81; }
+bool mfma_is_wide(int NC) { return NC > 41 && NC <= 81; }
 int mfma_hybrid_cells(int NC) { return mfma_hyb_cells(NC); }
 
 // maxabs_bits / bad (optional): when given and the MFMA layout is used, the scan of max |x| rides along; returns
@@ -1381,6 +1400,7 @@ void launch_global_sums(const double* blk, long nblocks, int NC, int FB, const D
 #define X(N) \
     case N: hipLaunchKernelGGL((k_global_sums_mfma<N>), g, dim3(256), 0, s, blk, nblocks, sc, stats); return;
         E2VQ_MFMA_NC_LIST(X)
+        E2VQ_MFMA_WIDE_NC_LIST(X)
 #undef X
         default: break;
     }
@@ -1453,6 +1473,28 @@ static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, c
 }
 
 
+// prediction orders 41 .. 80: assignment only (mode 0) or accumulate with global atomics (any other mode)
+template <int NC>
+static int launch_pass_mfma_wide(int mode, const double* blk, long T, long nblocks, const double* cbm, int M,
+                                 const DevScalars* sc, const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows,
+                                 hipStream_t s)
+{
+    constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
+    const int MT = (M + 15) / 16;
+    if (mode == 0) {
+        const int grid = grid_for(2 * nblocks, 4, 1024);
+        hipLaunchKernelGGL((k_pass_mfma<NC, 0, 256>), dim3(grid), dim3(256), 0, s, blk, T, nblocks, cbm, MT, M, sc,
+                           l1max_bits, sym, dmin, rows, 0);
+    } else {
+        const size_t lds = (size_t)8 * 16 * IMG * 4;
+        (void)hipFuncSetAttribute((const void*)k_pass_mfma<NC, 2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, E2VQ_LDS_BYTES);
+        const int grid = grid_for(2 * nblocks, 8, 256);
+        hipLaunchKernelGGL((k_pass_mfma<NC, 2, 512>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, MT, M, sc,
+                           l1max_bits, sym, dmin, rows, 0);
+    }
+    return 0;
+}
+
 int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const double* cbq, const double* cbm,
                 int M, const DevScalars* sc, const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows,
                 hipStream_t s)
@@ -1461,6 +1503,10 @@ int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const
 #define X(N) \
     case N: return launch_pass_mfma<N>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
         E2VQ_MFMA_NC_LIST(X)
+#undef X
+#define X(N) \
+    case N: return launch_pass_mfma_wide<N>(mode, blk, T, nblocks, cbm, M, sc, l1max_bits, sym, dmin, rows, s);
+        E2VQ_MFMA_WIDE_NC_LIST(X)
 #undef X
         default: break;
     }

@@ -722,7 +722,7 @@ extern "C" int e2vq_grow(e2vq_session* s)
 static int pass_mode(const e2vq_session* s)
 {
     if (const char* f = getenv("ECOZ2_VQ_FORCE_MODE")) return atoi(f);  // diagnostics only (0 = assignment only)
-    if (e2vq::uses_mfma(s->NC)) {
+    if (e2vq::uses_mfma(s->NC) && !e2vq::mfma_is_wide(s->NC)) {
         // all cells in the workgroup's LDS table while it fits beside the row images (NC = 37: M <= 128) ...
         const long images = 8L * 16 * (2 * s->NC + 5 + 3) * 4;
         if ((long)s->M * s->RS * 8 + images + 2048 <= E2VQ_LDS_BYTES && s->M <= 128) return 1;
@@ -1510,7 +1510,7 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
         HIPCHK(hipGetLastError());
         return 0;
     }
-    if (e2vq::uses_mfma(s->NC) && ((uintptr_t)device_frames & 15) == 0) {
+    if (e2vq::uses_mfma(s->NC) && !e2vq::mfma_is_wide(s->NC) && ((uintptr_t)device_frames & 15) == 0) {
         // P = 36: the sweep reads the row-major payload directly (coalesced staging through LDS)
         e2vq::launch_pass(s->NC, 4, (const double*)device_frames, T, nb, s->d_cbq, s->d_cbm, s->M, s->d_sc, s->d_l1max,
                           (unsigned short*)device_sym, (double*)device_dmin, nullptr, s->stream);

@@ -112,12 +112,14 @@ def test_invalid_inputs_fail_loudly():
         e.vq_quantize("/nonexistent.cbook", [])
 
 
-@pytest.mark.parametrize("Pn", [4, 7, 10, 12, 16, 20, 24, 30, 33, 35, 38, 40, 44])
+@pytest.mark.parametrize("Pn", [4, 7, 10, 12, 16, 20, 24, 30, 33, 35, 38, 40, 41, 44, 48, 63, 64, 65, 79, 80, 81])
 def test_other_prediction_orders(oracle, Pn):
-    """Every P = 4..40 runs on the matrix pipe (NC = 4k+1: trailing coefficient on the VALU; otherwise a zero-padded
-    last k-step with 2, 3 or 4 live coefficients); larger orders (44 here) use the generic VALU kernel."""
+    """Every P = 4..80 runs on the matrix pipe (NC = 4k+1: trailing coefficient on the VALU; otherwise a zero-padded
+    last k-step with 2, 3 or 4 live coefficients; P > 40, round 4: a wave sweeps a 32-frame half block, the accumulate goes
+    straight to global atomics, P > 63 with the thread-per-cell update kernels); larger orders (81 here) use the LDS-staged
+    VALU kernel."""
     frames = e.synth.synth_frames(41, 3, Pn, 0, 3000)
-    max_m = 256 if Pn in (7, 10, 12, 24, 30, 33, 35, 38, 40) else 8  # 256: LDS-table and hybrid accumulate modes
+    max_m = 256 if Pn in (7, 10, 12, 24, 30, 33, 35, 38, 40, 48, 64) else 8  # 256: LDS-table and hybrid accumulate modes
     rc, levels_o, cbs_o = oracle.learn(frames, 0.05, max_m)
     assert rc == 0
     cbs = []

@@ -62,7 +62,7 @@ def main():
     bad = 0
     t0 = time.time()
     for case in range(n):
-        P = int(rng.choice([36, 36, 36, int(rng.integers(4, 41)), int(rng.integers(4, 41)), int(rng.integers(41, 60))]))
+        P = int(rng.choice([36, 36, 36, int(rng.integers(4, 41)), int(rng.integers(4, 41)), int(rng.integers(41, 90))]))
         T = int(rng.choice([rng.integers(1, 200), rng.integers(200, 6000), rng.integers(6000, 40000)]))
         M = int(rng.choice([rng.integers(1, 20), rng.integers(20, 200), rng.integers(200, 700), rng.integers(700, 1500)]))
         frames = e.synth.synth_frames(int(rng.integers(1, 1 << 30)), int(rng.integers(1, 8)), P, int(rng.integers(0, 1000)), T)
