@@ -645,10 +645,10 @@ def run(args, comm):
         k_ms = kernel_ms_total / kernel_passes
         frames_per_launch = S
         # PMC traffic cannot be collected inside this process: it comes from separate rocprofv3 --pmc passes over this
-        # same command (tools/summarize_profiles.py -> profiles/r03_traffic*.json).  The file records the hash of the
+        # same command (tools/summarize_profiles.py -> profiles/r04_traffic*.json).  The file records the hash of the
         # kernel sources it was measured on; a figure measured on other sources is reported as stale (null).
         traffic, traffic_detail = None, None
-        tname = "r03_traffic" + ("" if M == 1024 else f"_M{M}") + ("" if prefiltered else "_noprefilter") + ".json"
+        tname = "r04_traffic" + ("" if M == 1024 else f"_M{M}") + ("" if prefiltered else "_noprefilter") + ".json"
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and S == FRAMES_PER_GPU:
             try:
