@@ -63,7 +63,25 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                             long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
                             hipStream_t s, const double* rowmajor_frames = nullptr, const int* ea_fused = nullptr,
                             const double* resident_rowmajor = nullptr, long long* family_table = nullptr,
-                            bool assign_only = false);
+                            bool assign_only = false, const struct PassRecords* records = nullptr);
+// records (accumulate, resident_rowmajor): the accumulating kernel RECORDS the frames that contribute instead of adding them
+// -- (frame, cell within its bin, sign) as 8 bytes into the region of (sweeping workgroup, bin of cells), positions from
+// per-workgroup LDS counters -- and launch_reduce_records folds them into the rows through LDS tables, one workgroup per
+// (bin, slice of the regions): work that follows the number of contributions.  Plan with prefilter_records_plan.
+struct PassRecords {
+    void* recs;        // grid * nbins * cap records of 8 bytes
+    int* counts;       // grid * nbins
+    int grid;          // workgroups of the sweep (= regions per bin)
+    int nbins;         // bins of rows + bins of the family side table
+    int nbins_rows;
+    int bin_cells;     // cells per bin (the LDS table of a reducing workgroup)
+    unsigned magic;    // cell / bin_cells == (cell * magic) >> 22 for every cell of the plan
+    int cap;           // records per region
+};
+// fills everything but the two pointers; false: no plan (order / size not served).  bytes: what recs needs.
+bool prefilter_records_plan(int NC, int M, bool family, long nblocks, PassRecords* plan, size_t* recs_bytes);
+int launch_reduce_records(int NC, const double* aos, const PassRecords& plan, bool few, const DevScalars* sc, long long* rows,
+                          long long* family_table, hipStream_t s);
 // assign_only (accumulate = false, resident_rowmajor and sym given): the accumulating kernel's sweep, outputs and
 // distortion sums (into `rows`) without its cell sums; sym[t] = 0xFFFF marks a frame left to the fallback sweep.
 // launch_accumulate_ranges then adds the cell sums from the symbols, pre-aggregated per (chunk of frames, range of cells)

@@ -97,6 +97,7 @@ struct e2vq_session {
     bool spec_valid = false;
     bool spec_zeroed = false;  // the pass prologue zeroed d_l1max_spec and the shadow image's scalars
     hipEvent_t ev_stats = nullptr;
+    bool stats_event = false;  // ECOZ2_VQ_STATS_EVENT=1: an event behind the statistics kernel instead of stream queries (A/B)
     struct HostStats { i64 l[64 * 8]; u64 l1bits; volatile u64 seq; i64 failed; volatile u64 seq2; volatile u64 err; }* h_stats = nullptr;  // pinned, host-mapped
     long verified_passes = 0;
     bool verify_publish = false;  // ECOZ2_VQ_VERIFY_PUBLISH: recompute every published statistic on the host from the rows
@@ -175,6 +176,17 @@ struct e2vq_session {
     // 1.06-1.11, but k_accum_ranges costs 0.17-0.42 / 0.21-0.46 / 0.29-0.55 ms on top (a workgroup per chunk and cell
     // range: its cost follows the number of ranges, not the number of movers): a gain at M = 256 only
     int split_max_M = 256;
+    // round 4: the RECORDED accumulate -- the accumulating sweep writes an 8-byte record per contribution into the region
+    // of (sweeping workgroup, bin of cells), k_reduce_records folds the records into the rows through LDS tables
+    // (vq_prefilter.hip).  ECOZ2_VQ_RECORDS=0: the paths above (k_accum_ranges up to split_max_M, the fused burst of
+    // atomics beyond); ECOZ2_VQ_RECORDS_MAX_MB bounds the record buffer (default 8192: it is sized for the worst case, every
+    // frame of a workgroup in one bin, i.e. 16 bytes x frames x bins)
+    bool rec_enabled = true;
+    int rec_min_M = 64;
+    size_t rec_max_bytes = (size_t)8192 << 20;
+    void* d_recs = nullptr;
+    size_t recs_cap = 0;
+    int* d_rec_counts = nullptr;
     i64* d_rows_local = nullptr;  // world > 1: the un-reduced rows (d_rows holds the all-reduced copy)
     int rows_local_cap = 0;
     // the seeded first pass of a level (vq_device.hip: k_seed_family): the rank's own rows of the last pass at the previous
@@ -309,6 +321,10 @@ static int session_init(e2vq_session* s)
     if (const char* fm = getenv("ECOZ2_VQ_FAMILY")) s->fam_enabled = atoi(fm) != 0;
     if (const char* fm = getenv("ECOZ2_VQ_FAMILY_MIN_M")) s->fam_min_M = std::max(64, atoi(fm));
     if (const char* sm = getenv("ECOZ2_VQ_SPLIT_ACC_MAX_M")) s->split_max_M = std::max(0, atoi(sm));
+    if (const char* se = getenv("ECOZ2_VQ_STATS_EVENT")) s->stats_event = atoi(se) != 0;
+    if (const char* rc = getenv("ECOZ2_VQ_RECORDS")) s->rec_enabled = atoi(rc) != 0;
+    if (const char* rc = getenv("ECOZ2_VQ_RECORDS_MIN_M")) s->rec_min_M = std::max(64, atoi(rc));
+    if (const char* rc = getenv("ECOZ2_VQ_RECORDS_MAX_MB")) s->rec_max_bytes = (size_t)std::max(0, atoi(rc)) << 20;
     if (s->pre_enabled) {
         HIPCHK(hipMalloc(&s->d_colmax, (size_t)s->NC * 8));
         HIPCHK(hipMalloc(&s->d_ea, (size_t)s->NC * sizeof(int)));
@@ -355,7 +371,7 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     void* ptrs[] = {s->d_cbT, s->sv.refl, s->sv.rows, s->sv.rows_local, s->sv.cells, s->d_rows_parent, s->d_fam, s->d_aos, s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
-                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg2[0], s->d_cimg2[1], s->d_ps2[0], s->d_ps2[1], s->d_ps, s->d_fblist, s->d_prev_sym, s->d_cells_new, s->d_rows_local,
+                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg2[0], s->d_cimg2[1], s->d_ps2[0], s->d_ps2[1], s->d_ps, s->d_fblist, s->d_prev_sym, s->d_cells_new, s->d_rows_local, s->d_recs, s->d_rec_counts,
                     s->d_ea_q, s->d_qfimg, s->d_qfg, s->d_qfblist, s->d_qcimg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -752,9 +768,23 @@ static bool use_prefilter(const e2vq_session* s, int mode)
            e2vq::prefilter_supports(s->NC, s->M);
 }
 
+// the recorded accumulate for accumulating prefiltered passes at this codebook size?  (plan: filled in but for the pointers)
+static bool records_plan(const e2vq_session* s, int M, bool family, e2vq::PassRecords* plan, size_t* bytes)
+{
+    e2vq::PassRecords p{};
+    size_t b = 0;
+    if (!(s->rec_enabled && s->pre_enabled && s->incr_enabled && s->d_aos && s->d_prev_sym && M >= s->pre_min_M &&
+          M >= s->rec_min_M && e2vq::prefilter_records_plan(s->NC, M, family, s->nblocks, &p, &b) && b <= s->rec_max_bytes))
+        return false;
+    if (plan) *plan = p;
+    if (bytes) *bytes = b;
+    return true;
+}
+
 // assignment-only sweep + k_accum_ranges for accumulating prefiltered passes at this codebook size?
 static bool split_accumulate(const e2vq_session* s, int M)
 {
+    if (records_plan(s, M, false, nullptr, nullptr)) return false;
     return s->pre_enabled && s->incr_enabled && s->d_aos && s->d_cells_new && s->d_prev_sym && M <= s->split_max_M &&
            M >= s->pre_min_M && e2vq::prefilter_supports(s->NC, M) && e2vq::prefilter_lds_stage(s->NC) &&
            e2vq::accumulate_ranges_supported(s->NC);
@@ -804,10 +834,40 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     // the first pass after a split, seeded with the parents' sums (e2vq_grow stashed them): k_seed_family
     const bool family = s->fam_pending && keep && !incremental && !split && s->d_aos && 2 * s->fam_M == s->M && mode != 0;
     s->fam_pending = false;
+    // round 4: contributions recorded by the sweep, folded into the rows by k_reduce_records
+    e2vq::PassRecords recplan{};
+    bool records = false;
+    if (keep && !split && mode != 0) {
+        size_t bytes = 0;
+        records = records_plan(s, s->M, family, &recplan, &bytes);
+        if (records && bytes > s->recs_cap) {
+            // (grown rarely: sized at once for a codebook four times this one's when the limit allows)
+            size_t want = bytes;
+            e2vq::PassRecords big{};
+            size_t bb = 0;
+            if (4 * s->M <= 4096 && e2vq::prefilter_records_plan(s->NC, 4 * s->M, true, s->nblocks, &big, &bb) && bb <= s->rec_max_bytes / 4)
+                want = std::max(want, bb);
+            if (s->d_recs) HIPCHK(hipFree(s->d_recs));
+            s->d_recs = nullptr;
+            s->recs_cap = 0;
+            if (hipMalloc(&s->d_recs, want) == hipSuccess) {
+                s->recs_cap = want;
+            } else {
+                (void)hipGetLastError();
+                if (want > bytes && hipMalloc(&s->d_recs, bytes) == hipSuccess)
+                    s->recs_cap = bytes;
+                else
+                    (void)hipGetLastError(), records = false;  // (no room: the burst of atomics instead)
+            }
+        }
+        if (records && !s->d_rec_counts) HIPCHK(hipMalloc(&s->d_rec_counts, 256 * 64 * sizeof(int)));
+        recplan.recs = s->d_recs;
+        recplan.counts = s->d_rec_counts;
+    }
     // The first pass of a level accumulates in full.  For the smallest prefiltered sizes that is cheaper on the plain
     // FP64 sweep with its workgroup-local LDS table (hybrid accumulate: 0.92 vs 1.5 ms at M = 256, where 2^21 frames
     // hammer 256 rows with global atomics); it records the cells for the incremental passes that follow.
-    const bool plain_first = s->plain_first && keep && !incremental && !family && !split && mode == 5 && s->M <= 384;
+    const bool plain_first = s->plain_first && keep && !incremental && !family && !split && !records && mode == 5 && s->M <= 384;
     if (s->last_prefiltered && !plain_first && ensure_codebook_image(s)) return 1;
     {
         // one prologue launch: the rows (all of them, or the distortion columns of an incremental pass), the fallback
@@ -886,11 +946,16 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             else
                 std::swap(s->d_prev_sym, s->d_cells_new);
         } else {
-        e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, d_cimg, d_ps,
-                                      s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
-                                      (double*)device_dmin, rows, s->d_fblist, keep ? s->d_prev_sym : nullptr,
-                                      incremental, /*hybrid_table=*/mode == 5 && !incremental && !family, s->stream, nullptr,
-                                      nullptr, s->d_aos, family ? s->d_fam : nullptr);
+        if (e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, d_cimg, d_ps,
+                                          s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
+                                          (double*)device_dmin, rows, s->d_fblist, keep ? s->d_prev_sym : nullptr,
+                                          incremental, /*hybrid_table=*/mode == 5 && !incremental && !family && !records, s->stream,
+                                          nullptr, nullptr, s->d_aos, family ? s->d_fam : nullptr, false,
+                                          records ? &recplan : nullptr))
+            return e2vq_set_error("prefiltered sweep: unsupported configuration");
+        if (records && e2vq::launch_reduce_records(s->NC, s->d_aos, recplan, incremental, s->d_sc, rows,
+                                                   family ? s->d_fam : nullptr, s->stream))
+            return e2vq_set_error("k_reduce_records: unsupported configuration");
         if (s->timing) {
             HIPCHK(hipEventRecord(s->ev1, s->stream));
             s->timed = true;
@@ -997,7 +1062,10 @@ static int spin_for_sequence(e2vq_session* s, volatile u64* word, const char* wh
 {
     for (unsigned long spins = 0; *word != s->stats_seq; ++spins) {
         if ((spins & 0xfff) == 0xfff) {
-            const hipError_t q = hipEventQuery(s->ev_stats);
+            // (the safety net: the stream has drained and the number never came.  A stream query, not an event recorded
+            // behind the kernel: the event's marker packet sat between the update and the next kernel of the stream and
+            // cost ~5 us of idle GPU per pass)
+            const hipError_t q = s->stats_event ? hipEventQuery(s->ev_stats) : hipStreamQuery(s->stream);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) return e2vq_set_error("%s failed: %s", what, hipGetErrorString(q));
             (void)hipGetLastError();  // (hipErrorNotReady is sticky for hipGetLastError: nobody downstream should see it)
@@ -1138,7 +1206,7 @@ static int pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_fai
                                  /*zero_first=*/false, image ? s->d_ea : nullptr,
                                  image ? e2vq::prefilter_codebook_scale(s->d_ps2[k]) : nullptr, &pub);
         s->failed_pending = true;
-        HIPCHK(hipEventRecord(s->ev_stats, s->stream));
+        if (s->stats_event) HIPCHK(hipEventRecord(s->ev_stats, s->stream));
         if (image) {
             e2vq::launch_prefilter_codebook(s->d_cbq_spec, s->M, s->NC, s->d_ea, s->d_ps2[k], s->d_cimg2[k], s->stream,
                                             /*scale_ready=*/true);
@@ -1150,7 +1218,7 @@ static int pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_fai
         e2vq::launch_rows_stats(s->d_rows, s->M, s->NC, s->d_sc, s->d_S, s->d_within, s->d_lstats, s->stream);
         e2vq::launch_publish_stats(s->d_lstats, s->d_l1max, s->d_within, s->M, dstats->l, &dstats->l1bits, (double*)dw,
                                    (u64*)&dstats->seq, ++s->stats_seq, s->stream);
-        HIPCHK(hipEventRecord(s->ev_stats, s->stream));
+        if (s->stats_event) HIPCHK(hipEventRecord(s->ev_stats, s->stream));
         e2vq::launch_centroids(s->d_rows, s->d_S, s->M, s->NC, s->d_refl, s->d_refl_spec, s->d_lstats, s->stream);
         s->lstats_dirty = true;
         e2vq::launch_codebook_prepare(s->d_refl_spec, s->M, s->NC, s->d_cbq_spec, s->d_l1max_spec, s->d_cbm_spec,

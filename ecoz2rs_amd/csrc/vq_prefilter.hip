@@ -1144,7 +1144,15 @@ __device__ __forceinline__ void pre_load_tile_asm(h8 (&A)[PrePack<NC>::NU], cons
     pre_load_tile_wait<NC>(A);
 }
 
-template <int NC, bool ROT, bool ACCUM>
+// records of the ACC = 2 pass (vq_device.h: PassRecords), as the kernels see them
+struct PreRec {
+    uint2* recs;
+    int* counts;
+    int nbins, nbins_rows, bin_cells, cap;
+    unsigned magic;
+};
+
+template <int NC, bool ROT, int ACC>
 __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restrict__ aos, long T, long nblocks,
                                                          const h8* __restrict__ fimg, const float* __restrict__ fg,
                                                          const h8* __restrict__ cimg, PreScalars* __restrict__ ps,
@@ -1154,15 +1162,18 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
                                                          unsigned short* __restrict__ sym, double* __restrict__ dmin,
                                                          i64* __restrict__ rows, int* __restrict__ fb_list, int stagger,
                                                          unsigned short* __restrict__ prev_sym, int incr,
-                                                         i64* __restrict__ fam)
+                                                         i64* __restrict__ fam, PreRec rec)
 {
+    constexpr bool ACCUM = ACC != 0;
     // incr: 0 = full accumulation; 1 = incremental (rows and cells of the previous pass persist: only frames that changed
     // cell are moved); 2 = the seeded first pass of a level (vq_device.hip, k_seed_family): a frame's old cell is the even
     // child 2 * prev_sym of the cell it had at the previous size; one that lands in the odd child 2 * prev_sym + 1 adds its
     // limbs to row prev_sym of the side table `fam` and nothing else
-    // ACCUM = false (round 4): the pass only assigns -- `sym` receives every frame's cell, 0xFFFF for a frame left to the
+    // ACC = 0 (round 4): the pass only assigns -- `sym` receives every frame's cell, 0xFFFF for a frame left to the
     // fallback sweep -- and adds the distortion sums; k_accum_ranges does the cell sums from the symbols (incr, prev_sym and
-    // fam are not used)
+    // fam are not used).  ACC = 1: the cell sums as a burst of atomics per block.  ACC = 2: the contributions are RECORDED
+    // -- 8 bytes each, into the region of (this workgroup, bin of cells) -- and k_reduce_records adds them up (`fam` is
+    // not used: a frame that lands in the odd child of its family is recorded for the side table's bin)
     typedef PrePack<NC> PK;
     typedef PreLds<NC> PL;
     constexpr int TPBM = 512;
@@ -1179,6 +1190,12 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
     const float* fgs = (const float*)(wbase + PL::STAGE_BYTES);
     const unsigned short* prevs = (const unsigned short*)(wbase + PL::STAGE_BYTES + 256);
     E2VQ_STAMP_DECL
+    // (ACC = 2) records written so far into each of this workgroup's regions: one LDS word per bin, behind the waves' regions
+    int* const rcnt = (int*)(smem + (size_t)8 * PL::WAVE_BYTES);
+    if constexpr (ACC == 2) {
+        if (threadIdx.x < 64) rcnt[threadIdx.x] = 0;
+        __syncthreads();
+    }
 
     const int sh_r = sc->sh_r;
     const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
@@ -1418,9 +1435,9 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
 
         u64 movers = 0;
         bool bulk = false;
-        if constexpr (ACCUM) {
         // ---- frames that contribute: all of a full pass, the movers of an incremental one ---------------------------------
-        const bool mov = live && !skip && (!incr || old != idx);
+        const bool mov = ACCUM && live && !skip && (!incr || old != idx);
+        if constexpr (ACC == 1) {
         // Many contributors (a full pass; the first incremental pass of a level): every contributing lane converts its own
         // row to limb pairs in place -- 37 conversions per lane, whatever the number of contributors.  Few: the lanes of
         // each atomic convert just the value they add (below) -- one conversion per lane and contributor.
@@ -1449,7 +1466,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        }  // ACCUM
+        }  // ACC == 1
         E2VQ_STAMP(5)  // limb conversion (bulk)
 
         // ---- the block's atomics, four frames per step ------------------------------------------------------------------
@@ -1457,7 +1474,41 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         // first atomic: nothing may wait on the vector-memory counter from here to tile 2 of the next block.  The builtin
         // (not inline asm) so that the compiler's own counter bookkeeping sees it and inserts no later wait for those registers.
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        if constexpr (ACCUM) {
+        if constexpr (ACC == 2) {
+            // A contribution = (frame, cell, sign): '+' for the cell the frame is in now -- row `old >> 1` of the side table
+            // when it landed in the odd child of its family (seeded pass) --, '-' for the cell an incremental mover left.
+            // Records of one bin go to this workgroup's region of that bin, at positions handed out by the LDS counter:
+            // per distinct bin among the wave's records one round of ballots gives every record its rank and lane `bin` the
+            // count; ONE ds_add_rtn (lane = bin) reserves the space for all bins, two shuffles hand the bases back.
+            const bool infam = incr == 2 && idx == old + 1;
+            const int vN = infam ? rec.nbins_rows * rec.bin_cells + (old >> 1) : idx;
+            const bool hasN = mov, hasO = mov && incr != 0 && !infam;
+            const int binN = (int)(((unsigned)vN * rec.magic) >> 22), binO = (int)(((unsigned)old * rec.magic) >> 22);
+            int rankN = 0, rankO = 0, cntv = 0;
+            u64 pn = __ballot(hasN), po = __ballot(hasO);
+            while ((pn | po) != 0) {
+                const int r = pn != 0 ? __builtin_amdgcn_readlane(binN, (int)__builtin_ctzll(pn))
+                                      : __builtin_amdgcn_readlane(binO, (int)__builtin_ctzll(po));
+                const bool inN = hasN && binN == r, inO = hasO && binO == r;
+                const u64 sn = __ballot(inN), so = __ballot(inO);
+                const int cn = __builtin_popcountll(sn);
+                if (inN) rankN = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sn >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sn, 0u));
+                if (inO) rankO = cn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(so >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)so, 0u));
+                if (ln == r) cntv = cn + __builtin_popcountll(so);
+                pn &= ~sn;
+                po &= ~so;
+            }
+            int basev = 0;
+            if (cntv > 0) basev = __hip_atomic_fetch_add(&rcnt[ln], cntv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int baseN = __shfl(basev, binN, 64), baseO = __shfl(basev, binO, 64);
+            uint2* const region0 = rec.recs + (size_t)blockIdx.x * (size_t)rec.nbins * (size_t)rec.cap;
+            if (hasN)
+                region0[(size_t)binN * rec.cap + (baseN + rankN)] = make_uint2((unsigned)t, (unsigned)(vN - binN * rec.bin_cells));
+            if (hasO)
+                region0[(size_t)binO * rec.cap + (baseO + rankO)] =
+                    make_uint2((unsigned)t, (unsigned)(old - binO * rec.bin_cells) | 0x10000u);
+        }
+        if constexpr (ACC == 1) {
             u64 mm = movers;
             const int tq = ln >> 4, te = ln & 15;
             constexpr int NE = PL::NE;            // limb pairs + count
@@ -1536,6 +1587,10 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
     }
 #undef E2VQ_LDS_LOAD_A
 #undef E2VQ_LDS_LOAD_B
+    if constexpr (ACC == 2) {  // what each of the workgroup's regions holds
+        __syncthreads();
+        if ((int)threadIdx.x < rec.nbins) rec.counts[(size_t)blockIdx.x * rec.nbins + threadIdx.x] = rcnt[threadIdx.x];
+    }
 #ifdef E2VQ_PRE_STAMP
     {
         E2VQ_STAMP_START
@@ -1669,6 +1724,246 @@ __global__ __launch_bounds__(ACC_TPB, 2) void k_accum_ranges(const double* __res
     for (int i = threadIdx.x; i < ncell * RS; i += ACC_TPB) {
         const i64 v = table[i];
         if (v != 0) atomicAdd((u64*)&rows[(long)lo * RS + i], (u64)v);
+    }
+}
+
+// ---- k_reduce_records (round 4): folds the records of an ACC = 2 pass into the rows ---------------------------------------
+// The sweep wrote one 8-byte record per contribution -- (frame, cell within its bin | sign << 16) -- into the region of
+// (sweeping workgroup, bin); the regions' fill counts are in `counts`.  grid = bins x slices: a workgroup owns one bin
+// (<= REC_BIN_CELLS cells) and the regions of the sweeping workgroups s, s + nslices, ... of that bin, which it walks as ONE
+// list (prefix sums of their counts in LDS), REC_CHUNK records at a time:
+//   1. counting sort of the chunk by cell, in LDS: one ds_add_rtn per record gives its rank within its cell, a scan of the
+//      counts the cells' offsets, and every record's (frame | sign << 31) goes to its sorted place;
+//   2. every wave walks an equal span of the sorted chunk, eight records at a time (the next eight rows are already
+//      requested): lane n loads coefficient n of the row (296 B, coalesced), converts it to its two limbs and adds them --
+//      negated for a '-' record -- to two 64-bit sums IN REGISTERS;
+//   3. where the cell changes (and at the span's end) the sums are added to the bin's table in LDS -- not to global memory:
+//      a wave's vector-memory operations retire in order, the next rows would wait behind the atomics --; at the end the
+//      table's non-zero words go to the global rows with one atomic each (the family side table for the bins behind the rows').
+// A table's ds_add_u64 retires one to two lanes per clock and CU: adding every RECORD to it (75 lane-adds) bounded the first
+// version of this kernel (and k_accum_ranges) at ~75 clocks per record and CU, whatever the number of waves.  Here a
+// record costs two 32-bit LDS atomics, one row load and ~15 vector instructions, and the table sees one add per (span, cell).
+// The work follows the number of contributions, not the number of frames; a workgroup whose regions are empty returns at
+// once.  Exact 64-bit integers: any order, same bits.
+constexpr int REC_BIN_CELLS = 60;   // x 640 B (NC = 37) = 38 KB of table + 25 KB: two workgroups per CU
+constexpr int REC_BIN_CELLS_BIG = 120;  // (codebooks that would need more than 64 bins of 60 cells)
+constexpr int REC_TPB = 512;
+constexpr int REC_PER_THREAD = 4;
+constexpr int REC_CHUNK = REC_TPB * REC_PER_THREAD;
+constexpr int REC_BATCH = 8;
+
+template <int NC>
+__global__ __launch_bounds__(REC_TPB, 4) void k_reduce_records(const double* __restrict__ aos, PreRec rec, int nregions,
+                                                            const DevScalars* __restrict__ sc,
+                                                            i64* __restrict__ rows, i64* __restrict__ fam)
+{
+    constexpr int RS = (2 * NC + 5 + 7) & ~7;
+    static_assert(NC < 64, "lane n = coefficient n, lane NC = the count");
+    __shared__ int pre[260];      // pre[k] = the bin's records in front of region k; pre[256] = all
+    __shared__ int hist[128];     // records of the chunk per cell
+    __shared__ int start[128];    // offset of a cell's records in `sorted`
+    __shared__ unsigned sorted[REC_CHUNK];
+    __shared__ unsigned char scell[REC_CHUNK];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    i64* const table = (i64*)smem;  // bin_cells x RS
+    // ---- which records are this workgroup's: the bins share the grid in proportion to their totals (a seeded pass puts half
+    // of all records into the side table's bins), a bin's share divides the bin's list -- its regions one after the other --
+    // into equal portions.  Every workgroup derives the same plan from the counts (grid x bins words, out of L2).
+    __shared__ int btot[64];   // records per bin
+    __shared__ int ubase[65];  // first workgroup of a bin
+    const int lane0 = threadIdx.x & 63;
+    {
+        const int b = (int)threadIdx.x >> 3, part = (int)threadIdx.x & 7;  // eight threads per bin
+        int sum = 0;
+        if (b < rec.nbins)
+            for (int w = part; w < nregions; w += 8) sum += rec.counts[(size_t)w * rec.nbins + b];
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        sum += __shfl_xor(sum, 4, 64);
+        if (b < 64 && part == 0) btot[b] = b < rec.nbins ? sum : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // wave 0: lane = bin
+        const int tb = btot[lane0];
+        long all = tb;
+        for (int d = 32; d >= 1; d >>= 1) all += __shfl_xor(all, d, 64);
+        const int nonempty = __builtin_popcountll(__ballot(tb > 0));
+        const long spare = (long)gridDim.x - nonempty;  // (the launch has at least one workgroup per bin)
+        int u = tb > 0 ? 1 + (int)((long)tb * spare / (all > 0 ? all : 1)) : 0;
+        int v = u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(v, d, 64);
+            if (lane0 >= d) v += o;
+        }
+        ubase[lane0] = v - u;
+        if (lane0 == 63) ubase[64] = v;
+    }
+    __syncthreads();
+    if ((int)blockIdx.x >= ubase[64]) return;  // (workgroup-uniform)
+    int r = 0;  // the last non-empty bin that starts at or before this workgroup
+    for (int b = 0; b < rec.nbins; ++b)
+        if (btot[b] > 0 && ubase[b] <= (int)blockIdx.x) r = b;
+    const int nunits = (r == 63 ? ubase[64] : ubase[r + 1]) - ubase[r];
+    const int portion = (int)blockIdx.x - ubase[r];
+    const int per = (btot[r] + nunits - 1) / nunits;
+    const int g_begin = portion * per, g_end = g_begin + per < btot[r] ? g_begin + per : btot[r];
+    // prefix sums of the bin's counts over the regions (<= 256): four per lane of wave 0
+    if (threadIdx.x < 64) {
+        int c4[4], sum4 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int w = lane0 * 4 + k;
+            c4[k] = w < nregions ? rec.counts[(size_t)w * rec.nbins + r] : 0;
+            sum4 += c4[k];
+        }
+        int v = sum4;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(v, d, 64);
+            if (lane0 >= d) v += o;
+        }
+        int acc = v - sum4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pre[lane0 * 4 + k] = acc;
+            acc += c4[k];
+        }
+        if (lane0 == 63) pre[256] = acc;
+    }
+    __syncthreads();
+    const int nreg = nregions;
+    const int total = g_end - g_begin;
+    if (total <= 0) return;  // (workgroup-uniform)
+    for (int i = threadIdx.x; i < rec.bin_cells * RS; i += REC_TPB) table[i] = 0;  // (the first barrier of the chunk loop follows)
+    const int sh_r = sc->sh_r;
+    const bool fast_fix = sh_r >= -1000 && sh_r <= 1000;
+    const double scale_r = __longlong_as_double((long long)(1023 + (fast_fix ? sh_r : 0)) << 52);
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // the bins behind the rows' belong to the family side table
+    i64* const dst = r < rec.nbins_rows ? rows + (size_t)r * rec.bin_cells * RS : fam + (size_t)(r - rec.nbins_rows) * rec.bin_cells * RS;
+    constexpr int WAVES = REC_TPB / 64;
+    for (int c0 = 0; c0 < total; c0 += REC_CHUNK) {
+        const int n = total - c0 < REC_CHUNK ? total - c0 : REC_CHUNK;
+        if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+        __syncthreads();
+        // ---- 1. the chunk's records: fetched (record g of the list lives in the region with pre[k] <= g < pre[k + 1]), ranked
+        {
+            uint2 rc[REC_PER_THREAD];
+            int rank[REC_PER_THREAD];
+#pragma unroll
+            for (int k = 0; k < REC_PER_THREAD; ++k) {
+                const int i = (int)threadIdx.x + k * REC_TPB;
+                rc[k] = make_uint2(0u, 0u);
+                rank[k] = 0;
+                if (i < n) {
+                    const int g = g_begin + c0 + i;
+                    int lo = 0, hi = nreg - 1;  // (empty regions never match)
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (pre[mid] <= g) lo = mid; else hi = mid - 1;
+                    }
+                    rc[k] = rec.recs[((size_t)lo * rec.nbins + r) * (size_t)rec.cap + (size_t)(g - pre[lo])];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < REC_PER_THREAD; ++k)
+                if ((int)threadIdx.x + k * REC_TPB < n)
+                    rank[k] = __hip_atomic_fetch_add(&hist[rc[k].y & 0x7Fu], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __syncthreads();
+            if (wib == 0) {  // exclusive scan of the 128 counts: two per lane
+                const int a = hist[2 * lane], b = hist[2 * lane + 1];
+                int v = a + b;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(v, d, 64);
+                    if (lane >= d) v += o;
+                }
+                start[2 * lane] = v - a - b;
+                start[2 * lane + 1] = v - b;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < REC_PER_THREAD; ++k)
+                if ((int)threadIdx.x + k * REC_TPB < n) {
+                    const int pos = start[rc[k].y & 0x7Fu] + rank[k];
+                    sorted[pos] = rc[k].x | ((rc[k].y >> 16) << 31);
+                    scell[pos] = (unsigned char)(rc[k].y & 0x7Fu);
+                }
+            __syncthreads();
+        }
+        // ---- 2. + 3. equal spans of the sorted chunk
+        const int span = ((n + WAVES * REC_BATCH - 1) / (WAVES * REC_BATCH)) * REC_BATCH;
+        const int j0 = wib * span, j1 = j0 + span < n ? j0 + span : n;
+        if (j0 < j1) {
+            i64 acc_hi = 0, acc_lo = 0;
+            int acc_n = 0, cur = -1;
+            auto flush = [&]() {
+                if (cur >= 0) {
+                    i64* row = table + cur * RS;
+                    if (lane < NC) {
+                        if (acc_hi != 0) atomicAdd((u64*)&row[2 * lane], (u64)acc_hi);
+                        if (acc_lo != 0) atomicAdd((u64*)&row[2 * lane + 1], (u64)acc_lo);
+                    } else if (lane == NC && acc_n != 0) {
+                        atomicAdd((u64*)&row[2 * NC], (u64)(i64)acc_n);
+                    }
+                }
+                acc_hi = 0;
+                acc_lo = 0;
+                acc_n = 0;
+            };
+            unsigned wA[REC_BATCH], wB[REC_BATCH];
+            int cA[REC_BATCH], cB[REC_BATCH];
+            double xA[REC_BATCH], xB[REC_BATCH];
+            auto load = [&](int j, unsigned (&w)[REC_BATCH], int (&c)[REC_BATCH], double (&x)[REC_BATCH]) {
+                const unsigned wv = sorted[j + (lane & 7)];
+                const int cv = scell[j + (lane & 7)];
+#pragma unroll
+                for (int k = 0; k < REC_BATCH; ++k) {
+                    w[k] = (unsigned)__builtin_amdgcn_readlane((int)wv, k);
+                    c[k] = __builtin_amdgcn_readlane(cv, k);
+                    x[k] = (j + k < j1 && lane < NC) ? aos[(long)(w[k] & 0x7FFFFFFFu) * NC + lane] : 0.0;
+                }
+            };
+            load(j0, wA, cA, xA);
+            for (int j = j0; j < j1; j += REC_BATCH) {
+                if (j + REC_BATCH < j1) load(j + REC_BATCH, wB, cB, xB);
+#pragma unroll
+                for (int k = 0; k < REC_BATCH; ++k) {
+                    if (j + k >= j1) break;  // wave-uniform
+                    if (cA[k] != cur) {      // wave-uniform
+                        flush();
+                        cur = cA[k];
+                    }
+                    int h, l;
+                    if (fast_fix)
+                        fix2_mul(xA[k], scale_r, h, l);
+                    else
+                        fix2(xA[k], sh_r, h, l);
+                    if (wA[k] >> 31) {
+                        acc_hi -= (i64)h;
+                        acc_lo -= (i64)l;
+                        acc_n -= 1;
+                    } else {
+                        acc_hi += (i64)h;
+                        acc_lo += (i64)l;
+                        acc_n += 1;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < REC_BATCH; ++k) {
+                    wA[k] = wB[k];
+                    cA[k] = cB[k];
+                    xA[k] = xB[k];
+                }
+            }
+            flush();
+        }
+        __syncthreads();  // (hist / sorted are rewritten by the next chunk)
+    }
+    for (int i = threadIdx.x; i < rec.bin_cells * RS; i += REC_TPB) {
+        const i64 v = table[i];
+        if (v != 0) atomicAdd((u64*)&dst[i], (u64)v);  // (cells beyond the codebook's last never receive a record: zero)
     }
 }
 
@@ -1822,7 +2117,8 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                                      const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym,
                                      double* dmin, long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental,
                                      bool hybrid_table, hipStream_t s, const double* aos, const int* ea_fused,
-                                     const double* aos_resident, long long* family_table, bool assign_only)
+                                     const double* aos_resident, long long* family_table, bool assign_only,
+                                     const PassRecords* records)
 {
     constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
     constexpr int TPBM = 512;  // 8 waves = 2 per SIMD, one persistent workgroup per CU
@@ -1843,24 +2139,40 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
         // round 3: FP64 frames staged in LDS, lane-per-frame exact evaluation, one burst of atomics per block
         if constexpr (PreLds<NC>::OK) {
             const int MT = M / 32;
+            PreRec rec{};
+            if (records) {
+                if (records->grid != grid || records->nbins > 64) return 1;  // (planned for another launch)
+                rec.recs = (uint2*)records->recs;
+                rec.counts = records->counts;
+                rec.nbins = records->nbins;
+                rec.nbins_rows = records->nbins_rows;
+                rec.bin_cells = records->bin_cells;
+                rec.cap = records->cap;
+                rec.magic = records->magic;
+            }
             auto go = [&](auto kernel) {
                 (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E2VQ_LDS_BYTES);
-                hipLaunchKernelGGL(kernel, dim3(grid), dim3(TPBM), (size_t)8 * PreLds<NC>::WAVE_BYTES, s, aos_resident, T,
-                                   nblocks, (const h8*)fimg, fg, (const h8*)cimg, (PreScalars*)ps, cbq, MT, idxmask, sc,
-                                   (const u64*)l1max_bits, sym, dmin, rows, fb_list, stagger, prev_sym,
-                                   family_table ? 2 : (incremental ? 1 : 0), (i64*)family_table);
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(TPBM), (size_t)8 * PreLds<NC>::WAVE_BYTES + (records ? 256 : 0), s,
+                                   aos_resident, T, nblocks, (const h8*)fimg, fg, (const h8*)cimg, (PreScalars*)ps, cbq, MT,
+                                   idxmask, sc, (const u64*)l1max_bits, sym, dmin, rows, fb_list, stagger, prev_sym,
+                                   family_table ? 2 : (incremental ? 1 : 0), (i64*)family_table, rec);
             };
             static const bool simple = getenv("ECOZ2_VQ_PRE_SIMPLE_LOOP") && atoi(getenv("ECOZ2_VQ_PRE_SIMPLE_LOOP")) != 0;  // (tests)
             const bool rot = MT >= 4 && (MT & 1) == 0 && !simple;
             if (assign_only) {  // (the cell sums follow in launch_accumulate_ranges)
                 if (rot)
-                    go(k_pass_pre_lds<NC, true, false>);
+                    go(k_pass_pre_lds<NC, true, 0>);
                 else
-                    go(k_pass_pre_lds<NC, false, false>);
+                    go(k_pass_pre_lds<NC, false, 0>);
+            } else if (records) {  // (the cell sums follow in launch_reduce_records)
+                if (rot)
+                    go(k_pass_pre_lds<NC, true, 2>);
+                else
+                    go(k_pass_pre_lds<NC, false, 2>);
             } else if (rot) {
-                go(k_pass_pre_lds<NC, true, true>);
+                go(k_pass_pre_lds<NC, true, 1>);
             } else {
-                go(k_pass_pre_lds<NC, false, true>);
+                go(k_pass_pre_lds<NC, false, 1>);
             }
         }
     } else if (accumulate) {
@@ -1898,8 +2210,9 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                             long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
                             hipStream_t s, const double* rowmajor_frames, const int* ea_fused, const double* resident_rowmajor,
-                            long long* family_table, bool assign_only)
+                            long long* family_table, bool assign_only, const PassRecords* records)
 {
+    if (records && (!accumulate || assign_only || hybrid_table || !resident_rowmajor || !prefilter_lds_stage(NC) || !prev_sym)) return 1;
     if (family_table && (!accumulate || hybrid_table || incremental || !resident_rowmajor || !prefilter_lds_stage(NC))) return 1;
     // assign_only: the accumulating kernel's sweep and distortion sums without its cell sums (k_accum_ranges follows)
     if (assign_only && (accumulate || !sym || !rows || !resident_rowmajor || !prefilter_lds_stage(NC) || ea_fused)) return 1;
@@ -1910,7 +2223,7 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
     case N:                                                                                                           \
         return launch_pass_prefiltered_t<N>(accumulate, blk, T, nblocks, fimg, fg, cimg, ps, cbq, M, sc, l1max_bits, sym, \
                                             dmin, rows, fb_list, prev_sym, incremental, hybrid_table, s, rowmajor_frames, \
-                                            ea_fused, resident_rowmajor, family_table, assign_only);
+                                            ea_fused, resident_rowmajor, family_table, assign_only, records);
         E2VQ_PRE_NC_LIST(X)
 #undef X
         default: return 1;
@@ -1940,6 +2253,75 @@ int launch_accumulate_ranges(int NC, const double* aos, long T, const unsigned s
                                       E2VQ_LDS_BYTES);                                                                \
             hipLaunchKernelGGL((k_accum_ranges<N>), dim3((unsigned)(used_chunks * nranges)), dim3(ACC_TPB), lds, s, aos, T, \
                                chunk_frames, cells_new, cells_old, incremental ? 1 : 0, M, range_cells, sc, (i64*)rows); \
+            return 0;                                                                                                 \
+        }                                                                                                             \
+        return 1;
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        default: return 1;
+    }
+}
+
+// ---- the recorded accumulate (k_pass_pre_lds<.., 2> + k_reduce_records) ------------------------------------------------------
+bool prefilter_records_plan(int NC, int M, bool family, long nblocks, PassRecords* plan, size_t* recs_bytes)
+{
+    if (!pre_has_nc(NC) || !prefilter_lds_stage(NC) || 2 * NC + 1 > 80 || !prefilter_supports(NC, M)) return false;
+    if (nblocks * 64 >= (1L << 31)) return false;  // (frame numbers are 32-bit in a record)
+    const int RS = (2 * NC + 5 + 7) & ~7;
+    (void)RS;
+    const int max_cells = (M + (family ? M / 2 : 0) + 2 * REC_BIN_CELLS) / REC_BIN_CELLS <= 64 ? REC_BIN_CELLS : REC_BIN_CELLS_BIG;
+    const int nb_rows = (M + max_cells - 1) / max_cells;
+    const int bc = (M + nb_rows - 1) / nb_rows;  // balanced bins
+    const int fam_cells = family ? M / 2 : 0;
+    const int nb_fam = (fam_cells + bc - 1) / bc;
+    if (nb_rows + nb_fam > 64) return false;  // (a bin's count travels in lane `bin` of the recording wave)
+    const unsigned magic = (unsigned)(((1u << 22) + bc - 1) / bc);
+    const int ncells = (nb_rows + nb_fam) * bc;
+    for (int c = 0; c < ncells; ++c)
+        if ((int)(((unsigned)c * magic) >> 22) != c / bc) return false;
+    const int grid = pre_grid(nblocks, 8, 256);
+    const long blocks_per_wave = (nblocks + (long)grid * 8 - 1) / ((long)grid * 8);
+    const long cap = 2 * 8 * blocks_per_wave * 64;  // every frame of the workgroup twice in one bin: '+' and '-'
+    if (cap >= (1L << 30)) return false;
+    plan->grid = grid;
+    plan->nbins = nb_rows + nb_fam;
+    plan->nbins_rows = nb_rows;
+    plan->bin_cells = bc;
+    plan->magic = magic;
+    plan->cap = (int)cap;
+    if (recs_bytes) *recs_bytes = (size_t)grid * (size_t)plan->nbins * (size_t)cap * 8;
+    return true;
+}
+
+// few: an incremental pass (a fraction of the frames recorded): one reducing workgroup per CU keeps the flush small;
+// else two per CU
+int launch_reduce_records(int NC, const double* aos, const PassRecords& plan, bool few, const DevScalars* sc, long long* rows,
+                          long long* family_table, hipStream_t s)
+{
+    if (plan.nbins > plan.nbins_rows && !family_table) return 1;
+    const int RS = (2 * NC + 5 + 7) & ~7;
+    // (three workgroups per CU by registers and LDS; the kernel shares them out over the bins by their record counts)
+    static const int wg_env = getenv("ECOZ2_VQ_REC_WG") ? atoi(getenv("ECOZ2_VQ_REC_WG")) : 768;
+    (void)few;
+    const int nwg = wg_env < plan.nbins ? plan.nbins : wg_env;
+    if (plan.grid > 256 || plan.bin_cells > 128 || plan.nbins > 64) return 1;  // (the prefix array; the histogram; lane = bin)
+    const size_t lds = (size_t)plan.bin_cells * RS * 8;
+    PreRec rec{};
+    rec.recs = (uint2*)plan.recs;
+    rec.counts = plan.counts;
+    rec.nbins = plan.nbins;
+    rec.nbins_rows = plan.nbins_rows;
+    rec.bin_cells = plan.bin_cells;
+    rec.cap = plan.cap;
+    rec.magic = plan.magic;
+    switch (NC) {
+#define X(N)                                                                                                          \
+    case N:                                                                                                           \
+        if constexpr (2 * N + 1 <= 80) {                                                                              \
+            (void)hipFuncSetAttribute((const void*)k_reduce_records<N>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                      E2VQ_LDS_BYTES - 32768);                                                        \
+            hipLaunchKernelGGL((k_reduce_records<N>), dim3((unsigned)nwg), dim3(REC_TPB), lds, s, aos, rec, plan.grid, sc, \
+                               (i64*)rows, (i64*)family_table);                                                       \
             return 0;                                                                                                 \
         }                                                                                                             \
         return 1;

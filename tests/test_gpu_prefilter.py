@@ -208,19 +208,22 @@ def test_learn_ladder_with_prefilter_matches_oracle(oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("M,prefilter", [(16, True), (64, False), (256, False), (256, True), (1024, False)])
-@pytest.mark.parametrize("plain_first", [False, True])
+@pytest.mark.parametrize("accumulate", ["records", "ranges", "burst"])
 @pytest.mark.parametrize("collective", [False, True])
-def test_incremental_rows_match_a_full_accumulation_every_pass(oracle, monkeypatch, collective, plain_first, M, prefilter):
+def test_incremental_rows_match_a_full_accumulation_every_pass(oracle, monkeypatch, collective, accumulate, M, prefilter):
     """Five passes at one codebook size with centroid updates in between: from the second pass on only the frames
     that changed cell are moved (LDS-table, hybrid and global-atomic accumulates of the plain sweep, the prefiltered
     sweep and its fallback list alike); the rows must equal the oracle's full accumulation every time.  `collective`
     routes the rows through the all-reduce hook (own copy + reduced copy)."""
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER", "1" if prefilter else "0")
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
-    monkeypatch.setenv("ECOZ2_VQ_PLAIN_FIRST", "1" if plain_first else "0")  # first pass on the plain hybrid kernel?
-    # (round 4: up to M = 256 the default pass is an assignment-only sweep + k_accum_ranges, full or incremental, and the
-    # plain first pass is not used; with plain_first the one-kernel paths of round 3 are exercised instead)
-    monkeypatch.setenv("ECOZ2_VQ_SPLIT_ACC_MAX_M", "0" if plain_first else "512")
+    # the three accumulates of a prefiltered pass -- "records" (round 4, the default): the sweep records every contribution,
+    # k_reduce_records folds the records into the rows; "ranges": an assignment-only sweep + k_accum_ranges; "burst":
+    # round 3's one kernel with its atomics, the first pass of M = 256 on the plain hybrid kernel
+    plain_first = accumulate == "burst"
+    monkeypatch.setenv("ECOZ2_VQ_RECORDS", "1" if accumulate == "records" else "0")
+    monkeypatch.setenv("ECOZ2_VQ_PLAIN_FIRST", "1" if plain_first else "0")
+    monkeypatch.setenv("ECOZ2_VQ_SPLIT_ACC_MAX_M", "512" if accumulate == "ranges" else "0")
     if collective:
         monkeypatch.setenv("ECOZ2_VQ_FORCE_ALLREDUCE", "1")
     frames = _frames(20257, 9000)
@@ -247,7 +250,7 @@ def test_incremental_rows_match_a_full_accumulation_every_pass(oracle, monkeypat
     assert bool(calls) == collective
 
 
-@pytest.mark.parametrize("split_max_m", [0, 128, 4096])
+@pytest.mark.parametrize("split_max_m", [-1, 0, 128, 4096])
 @pytest.mark.parametrize("collective", [False, True])
 @pytest.mark.parametrize("min_m", [64, 256])
 def test_seeded_first_pass_after_a_split_equals_a_full_accumulation(oracle, monkeypatch, min_m, collective, split_max_m):
@@ -258,10 +261,12 @@ def test_seeded_first_pass_after_a_split_equals_a_full_accumulation(oracle, monk
     `collective` the parent rows come from the rank's own copy.
     split_max_m (round 4): up to that size the pass is an assignment-only sweep + k_accum_ranges (cell sums through LDS
     tables, full on the first pass of a level and incremental after; two cell arrays swapped per pass) instead -- 0: seeded
-    passes everywhere; 128: the two kinds of level follow each other; 4096: no seeded pass at all."""
+    passes everywhere; 128: the two kinds of level follow each other; 4096: no seeded pass at all.  -1: the recorded
+    accumulate (the default: seeded first passes whose records include the side table's bins, incremental ones after)."""
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", str(min_m))
     monkeypatch.setenv("ECOZ2_VQ_FAMILY_MIN_M", str(min_m))  # (default 512: below, the plain first pass is faster)
-    monkeypatch.setenv("ECOZ2_VQ_SPLIT_ACC_MAX_M", str(split_max_m))
+    monkeypatch.setenv("ECOZ2_VQ_RECORDS", "1" if split_max_m < 0 else "0")
+    monkeypatch.setenv("ECOZ2_VQ_SPLIT_ACC_MAX_M", str(max(0, split_max_m)))
     monkeypatch.setenv("ECOZ2_VQ_QUIET", "1")
     if collective:
         monkeypatch.setenv("ECOZ2_VQ_FORCE_ALLREDUCE", "1")

@@ -131,6 +131,11 @@ def fuzz_prefilter(n, rng, oracle):
         rc, st = oracle.data_stats(frames)
         sh_r, sh_q = oracle.shifts(st.maxabs)
         ok, what = True, ""
+        # the accumulate of the prefiltered passes: recorded contributions + k_reduce_records (the default), the
+        # assignment-only sweep + k_accum_ranges, or the one kernel with its burst of atomics
+        acc = int(rng.integers(0, 4))
+        os.environ["ECOZ2_VQ_RECORDS"] = "0" if acc >= 2 else "1"
+        os.environ["ECOZ2_VQ_SPLIT_ACC_MAX_M"] = "4096" if acc == 2 else "0"
         with e.VqSession(P) as s:
             s.set_frames(frames); s.prepare(); s.set_codebook(refl)
             for it in range(3):
