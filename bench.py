@@ -508,7 +508,10 @@ def run(args, comm):
     dt = time.perf_counter() - t0
     ar_now = comm.counters()
     ar_timed = {k: ar_now[k] - ar_before[k] for k in ("n", "bytes")}
-    kernel_ms_total, kernel_passes = sess.timing_total()
+    # the dominant kernel alone (the sweep), and the pass's kernels together (sweep + k_reduce_records where the accumulate
+    # is a kernel of its own)
+    kernel_ms_total, kernel_passes = sess.timing_sweep_total()
+    pass_kernels_ms_total = sess.timing_total()[0]
     assert kernel_passes == args.steps, (kernel_passes, args.steps)
     ar_ms, ar_n, ar_b = sess.collective_timing()
     sess.enable_collective_timing(False)
@@ -672,9 +675,11 @@ def run(args, comm):
             roofline = {
                 "bound": "mfma",
                 "kernel": "k_pass_pre_lds<37> (exact f16-limb prefilter on v_mfma_f32_32x32x16_f16 + top-3 keys; FP64 frames "
-                          "of the block staged in LDS, the certified top two evaluated as lane-per-frame v_fma_f64 chains; exact "
-                          "accumulate: seeded on the first pass of the level, incremental after); uncertified frames: "
-                          "k_pass_mfma<37,2,256,2>",
+                          "of the block staged in LDS, the certified top two evaluated as lane-per-frame v_fma_f64 chains; "
+                          "contributions to the cell sums -- seeded on the first pass of the level, incremental after -- "
+                          "recorded as 8-byte records, or added as a burst of atomics with ECOZ2_VQ_RECORDS=0); then "
+                          "k_reduce_records (records sorted by cell in LDS, rows summed in registers, exact int64) and, for "
+                          "uncertified frames, k_pass_mfma<37,2,256,2>",
                 "achieved": exec_tf,
                 "peak": F16_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
@@ -682,6 +687,7 @@ def run(args, comm):
                 "traffic": traffic,
                 "traffic_detail": traffic_detail,
                 "kernel_ms": k_ms,
+                "accumulate_kernel_ms": (pass_kernels_ms_total - kernel_ms_total) / kernel_passes,
                 "launches": kernel_passes,
                 "trace_dispatches": {"kernel": "k_pass_pre", "first": launches_before[0], "count": timed_pre,
                                      "plain_first": launches_before[1], "plain_count": timed_plain},

@@ -87,6 +87,7 @@ _sig("e2vq_update", C.c_int, C.c_void_p)
 _sig("e2vq_enable_timing", C.c_int, C.c_void_p, C.c_int)
 _sig("e2vq_last_pass_kernel_ms", C.c_int, C.c_void_p, C.POINTER(C.c_float))
 _sig("e2vq_timing_total", C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64))
+_sig("e2vq_timing_sweep_total", C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64))
 _sig("e2vq_iterate", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LevelStatsC))
 _sig("e2vq_last_pass_info", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64))
 _sig("e2vq_set_prev_distortion", C.c_int, C.c_void_p, C.c_double)

@@ -127,14 +127,17 @@ struct e2vq_session {
     double* d_qdmin = nullptr;
     i64 q_cap = 0, qblk_cap = 0;
     // HIP events around the sweep kernel (bench.py's roofline figures)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;  // (ev_mid: between the sweep and its accumulate kernel)
+    bool timing_mid = false;        // the pending pass has an ev_mid
+    double timing_sweep_ms = 0.0;   // the sweep kernels alone (e2vq_timing_sweep_total)
     bool timing = false, timed = false;
     double timing_sum_ms = 0.0;  // kernel time of the timed passes already folded in (e2vq_timing_total)
     long timing_count = 0;
     bool timing_pending = false;  // ev0/ev1 hold a pass that is not in the sum yet
     // prefiltered sweep (P = 36, M >= pre_min_M): f16 limb images of the frames / the codebook, fallback list
     bool pre_enabled = false;
-    int pre_min_M = 256;
+    int pre_min_M = 256;    // (training passes with the recorded accumulate: 128, see rec_enabled)
+    int pre_min_M_quant = 256;
     unsigned long long* d_colmax = nullptr;
     int* d_ea = nullptr;
     void* d_fimg = nullptr;
@@ -305,6 +308,7 @@ static int session_init(e2vq_session* s)
     HIPCHK(hipMemset(s->d_sc, 0, sizeof(DevScalars)));
     HIPCHK(hipEventCreate(&s->ev0));
     HIPCHK(hipEventCreate(&s->ev1));
+    HIPCHK(hipEventCreate(&s->ev_mid));
     HIPCHK(hipEventCreateWithFlags(&s->ev_stats, hipEventDisableTiming));
     HIPCHK(hipMalloc(&s->d_l1max_spec, 8));
     HIPCHK(hipHostMalloc(&s->h_stats, sizeof(*s->h_stats), hipHostMallocMapped | hipHostMallocCoherent));
@@ -315,7 +319,7 @@ static int session_init(e2vq_session* s)
     // ECOZ2_VQ_PREFILTER=0 keeps every pass on the FP64 sweep; ECOZ2_VQ_PREFILTER_MIN_M moves the switch-over size
     const char* pf = getenv("ECOZ2_VQ_PREFILTER");
     s->pre_enabled = e2vq::prefilter_supports(s->NC, 64) && !(pf && atoi(pf) == 0);
-    if (const char* mm = getenv("ECOZ2_VQ_PREFILTER_MIN_M")) s->pre_min_M = std::max(64, atoi(mm));
+    if (const char* mm = getenv("ECOZ2_VQ_PREFILTER_MIN_M")) s->pre_min_M = s->pre_min_M_quant = std::max(64, atoi(mm));
     if (const char* inc = getenv("ECOZ2_VQ_INCREMENTAL")) s->incr_enabled = atoi(inc) != 0;
     if (const char* pf1 = getenv("ECOZ2_VQ_PLAIN_FIRST")) s->plain_first = atoi(pf1) != 0;
     if (const char* fm = getenv("ECOZ2_VQ_FAMILY")) s->fam_enabled = atoi(fm) != 0;
@@ -325,6 +329,12 @@ static int session_init(e2vq_session* s)
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS")) s->rec_enabled = atoi(rc) != 0;
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS_MIN_M")) s->rec_min_M = std::max(64, atoi(rc));
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS_MAX_MB")) s->rec_max_bytes = (size_t)std::max(0, atoi(rc)) << 20;
+    // With the recorded accumulate the prefiltered pass also wins at M = 128 (0.36 vs 0.43 ms per pass on 2^21 frames; not
+    // at 64: 0.30 vs 0.28), and a seeded first pass halves the records of every prefiltered level's first pass
+    if (s->rec_enabled && e2vq::prefilter_lds_stage(s->NC)) {
+        if (!getenv("ECOZ2_VQ_PREFILTER_MIN_M")) s->pre_min_M = 128;
+        if (!getenv("ECOZ2_VQ_FAMILY_MIN_M")) s->fam_min_M = 128;
+    }
     if (s->pre_enabled) {
         HIPCHK(hipMalloc(&s->d_colmax, (size_t)s->NC * 8));
         HIPCHK(hipMalloc(&s->d_ea, (size_t)s->NC * sizeof(int)));
@@ -385,6 +395,7 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (s->h_within) (void)hipHostFree(s->h_within);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->ev_mid) (void)hipEventDestroy(s->ev_mid);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     delete s;
 }
@@ -757,6 +768,9 @@ static int fold_pending_timing(e2vq_session* s)
     HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     s->timing_sum_ms += ms;
     s->timing_count += 1;
+    if (s->timing_mid) HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev_mid));
+    s->timing_sweep_ms += ms;
+    s->timing_mid = false;
     s->timing_pending = false;
     return 0;
 }
@@ -953,6 +967,10 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
                                           nullptr, nullptr, s->d_aos, family ? s->d_fam : nullptr, false,
                                           records ? &recplan : nullptr))
             return e2vq_set_error("prefiltered sweep: unsupported configuration");
+        if (records && s->timing) {
+            HIPCHK(hipEventRecord(s->ev_mid, s->stream));
+            s->timing_mid = true;
+        }
         if (records && e2vq::launch_reduce_records(s->NC, s->d_aos, recplan, incremental, s->d_sc, rows,
                                                    family ? s->d_fam : nullptr, s->stream))
             return e2vq_set_error("k_reduce_records: unsupported configuration");
@@ -1028,7 +1046,23 @@ extern "C" int e2vq_enable_timing(e2vq_session* s, int on)
     s->timed = false;
     s->timing_pending = false;
     s->timing_sum_ms = 0.0;
+    s->timing_sweep_ms = 0.0;
+    s->timing_mid = false;
     s->timing_count = 0;
+    return 0;
+}
+
+// the sweep kernels alone: where a pass is a sweep + an accumulate kernel (recorded contributions + k_reduce_records),
+// e2vq_timing_total covers both, this one the sweep
+extern "C" int e2vq_timing_sweep_total(e2vq_session* s, double* total_ms, int64_t* passes)
+{
+    HIPCHK(hipSetDevice(s->device));
+    if (s->timing_pending) {
+        HIPCHK(hipEventSynchronize(s->ev1));
+        if (fold_pending_timing(s)) return 1;
+    }
+    if (total_ms) *total_ms = s->timing_sweep_ms;
+    if (passes) *passes = s->timing_count;
     return 0;
 }
 
@@ -1524,7 +1558,7 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
     if (T > (int64_t)INT32_MAX - 64) return e2vq_set_error("%lld frames per quantize call exceed 2^31 - 65 (split the call)", (long long)T);
     HIPCHK(hipSetDevice(s->device));
     const i64 nb = (T + s->FB - 1) / s->FB;
-    if (s->pre_enabled && s->M >= s->pre_min_M && e2vq::prefilter_supports(s->NC, s->M)) {
+    if (s->pre_enabled && s->M >= s->pre_min_M_quant && e2vq::prefilter_supports(s->NC, s->M)) {
         // prefiltered sweep.  Fused (P <= 38): the assignment-only kernel builds the f16 limb images of its frames from the
         // row-major payload itself and keeps the FP64 frames in LDS for the exact evaluation -- every frame is read once.
         // Otherwise one preparation pass over the payload writes the limb image and the tolerance terms first.  Either

@@ -258,6 +258,12 @@ class VqSession:
         check(lib.e2vq_timing_total(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def timing_sweep_total(self):
+        """The same for the sweep kernels alone (a pass with a separate accumulate kernel counts with both in timing_total)."""
+        ms, n = C.c_double(), C.c_int64()
+        check(lib.e2vq_timing_sweep_total(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def last_pass_info(self):
         """(prefiltered sweep used?, frames it left to the full FP64 sweep) of the last run_pass."""
         used, n = C.c_int(), C.c_int64()

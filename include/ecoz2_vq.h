@@ -191,6 +191,9 @@ int e2vq_last_pass_kernel_ms(e2vq_session *s, float *ms);
 /* sum of those event-measured kernel times over all passes since e2vq_enable_timing(1), and their number: lets a
  * caller time K iterations without a host synchronisation per iteration */
 int e2vq_timing_total(e2vq_session *s, double *total_ms, int64_t *passes);
+/* the same for the sweep kernels alone: a pass whose accumulate is a kernel of its own (recorded contributions folded by
+ * k_reduce_records) counts with both kernels in e2vq_timing_total, with the sweep only here */
+int e2vq_timing_sweep_total(e2vq_session *s, double *total_ms, int64_t *passes);
 /* which sweep served the last e2vq_pass: *prefiltered = 1 when the f16-prefiltered sweep ran (P = 36, large M),
  * *fallback_frames = frames it handed to the full FP64 sweep (synchronises the stream) */
 int e2vq_last_pass_info(e2vq_session *s, int *prefiltered, int64_t *fallback_frames);
