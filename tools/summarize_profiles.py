@@ -58,6 +58,26 @@ def timed_rows(path, hint):
     return rows[hint["first"]:hint["first"] + hint["count"]]
 
 
+def reduce_rows(path, hint):
+    """k_reduce_records launches of the timed region: one behind every training sweep of the k_pass_pre family when the
+    accumulate is recorded (the default) -- same indices; none otherwise."""
+    allr = list(csv.DictReader(open(path)))
+    red = [r for r in allr if "k_reduce_records" in r["Kernel_Name"]]
+    # (quantize sweeps are of the k_pass_pre family too, but follow the timed region)
+    return red[hint["first"]:hint["first"] + hint["count"]] if hint["kernel"] == "k_pass_pre" else []
+
+
+def counters_of(path, rows_sel):
+    ids = {r["Dispatch_Id"] for r in rows_sel}
+    per = {}
+    for r in csv.DictReader(open(path)):
+        if r["Dispatch_Id"] in ids:
+            per.setdefault(r["Dispatch_Id"], {})
+            per[r["Dispatch_Id"]][r["Counter_Name"]] = per[r["Dispatch_Id"]].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    vals = list(per.values())
+    return {k: sum(x[k] for x in vals) / len(vals) for k in vals[0]} if vals else {}
+
+
 def counters(path, hint):
     per, order = {}, []
     for r in csv.DictReader(open(path)):
@@ -98,6 +118,18 @@ def main():
         "source": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --steps 21 "
                   f"--warmup 3; timed dispatches = {hint['kernel']} launches [{hint['first']}, {hint['first'] + hint['count']})",
     }
+    red = reduce_rows(kt, hint)
+    if red:
+        rd = [ms(r) for r in red]
+        out["accumulate_kernel"] = {
+            "kernel": "k_reduce_records<37>: the launch behind each of the timed sweeps (records sorted by cell in LDS, rows summed "
+                      "in registers)",
+            "dispatches": len(rd), "avg_ms": sum(rd) / len(rd),
+            "avg_ms_by_pass_of_level": [sum(rd[i] for i in range(len(rd)) if i % L == k) / max(1, len([i for i in range(len(rd)) if i % L == k])) for k in range(L)],
+            "bench_accumulate_kernel_ms": b["roofline"].get("accumulate_kernel_ms"),
+            "vgpr": red[0].get("VGPR_Count"), "lds_bytes": red[0].get("LDS_Block_Size"), "grid": red[0].get("Grid_Size"),
+            "workgroup": red[0].get("Workgroup_Size"),
+        }
     sfx = "" if M == 1024 else f"_M{M}"
     json.dump(out, open(f"{DST}/{TAG}_pass_kernel{sfx}.json", "w"), indent=1)
     shutil.copy(newest(f"{SRC}/{TAG}_kt/*/*_kernel_stats.csv"), f"{DST}/{TAG}_kernel_stats{sfx}.csv")
@@ -122,6 +154,17 @@ def main():
             "kernel_sources_sha16": kernel_sources_sha16(),
             "note": "average over the timed launches (full-accumulate and incremental passes of the level mixed as in the bench)",
         }
+        try:  # the accumulate kernel's own traffic (row re-reads, records, flush atomics)
+            ff = newest(f"{SRC}/{TAG}_fetch/*/*_counter_collection.csv")
+            fw = newest(f"{SRC}/{TAG}_write/*/*_counter_collection.csv")
+            rf = counters_of(ff, reduce_rows(newest(f"{SRC}/{TAG}_fetch/*/*_kernel_trace.csv"), hf))
+            rw = counters_of(fw, reduce_rows(newest(f"{SRC}/{TAG}_write/*/*_kernel_trace.csv"), hw))
+            if rf and rw:
+                tj["accumulate_kernel"] = {"kernel": "k_reduce_records", "fetch_bytes": rf["FETCH_SIZE"] * 2048,
+                                           "write_bytes": rw["WRITE_SIZE"] * 1024,
+                                           "note": "per launch, averaged over the timed launches; same corrections"}
+        except (IndexError, FileNotFoundError, KeyError) as ex:
+            print("no traffic of the accumulate kernel:", ex)
         json.dump(tj, open(f"{DST}/{TAG}_traffic{sfx}{'' if prefiltered else '_noprefilter'}.json", "w"), indent=1)
         print("fetch raw KB", f["FETCH_SIZE"], "write raw KB per step", [round(x["WRITE_SIZE"]) for x in wsel])
     except (IndexError, FileNotFoundError, KeyError) as ex:
