@@ -126,7 +126,7 @@ def test_small_codebook_register_sums(oracle, monkeypatch, T, M):
     assert np.array_equal(got[0], got[1])
 
 
-@pytest.mark.parametrize("T,M", [(5000, 64), (7777, 256), (20000, 1024), (9001, 2048), (6000, 4096)])
+@pytest.mark.parametrize("T,M", [(5000, 64), (7777, 256), (20000, 1024), (9001, 2048), (6000, 4096), (9000, 8192)])
 def test_prefiltered_pass_bit_exact(oracle, monkeypatch, T, M):
     frames = _frames(20250, T)
     _check(oracle, frames, _codebook(oracle, frames, M, seed=3), monkeypatch)
