@@ -93,6 +93,8 @@ int launch_accumulate_ranges(int NC, const double* aos, long T, const unsigned s
 // 64-frame blocks; with it (and prefilter_lds_stage(NC)) the pass runs k_pass_pre_lds; prev_sym must then be padded
 // by 128 bytes
 bool prefilter_lds_stage(int NC);
+// ... and rows of at most 80 elements (P <= 39) for its burst of atomics / the seeded first pass without records
+bool prefilter_burst_supported(int NC);
 // fused quantize (ea_fused != nullptr, assignment only): no frame image at all -- the sweep builds the limb images of
 // its frames from rowmajor_frames with the per-coefficient scales ea_fused (launch_prefilter_quantize_scales)
 bool prefilter_fused_quantize(int NC);

@@ -846,7 +846,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     // round 4: the sweep only assigns, k_accum_ranges adds the cell sums (full or incremental) through LDS tables
     const bool split = keep && split_accumulate(s, s->M);
     // the first pass after a split, seeded with the parents' sums (e2vq_grow stashed them): k_seed_family
-    const bool family = s->fam_pending && keep && !incremental && !split && s->d_aos && 2 * s->fam_M == s->M && mode != 0;
+    bool family = s->fam_pending && keep && !incremental && !split && s->d_aos && 2 * s->fam_M == s->M && mode != 0;
     s->fam_pending = false;
     // round 4: contributions recorded by the sweep, folded into the rows by k_reduce_records
     e2vq::PassRecords recplan{};
@@ -878,6 +878,8 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         recplan.recs = s->d_recs;
         recplan.counts = s->d_rec_counts;
     }
+    // (P = 40: rows of 83 elements are seeded only where the contributions are recorded -- the burst cannot add them)
+    if (family && !records && !e2vq::prefilter_burst_supported(s->NC)) family = false;
     // The first pass of a level accumulates in full.  For the smallest prefiltered sizes that is cheaper on the plain
     // FP64 sweep with its workgroup-local LDS table (hybrid accumulate: 0.92 vs 1.5 ms at M = 256, where 2^21 frames
     // hammer 256 rows with global atomics); it records the cells for the incremental passes that follow.
@@ -1559,7 +1561,7 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
     HIPCHK(hipSetDevice(s->device));
     const i64 nb = (T + s->FB - 1) / s->FB;
     if (s->pre_enabled && s->M >= s->pre_min_M_quant && e2vq::prefilter_supports(s->NC, s->M)) {
-        // prefiltered sweep.  Fused (P <= 38): the assignment-only kernel builds the f16 limb images of its frames from the
+        // prefiltered sweep.  Fused (every prefiltered order): the assignment-only kernel builds the f16 limb images of its frames from the
         // row-major payload itself and keeps the FP64 frames in LDS for the exact evaluation -- every frame is read once.
         // Otherwise one preparation pass over the payload writes the limb image and the tolerance terms first.  Either
         // way the FP64 sweep of whatever could not be certified reads the payload too (no blocked copy).

@@ -1081,7 +1081,13 @@ struct PreLds {
     static constexpr int AUX_BYTES = 256 + 256;      // tolerance terms (64 floats); cells of the previous pass (64 u16, read as 64 dwords)
     static constexpr int WAVE_BYTES = STAGE_BYTES + AUX_BYTES;
     static constexpr int NE = 2 * NC + 1;            // elements of a frame's contribution: limb pairs + count
-    static constexpr bool OK = 8 * WAVE_BYTES <= E2VQ_LDS_BYTES && NE <= 80;
+    // waves per workgroup: eight (two per SIMD) while their regions fit; P = 40 (21 KB per wave) runs seven
+    static constexpr int FIT = (E2VQ_LDS_BYTES - 512) / WAVE_BYTES;
+    static constexpr int WAVES = FIT >= 8 ? 8 : FIT;
+    static constexpr bool OK = WAVES >= 6 && NC < 64;
+    // the burst of atomics (ACC = 1) and k_accum_ranges add a row with one 64-lane instruction + one carrying four 16-lane
+    // tails: rows of at most 80 elements (P <= 39); longer rows are recorded (ACC = 2) or take the round-2 kernel
+    static constexpr bool BURST_OK = OK && NE <= 80;
 };
 
 // requests block b of the row-major frames (padded with zero rows to whole blocks), its tolerance terms and the cells
@@ -1176,7 +1182,8 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
     // not used: a frame that lands in the odd child of its family is recorded for the side table's bin)
     typedef PrePack<NC> PK;
     typedef PreLds<NC> PL;
-    constexpr int TPBM = 512;
+    constexpr int TPBM = PL::WAVES * 64;
+    static_assert(ACC != 1 || PL::BURST_OK, "rows of more than 80 elements are recorded, not added in a burst");
     constexpr int NU = PK::NU;
     constexpr int RS = (2 * NC + 5 + 7) & ~7, NPAD = (NC + 7) & ~7;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1191,7 +1198,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
     const unsigned short* prevs = (const unsigned short*)(wbase + PL::STAGE_BYTES + 256);
     E2VQ_STAMP_DECL
     // (ACC = 2) records written so far into each of this workgroup's regions: one LDS word per bin, behind the waves' regions
-    int* const rcnt = (int*)(smem + (size_t)8 * PL::WAVE_BYTES);
+    int* const rcnt = (int*)(smem + (size_t)PL::WAVES * PL::WAVE_BYTES);
     if constexpr (ACC == 2) {
         if (threadIdx.x < 64) rcnt[threadIdx.x] = 0;
         __syncthreads();
@@ -2089,13 +2096,37 @@ void launch_prefilter_codebook(const double* cbq, int M, int NC, const int* ea, 
     }
 }
 
-// fused quantize keeps 8 waves x 64 row-major FP64 frames in LDS: P <= 38 (NC = 41 takes the separate preparation pass)
-__host__ __device__ constexpr bool fused_quantize_fits(int NC) { return 8 * 64 * NC * 8 + NC * 4 <= E2VQ_LDS_BYTES; }
+// fused quantize keeps the 64 row-major FP64 frames of every wave in LDS: eight waves for P <= 38, seven at P = 40
+// (waves per workgroup: eight while their stages fit; P = 40 runs seven)
+__host__ __device__ constexpr int fused_quantize_waves(int NC)
+{
+    return (E2VQ_LDS_BYTES - NC * 4) / (64 * NC * 8) >= 8 ? 8 : (E2VQ_LDS_BYTES - NC * 4) / (64 * NC * 8);
+}
+__host__ __device__ constexpr bool fused_quantize_fits(int NC) { return fused_quantize_waves(NC) >= 6; }
 bool prefilter_fused_quantize(int NC) { return pre_has_nc(NC) && fused_quantize_fits(NC) && !getenv("ECOZ2_VQ_QUANTIZE_UNFUSED"); }
 
-// the accumulating pass with LDS-staged frames (k_pass_pre_lds) needs 8 waves x (64 frames + 512 B) of LDS: P <= 38;
+// the accumulating pass with LDS-staged frames (k_pass_pre_lds) needs (64 frames + 512 B) of LDS per wave: eight waves for P <= 38, seven at P = 40;
 // ECOZ2_VQ_PRE_LDS=0 keeps the round-2 kernel (A/B)
 template <int NC> static constexpr bool lds_stage_ok_t() { return PreLds<NC>::OK; }
+static int pre_lds_waves(int NC)
+{
+    switch (NC) {
+#define X(N) case N: return PreLds<N>::WAVES;
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        default: return 8;
+    }
+}
+// the burst of atomics inside the sweep kernel (and the seeded first pass without records) serves rows of at most 80 elements
+bool prefilter_burst_supported(int NC)
+{
+    switch (NC) {
+#define X(N) case N: return PreLds<N>::BURST_OK;
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        default: return false;
+    }
+}
 bool prefilter_lds_stage(int NC)
 {
     static const bool off = getenv("ECOZ2_VQ_PRE_LDS") && atoi(getenv("ECOZ2_VQ_PRE_LDS")) == 0;
@@ -2137,13 +2168,14 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
         hipLaunchKernelGGL((k_pass_pre<NC, 5, TPBM>), dim3(grid), dim3(TPBM), lds5, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
                            dmin, rows, fb_list, stagger, prev_sym, 0, (const double*)nullptr, (const int*)nullptr);
-    } else if ((accumulate || assign_only) && aos_resident && prefilter_lds_stage(NC)) {
+    } else if ((accumulate || assign_only) && aos_resident && prefilter_lds_stage(NC) &&
+               (records || assign_only || PreLds<NC>::BURST_OK)) {
         // round 3: FP64 frames staged in LDS, lane-per-frame exact evaluation, one burst of atomics per block
         if constexpr (PreLds<NC>::OK) {
             const int MT = M / 32;
             PreRec rec{};
             if (records) {
-                if (records->grid != grid || records->nbins > 64) return 1;  // (planned for another launch)
+                if (records->nbins > 64) return 1;
                 rec.recs = (uint2*)records->recs;
                 rec.counts = records->counts;
                 rec.nbins = records->nbins;
@@ -2152,29 +2184,46 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                 rec.cap = records->cap;
                 rec.magic = records->magic;
             }
+            constexpr int WAVES = PreLds<NC>::WAVES;
+            const int grid_w = pre_grid(nblocks, WAVES, 256);
+            if (records && records->grid != grid_w) return 1;  // (planned for another launch)
             auto go = [&](auto kernel) {
                 (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E2VQ_LDS_BYTES);
-                hipLaunchKernelGGL(kernel, dim3(grid), dim3(TPBM), (size_t)8 * PreLds<NC>::WAVE_BYTES + (records ? 256 : 0), s,
+                hipLaunchKernelGGL(kernel, dim3(grid_w), dim3(WAVES * 64), (size_t)WAVES * PreLds<NC>::WAVE_BYTES + (records ? 256 : 0), s,
                                    aos_resident, T, nblocks, (const h8*)fimg, fg, (const h8*)cimg, (PreScalars*)ps, cbq, MT,
                                    idxmask, sc, (const u64*)l1max_bits, sym, dmin, rows, fb_list, stagger, prev_sym,
                                    family_table ? 2 : (incremental ? 1 : 0), (i64*)family_table, rec);
             };
             static const bool simple = getenv("ECOZ2_VQ_PRE_SIMPLE_LOOP") && atoi(getenv("ECOZ2_VQ_PRE_SIMPLE_LOOP")) != 0;  // (tests)
             const bool rot = MT >= 4 && (MT & 1) == 0 && !simple;
+            // (two register sets of codeword granules: up to nine granules per tile -- P = 40 has eleven and would spill)
+            constexpr bool ROT_OK = PrePack<NC>::NU <= 9;
             if (assign_only) {  // (the cell sums follow in launch_accumulate_ranges)
-                if (rot)
-                    go(k_pass_pre_lds<NC, true, 0>);
-                else
-                    go(k_pass_pre_lds<NC, false, 0>);
+                if constexpr (ROT_OK) {
+                    if (rot) {
+                        go(k_pass_pre_lds<NC, true, 0>);
+                        return 0;
+                    }
+                }
+                go(k_pass_pre_lds<NC, false, 0>);
             } else if (records) {  // (the cell sums follow in launch_reduce_records)
-                if (rot)
-                    go(k_pass_pre_lds<NC, true, 2>);
-                else
-                    go(k_pass_pre_lds<NC, false, 2>);
-            } else if (rot) {
-                go(k_pass_pre_lds<NC, true, 1>);
-            } else {
+                if constexpr (ROT_OK) {
+                    if (rot) {
+                        go(k_pass_pre_lds<NC, true, 2>);
+                        return 0;
+                    }
+                }
+                go(k_pass_pre_lds<NC, false, 2>);
+            } else if constexpr (PreLds<NC>::BURST_OK) {
+                if constexpr (ROT_OK) {
+                    if (rot) {
+                        go(k_pass_pre_lds<NC, true, 1>);
+                        return 0;
+                    }
+                }
                 go(k_pass_pre_lds<NC, false, 1>);
+            } else {
+                return 1;  // (launch_pass_prefiltered sends rows of more than 80 elements without records to k_pass_pre)
             }
         }
     } else if (accumulate) {
@@ -2187,10 +2236,11 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                            (const int*)nullptr);
     } else if (ea_fused) {  // fused quantize: limb images built in the kernel from the row-major payload
         if constexpr (fused_quantize_fits(NC)) {
-            const size_t lds6 = (size_t)(TPBM / 64) * 64 * NC * 8 + (size_t)NC * sizeof(int);
-            (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 6, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            constexpr int QT = fused_quantize_waves(NC) * 64;
+            const size_t lds6 = (size_t)(QT / 64) * 64 * NC * 8 + (size_t)NC * sizeof(int);
+            (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 6, QT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       E2VQ_LDS_BYTES);
-            hipLaunchKernelGGL((k_pass_pre<NC, 6, TPBM>), dim3(grid), dim3(TPBM), lds6, s, (const double*)nullptr, T, nblocks,
+            hipLaunchKernelGGL((k_pass_pre<NC, 6, QT>), dim3(pre_grid(nblocks, QT / 64, 256)), dim3(QT), lds6, s, (const double*)nullptr, T, nblocks,
                                (const h8*)nullptr, (const float*)nullptr, (const h8*)cimg, (PreScalars*)ps, cbq, M / 32,
                                idxmask, sc, (const u64*)l1max_bits, sym, dmin, rows, fb_list, stagger, prev_sym, 0, aos,
                                ea_fused);
@@ -2267,7 +2317,7 @@ int launch_accumulate_ranges(int NC, const double* aos, long T, const unsigned s
 // ---- the recorded accumulate (k_pass_pre_lds<.., 2> + k_reduce_records) ------------------------------------------------------
 bool prefilter_records_plan(int NC, int M, bool family, long nblocks, PassRecords* plan, size_t* recs_bytes)
 {
-    if (!pre_has_nc(NC) || !prefilter_lds_stage(NC) || 2 * NC + 1 > 80 || !prefilter_supports(NC, M)) return false;
+    if (!pre_has_nc(NC) || !prefilter_lds_stage(NC) || NC >= 64 || !prefilter_supports(NC, M)) return false;
     if (nblocks * 64 >= (1L << 31)) return false;  // (frame numbers are 32-bit in a record)
     const int RS = (2 * NC + 5 + 7) & ~7;
     (void)RS;
@@ -2281,9 +2331,10 @@ bool prefilter_records_plan(int NC, int M, bool family, long nblocks, PassRecord
     const int ncells = (nb_rows + nb_fam) * bc;
     for (int c = 0; c < ncells; ++c)
         if ((int)(((unsigned)c * magic) >> 22) != c / bc) return false;
-    const int grid = pre_grid(nblocks, 8, 256);
-    const long blocks_per_wave = (nblocks + (long)grid * 8 - 1) / ((long)grid * 8);
-    const long cap = 2 * 8 * blocks_per_wave * 64;  // every frame of the workgroup twice in one bin: '+' and '-'
+    const int waves = pre_lds_waves(NC);  // waves per sweeping workgroup
+    const int grid = pre_grid(nblocks, waves, 256);
+    const long blocks_per_wave = (nblocks + (long)grid * waves - 1) / ((long)grid * waves);
+    const long cap = 2 * waves * blocks_per_wave * 64;  // every frame of the workgroup twice in one bin: '+' and '-'
     if (cap >= (1L << 30)) return false;
     plan->grid = grid;
     plan->nbins = nb_rows + nb_fam;
@@ -2319,7 +2370,7 @@ int launch_reduce_records(int NC, const double* aos, const PassRecords& plan, bo
     switch (NC) {
 #define X(N)                                                                                                          \
     case N:                                                                                                           \
-        if constexpr (2 * N + 1 <= 80) {                                                                              \
+        if constexpr (N < 64) {                                                                                       \
             (void)hipFuncSetAttribute((const void*)k_reduce_records<N>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                       E2VQ_LDS_BYTES - 32768);                                                        \
             hipLaunchKernelGGL((k_reduce_records<N>), dim3((unsigned)nwg), dim3(REC_TPB), lds, s, aos, rec, plan.grid, sc, \

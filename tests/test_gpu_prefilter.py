@@ -410,6 +410,32 @@ def test_prefilter_for_other_prediction_orders(oracle, monkeypatch, Pn):
     assert oracle_lib.rows_match(rows_bad, rows_o, Pn), np.argwhere(rows_bad != rows_o)[:10]
 
 
+@pytest.mark.parametrize("records", ["1", "0"])
+def test_order_40_runs_seven_waves_per_workgroup(oracle, monkeypatch, records):
+    """P = 40: 21 KB of FP64 frames per wave -- seven waves per workgroup instead of eight in the LDS-staged pass and in
+    fused quantize (round 4) -- and rows of 83 elements, which only the recorded accumulate can add: with
+    ECOZ2_VQ_RECORDS=0 the pass falls back to round 2's kernel and no first pass is seeded.  Default thresholds (prefilter and
+    seeding from M = 128), ladder to 1024 on a ragged frame count."""
+    monkeypatch.setenv("ECOZ2_VQ_RECORDS", records)
+    Pn = 40
+    frames = e.synth.synth_frames(20340, 9, Pn, 0, 64 * 7 * 9 + 37)
+    rc, levels_o, cbs_o = oracle.learn(frames, 0.05, 1024)
+    assert rc == 0
+    cbs = []
+    with e.VqSession(Pn) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        levels = s.learn(0.05, 1024, callback=lambda M, a, sg, i: cbs.append((M, a, sg, i)))
+        refl = s.get_codebook()
+        used = s.last_pass_info()[0]
+        sym, dmin = s.quantize(frames)
+    assert used and [(l.M, l.passes) for l in levels] == [(l["M"], l["passes"]) for l in levels_o] and cbs == cbs_o
+    assert np.array_equal(refl.view(np.uint64), levels_o[-1]["reflections"].view(np.uint64))
+    sym_o, dmin_o = oracle.quantize(oracle.reflections_to_cq(refl), frames)
+    assert np.array_equal(sym, sym_o) and np.array_equal(dmin.view(np.uint64), dmin_o.view(np.uint64))
+
+
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("first,T", [(1, 4097), (3, 64), (5, 63), (2, 1), (7, 12345)])
 def test_device_resident_quantize_at_unaligned_offsets(oracle, monkeypatch, fused, first, T):
