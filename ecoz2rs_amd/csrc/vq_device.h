@@ -77,6 +77,7 @@ struct PassRecords {
     int bin_cells;     // cells per bin (the LDS table of a reducing workgroup)
     unsigned magic;    // cell / bin_cells == (cell * magic) >> 22 for every cell of the plan
     int cap;           // records per region
+    long long* total_out;  // (optional, host-mapped) the reduce kernel stores the pass's number of records here
 };
 // fills everything but the two pointers; false: no plan (order / size not served).  bytes: what recs needs.
 bool prefilter_records_plan(int NC, int M, bool family, long nblocks, PassRecords* plan, size_t* recs_bytes);

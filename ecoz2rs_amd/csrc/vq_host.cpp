@@ -98,7 +98,7 @@ struct e2vq_session {
     bool spec_zeroed = false;  // the pass prologue zeroed d_l1max_spec and the shadow image's scalars
     hipEvent_t ev_stats = nullptr;
     bool stats_event = false;  // ECOZ2_VQ_STATS_EVENT=1: an event behind the statistics kernel instead of stream queries (A/B)
-    struct HostStats { i64 l[64 * 8]; u64 l1bits; volatile u64 seq; i64 failed; volatile u64 seq2; volatile u64 err; }* h_stats = nullptr;  // pinned, host-mapped
+    struct HostStats { i64 l[64 * 8]; u64 l1bits; volatile u64 seq; i64 failed; volatile u64 seq2; volatile u64 err; volatile i64 rec_total; }* h_stats = nullptr;  // pinned, host-mapped
     long verified_passes = 0;
     bool verify_publish = false;  // ECOZ2_VQ_VERIFY_PUBLISH: recompute every published statistic on the host from the rows
     bool failed_pending = false;              // the failed-recursion count of stats_seq has not been read yet (seq2)
@@ -187,6 +187,16 @@ struct e2vq_session {
     bool rec_enabled = true;
     int rec_min_M = 64;
     size_t rec_max_bytes = (size_t)8192 << 20;
+    // Few contributions (the later passes of a level run to a small epsilon): the burst of atomics inside the sweep hides
+    // under the sweep and is cheaper than a second kernel.  k_reduce_records publishes the pass's record count; once it falls
+    // below frames / rec_few_div the rest of the level runs the burst (ECOZ2_VQ_RECORDS_FEW_DIV, 0 = never switch).
+    // Measured on levels of 11-12 passes (profiles/r04_records.txt): 1/3 is best or within noise of it at M = 256 / 512 /
+    // 1024; the usual three-pass level (65 % / 46 % / 31 % of the frames recorded) stays on records throughout
+    int rec_few_div = 3;
+    bool last_recorded = false;    // the last pass recorded its contributions
+    bool rec_pending = false;      // the pass in flight publishes its record count
+    bool rec_level_burst = false;  // this level has switched to the burst
+    i64 rec_last_total = -1;       // records of the last recorded pass (-1: none yet at this level)
     void* d_recs = nullptr;
     size_t recs_cap = 0;
     int* d_rec_counts = nullptr;
@@ -329,6 +339,7 @@ static int session_init(e2vq_session* s)
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS")) s->rec_enabled = atoi(rc) != 0;
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS_MIN_M")) s->rec_min_M = std::max(64, atoi(rc));
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS_MAX_MB")) s->rec_max_bytes = (size_t)std::max(0, atoi(rc)) << 20;
+    if (const char* rc = getenv("ECOZ2_VQ_RECORDS_FEW_DIV")) s->rec_few_div = std::max(0, atoi(rc));
     // With the recorded accumulate the prefiltered pass also wins at M = 128 (0.36 vs 0.43 ms per pass on 2^21 frames; not
     // at 64: 0.30 vs 0.28), and a seeded first pass halves the records of every prefiltered level's first pass
     if (s->rec_enabled && e2vq::prefilter_lds_stage(s->NC)) {
@@ -854,6 +865,15 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     if (keep && !split && mode != 0) {
         size_t bytes = 0;
         records = records_plan(s, s->M, family, &recplan, &bytes);
+        // few records on the last pass of this level: the rest of the level adds its contributions as a burst
+        if (!incremental) {
+            s->rec_level_burst = false;
+            s->rec_last_total = -1;
+        } else if (records && s->rec_few_div > 0 && e2vq::prefilter_burst_supported(s->NC) &&
+                   (s->rec_level_burst || (s->rec_last_total >= 0 && s->rec_last_total < s->T / s->rec_few_div))) {
+            s->rec_level_burst = true;
+            records = false;
+        }
         if (records && bytes > s->recs_cap) {
             // (grown rarely: sized at once for a codebook four times this one's when the limit allows)
             size_t want = bytes;
@@ -877,6 +897,13 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         if (records && !s->d_rec_counts) HIPCHK(hipMalloc(&s->d_rec_counts, 256 * 64 * sizeof(int)));
         recplan.recs = s->d_recs;
         recplan.counts = s->d_rec_counts;
+        s->last_recorded = records;
+        if (records) {
+            void* dt = nullptr;
+            HIPCHK(hipHostGetDevicePointer(&dt, (void*)&s->h_stats->rec_total, 0));
+            recplan.total_out = (long long*)dt;
+            s->rec_pending = true;
+        }
     }
     // (P = 40: rows of 83 elements are seeded only where the contributions are recorded -- the burst cannot add them)
     if (family && !records && !e2vq::prefilter_burst_supported(s->NC)) family = false;
@@ -1014,6 +1041,15 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     s->rows_fresh = true;
     s->spec_valid = false;
     s->img_valid[1 - s->img_cur] = false;
+    return 0;
+}
+
+// did the last e2vq_pass record its contributions for k_reduce_records (1) or add them itself (0), and how many records the
+// last recorded pass of this level wrote (-1: none yet; valid once that pass's statistics have been read)
+extern "C" int e2vq_last_pass_records(e2vq_session* s, int* recorded, int64_t* records)
+{
+    if (recorded) *recorded = s->last_recorded ? 1 : 0;
+    if (records) *records = s->rec_last_total;
     return 0;
 }
 
@@ -1264,6 +1300,10 @@ static int pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_fai
     s->spec_valid = true;
     // spin on the sequence number (microseconds); the event is the safety net should the kernel never get there
     if (spin_for_sequence(s, &s->h_stats->seq, "statistics kernel")) return 1;
+    if (s->rec_pending) {  // (stored by the reduce kernel, which ran ahead of the statistics kernel on the same queue)
+        s->rec_last_total = s->h_stats->rec_total;
+        s->rec_pending = false;
+    }
     i64 l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int slot = 0; slot < 64; ++slot)
         for (int k = 0; k < 8; ++k) l[k] += s->h_stats->l[slot * 8 + k];

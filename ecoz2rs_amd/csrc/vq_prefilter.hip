@@ -1156,6 +1156,7 @@ struct PreRec {
     int* counts;
     int nbins, nbins_rows, bin_cells, cap;
     unsigned magic;
+    long long* total_out;
 };
 
 template <int NC, bool ROT, int ACC>
@@ -1759,6 +1760,8 @@ constexpr int REC_PER_THREAD = 4;
 constexpr int REC_CHUNK = REC_TPB * REC_PER_THREAD;
 constexpr int REC_BATCH = 8;
 
+// (three workgroups per CU need <= 85 VGPRs: 66 as compiled -- the allocation is touchy, a store of `all` straight from the
+// scan cost 104 registers and a third of the kernel's speed; check with tools/isa_regs.py after touching this kernel)
 template <int NC>
 __global__ __launch_bounds__(REC_TPB, 4) void k_reduce_records(const double* __restrict__ aos, PreRec rec, int nregions,
                                                             const DevScalars* __restrict__ sc,
@@ -1777,7 +1780,7 @@ __global__ __launch_bounds__(REC_TPB, 4) void k_reduce_records(const double* __r
     // of all records into the side table's bins), a bin's share divides the bin's list -- its regions one after the other --
     // into equal portions.  Every workgroup derives the same plan from the counts (grid x bins words, out of L2).
     __shared__ int btot[64];   // records per bin
-    __shared__ int ubase[65];  // first workgroup of a bin
+    __shared__ int ubase[66];  // first workgroup of a bin; [64] = workgroups in use, [65] = records of the pass
     const int lane0 = threadIdx.x & 63;
     {
         const int b = (int)threadIdx.x >> 3, part = (int)threadIdx.x & 7;  // eight threads per bin
@@ -1805,8 +1808,12 @@ __global__ __launch_bounds__(REC_TPB, 4) void k_reduce_records(const double* __r
         }
         ubase[lane0] = v - u;
         if (lane0 == 63) ubase[64] = v;
+        if (lane0 == 0) ubase[65] = (int)(all > 0x7fffffff ? 0x7fffffff : all);  // (published below)
     }
     __syncthreads();
+    // (the host picks the next pass's accumulate by the number of records: few -> the burst of atomics is cheaper than this kernel)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && rec.total_out)
+        __hip_atomic_store(rec.total_out, (long long)ubase[65], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((int)blockIdx.x >= ubase[64]) return;  // (workgroup-uniform)
     int r = 0;  // the last non-empty bin that starts at or before this workgroup
     for (int b = 0; b < rec.nbins; ++b)
@@ -2367,6 +2374,7 @@ int launch_reduce_records(int NC, const double* aos, const PassRecords& plan, bo
     rec.bin_cells = plan.bin_cells;
     rec.cap = plan.cap;
     rec.magic = plan.magic;
+    rec.total_out = plan.total_out;
     switch (NC) {
 #define X(N)                                                                                                          \
     case N:                                                                                                           \

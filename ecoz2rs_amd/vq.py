@@ -264,6 +264,12 @@ class VqSession:
         check(lib.e2vq_timing_sweep_total(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def last_pass_records(self):
+        """(did the last run_pass record its contributions for k_reduce_records?, records of the level's last recorded pass)."""
+        r, n = C.c_int(), C.c_int64()
+        check(lib.e2vq_last_pass_records(self._h, C.byref(r), C.byref(n)))
+        return bool(r.value), n.value
+
     def last_pass_info(self):
         """(prefiltered sweep used?, frames it left to the full FP64 sweep) of the last run_pass."""
         used, n = C.c_int(), C.c_int64()

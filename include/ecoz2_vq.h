@@ -197,6 +197,10 @@ int e2vq_timing_sweep_total(e2vq_session *s, double *total_ms, int64_t *passes);
 /* which sweep served the last e2vq_pass: *prefiltered = 1 when the f16-prefiltered sweep ran (P = 36, large M),
  * *fallback_frames = frames it handed to the full FP64 sweep (synchronises the stream) */
 int e2vq_last_pass_info(e2vq_session *s, int *prefiltered, int64_t *fallback_frames);
+/* *recorded = 1 when the last e2vq_pass recorded its contributions to the cell sums for k_reduce_records (0: it added them
+ * itself); *records = how many the last recorded pass of this level wrote (-1: none yet; valid once e2vq_pass_stats has
+ * returned for that pass).  Few records switch the rest of a level to the burst of atomics (ECOZ2_VQ_RECORDS_FEW_DIV). */
+int e2vq_last_pass_records(e2vq_session *s, int *recorded, int64_t *records);
 /* number of training-pass sweep launches so far, by kernel family (k_pass_pre / k_pass_mfma+generic): lets a
  * kernel trace of a whole run be cut to the dispatches of a timed region */
 int e2vq_sweep_launch_counts(e2vq_session *s, int64_t *prefiltered, int64_t *plain);
