@@ -108,7 +108,8 @@ int launch_pass_fallback(int NC, bool accumulate, const double* blk, const doubl
 // (cells_out: where the listed frames' new cells are recorded -- default: in place, prev_sym)
 // the seeded first pass after a split (vq_device.hip: k_seed_family): rows <- parents' sums in the even children, X <- 0;
 // after the pass (and its fallback sweep) launch_family_fixup moves the in-family arrivals X[i] from row 2 i to row 2 i + 1
-void launch_seed_family(const long long* parent, long long* rows, long long* X, int Mold, int NC, hipStream_t s);
+void launch_seed_family(const long long* parent, long long* rows, long long* X, int Mold, int NC, hipStream_t s,
+                        const struct ZeroList* zero = nullptr);
 void launch_family_fixup(long long* rows, const long long* X, int Mold, int NC, hipStream_t s);
 void launch_zero_distortion_columns(long long* rows, int M, int NC, hipStream_t s);
 void launch_rows_stats(const long long* rows, int M, int NC, const DevScalars* sc, double* S, double* within,
@@ -163,7 +164,7 @@ void launch_pass_prologue(long long* rows, int M, int NC, int what, const ZeroLi
 void launch_finish_q(const long long* stats, int NC, DevScalars* sc, hipStream_t s);
 void launch_init_codebook(const long long* stats, int NC, const DevScalars* sc, double* reflections, int* status,
                           hipStream_t s);
-void launch_grow(const double* old_refl, int M, int NC, double* new_refl, hipStream_t s);
+void launch_grow(const double* old_refl, int M, int NC, double* new_refl, hipStream_t s, const struct ZeroList* zero = nullptr);
 void launch_codebook_prepare(const double* reflections, int M, int NC, double* cbq, unsigned long long* l1max_bits,
                              double* cbm, hipStream_t s);
 

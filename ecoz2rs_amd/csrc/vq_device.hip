@@ -1285,8 +1285,13 @@ __global__ void k_finish_q(const i64* __restrict__ stats, int NC, DevScalars* __
 }
 
 // K4a: M -> 2M split, in place from the top (new[2i] = old[i]*0.99, new[2i+1] = old[i]*1.01)
-__global__ void k_grow(const double* __restrict__ old_refl, int M, int NC, double* __restrict__ new_refl)
+// (+ up to two small blocks of words zeroed on the way -- the L1 maximum and the limb-image scalars that the kernels behind it
+// accumulate into with atomicMax: a memset each, with its own gap in the queue, otherwise)
+__global__ void k_grow(const double* __restrict__ old_refl, int M, int NC, double* __restrict__ new_refl, ZeroList z)
 {
+    if (blockIdx.x == 0)
+        for (int k = 0; k < 3; ++k)
+            for (int j = threadIdx.x; j < z.words[k]; j += blockDim.x) ((unsigned int*)z.p[k])[j] = 0u;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * NC) return;
     const int m = i / NC, n = i - m * NC;
@@ -1578,8 +1583,11 @@ int launch_pass_fallback(int NC, bool accumulate, const double* blk, const doubl
 // += X[i], rows[2 i] -= X[i].  Exact 64-bit integers throughout: the rows equal a full accumulation bit for bit, at
 // ~0.55-0.65 of its atomic traffic (1 add for ~46 % of the frames, 2 for the 3-10 % that leave, none for the rest).
 __global__ void k_seed_family(const i64* __restrict__ parent, i64* __restrict__ rows, i64* __restrict__ X, int Mold, int NC,
-                              int RS)
+                              int RS, ZeroList z)
 {
+    if (blockIdx.x == 0)  // (the pass's small words to zero: this kernel stands in for the prologue of a seeded pass)
+        for (int k = 0; k < 3; ++k)
+            for (int j = threadIdx.x; j < z.words[k]; j += blockDim.x) ((unsigned int*)z.p[k])[j] = 0u;
     const long n = (long)Mold * RS;
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
         const long i = o / RS;
@@ -1605,10 +1613,12 @@ __global__ void k_family_fixup(i64* __restrict__ rows, const i64* __restrict__ X
     }
 }
 
-void launch_seed_family(const i64* parent, i64* rows, i64* X, int Mold, int NC, hipStream_t s)
+void launch_seed_family(const i64* parent, i64* rows, i64* X, int Mold, int NC, hipStream_t s, const ZeroList* zero)
 {
     const int RS = row_stride(NC);
-    hipLaunchKernelGGL(k_seed_family, dim3(grid_for((long)Mold * RS, 256, 1024)), dim3(256), 0, s, parent, rows, X, Mold, NC, RS);
+    ZeroList z{};
+    if (zero) z = *zero;
+    hipLaunchKernelGGL(k_seed_family, dim3(grid_for((long)Mold * RS, 256, 1024)), dim3(256), 0, s, parent, rows, X, Mold, NC, RS, z);
 }
 
 void launch_family_fixup(i64* rows, const i64* X, int Mold, int NC, hipStream_t s)
@@ -1755,9 +1765,11 @@ void launch_init_codebook(const i64* stats, int NC, const DevScalars* sc, double
                        status);
 }
 
-void launch_grow(const double* old_refl, int M, int NC, double* new_refl, hipStream_t s)
+void launch_grow(const double* old_refl, int M, int NC, double* new_refl, hipStream_t s, const ZeroList* zero)
 {
-    hipLaunchKernelGGL(k_grow, dim3((M * NC + 255) / 256), dim3(256), 0, s, old_refl, M, NC, new_refl);
+    ZeroList z{};
+    if (zero) z = *zero;
+    hipLaunchKernelGGL(k_grow, dim3((M * NC + 255) / 256), dim3(256), 0, s, old_refl, M, NC, new_refl, z);
 }
 
 void launch_codebook_prepare(const double* reflections, int M, int NC, double* cbq, u64* l1max_bits, double* cbm,

@@ -162,6 +162,8 @@ struct e2vq_session {
     i64 qpre_cap = 0;
     i64 qfb_cap = 0;
     u64 cb_version = 1;    // bumped whenever the codebook in d_cbq changes
+    u64 scale_version = 0; // codebook version whose limb-image scale e2vq_grow's update kernel has already found ...
+    int scale_img = -1;    // ... in the scalars of this image (zeroed there too)
     u64 qimg_version = 0;  // codebook version d_qcimg / d_ea_q / d_ps were built for
     int qcimg_cap = 0;
     // incremental accumulation (prefiltered passes): the rank's own rows and every frame's cell persist between
@@ -241,6 +243,8 @@ struct e2vq_session {
 };
 
 static bool split_accumulate(const e2vq_session* s, int M);
+static int pass_mode(const e2vq_session* s);
+static bool use_prefilter(const e2vq_session* s, int mode);
 
 static int ensure_codebook_capacity(e2vq_session* s, int M)
 {
@@ -666,16 +670,25 @@ extern "C" int e2vq_prepare(e2vq_session* s)
 // ---- codebook ----------------------------------------------------------------------------
 
 // (callers that redefine the codebook's size or contents from outside: set / init / grow)
-static int codebook_prepare(e2vq_session* s, bool redefined = true, bool grown = false)
+// zeroed_with_scale >= 0 (e2vq_grow): the L1 maximum and the scalars of limb image `zeroed_with_scale` have been zeroed by
+// the kernel in front (k_grow), and the update kernel also finds the image's scale -- the image kernel of the first pass then
+// needs neither a memset nor k_pre_cmax
+static int codebook_prepare(e2vq_session* s, bool redefined = true, bool grown = false, int zeroed_with_scale = -1)
 {
     if (redefined) s->incr_valid = false;
     if (!grown) s->fam_pending = false;  // (set / init: whatever e2vq_grow stashed belongs to another codebook)
     s->img_valid[0] = s->img_valid[1] = false;  // the codebook in d_cbq is a new one
     s->cb_version++;
-    if (e2vq::has_cell_update(s->NC))
+    if (e2vq::has_cell_update(s->NC)) {
+        const bool scale = zeroed_with_scale >= 0;  // (-2: only the L1 maximum has been zeroed)
         e2vq::launch_cell_update(nullptr, s->M, s->NC, s->d_sc, s->d_refl, nullptr, s->d_cbq, s->d_cbm, s->d_l1max,
-                                 nullptr, nullptr, s->stream);
-    else
+                                 nullptr, nullptr, s->stream, /*zero_first=*/zeroed_with_scale == -1, scale ? s->d_ea : nullptr,
+                                 scale ? e2vq::prefilter_codebook_scale(s->d_ps2[zeroed_with_scale]) : nullptr);
+        if (scale) {
+            s->scale_version = s->cb_version;
+            s->scale_img = zeroed_with_scale;
+        }
+    } else
         e2vq::launch_codebook_prepare(s->d_refl, s->M, s->NC, s->d_cbq, s->d_l1max, s->d_cbm, s->stream);
     HIPCHK(hipGetLastError());
     s->stats_valid = false;
@@ -747,10 +760,25 @@ extern "C" int e2vq_grow(e2vq_session* s)
         s->fam_M = s->M;
     }
     if (ensure_codebook_capacity(s, 2 * s->M)) return 1;
-    e2vq::launch_grow(s->d_refl, s->M, s->NC, s->d_refl_next, s->stream);
+    // one kernel zeroes what the kernels behind it accumulate into with atomicMax: the L1 maximum of the grown codebook and --
+    // when its first pass will be a prefiltered one -- the scalars of the limb image that pass builds
+    const int Mold = s->M;
+    s->M = 2 * Mold;
+    const bool fused = e2vq::has_cell_update(s->NC);
+    const bool pre_next = fused && s->d_ea && s->d_ps2[s->img_cur] && use_prefilter(s, pass_mode(s));
+    e2vq::ZeroList z{};
+    int nz = 0;
+    if (fused) {
+        z.p[nz] = s->d_l1max;
+        z.words[nz++] = 2;
+        if (pre_next) {
+            z.p[nz] = s->d_ps2[s->img_cur];
+            z.words[nz++] = (int)(e2vq::prefilter_scalars_bytes() / 4);
+        }
+    }
+    e2vq::launch_grow(s->d_refl, Mold, s->NC, s->d_refl_next, s->stream, &z);
     std::swap(s->d_refl, s->d_refl_next);
-    s->M *= 2;
-    if (codebook_prepare(s, true, /*grown=*/true)) return 1;
+    if (codebook_prepare(s, true, /*grown=*/true, fused ? (pre_next ? s->img_cur : -2) : -1)) return 1;
     s->fam_pending = seed;
     return 0;
 }
@@ -928,10 +956,12 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             z.p[nz] = s->d_ps2[1 - s->img_cur];
             z.words[nz++] = (int)(e2vq::prefilter_scalars_bytes() / 4);
         }
-        // (the seeded first pass writes every word of the rows itself)
-        e2vq::launch_pass_prologue(rows, s->M, s->NC, family ? 0 : (incremental ? 2 : (mode != 0 ? 1 : 0)), z, s->stream);
+        // (the seeded first pass writes every word of the rows itself: k_seed_family takes the small words along)
+        if (family)
+            e2vq::launch_seed_family(s->d_rows_parent, rows, s->d_fam, s->fam_M, s->NC, s->stream, &z);
+        else
+            e2vq::launch_pass_prologue(rows, s->M, s->NC, incremental ? 2 : (mode != 0 ? 1 : 0), z, s->stream);
         s->spec_zeroed = true;
-        if (family) e2vq::launch_seed_family(s->d_rows_parent, rows, s->d_fam, s->fam_M, s->NC, s->stream);
     }
     // a plain pass records every frame's cell when the next size could be seeded from it (the level below the first
     // prefiltered one)
@@ -959,7 +989,8 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         const int k = s->img_cur;
         if (!s->img_valid[k])  // (else: built ahead by e2vq_pass_stats for the codebook committed since; the prologue
                                // restarted its fallback count)
-            e2vq::launch_prefilter_codebook(s->d_cbq, s->M, s->NC, s->d_ea, s->d_ps2[k], s->d_cimg2[k], s->stream);
+            e2vq::launch_prefilter_codebook(s->d_cbq, s->M, s->NC, s->d_ea, s->d_ps2[k], s->d_cimg2[k], s->stream,
+                                            /*scale_ready=*/s->scale_version == s->cb_version && s->scale_img == k);
         s->img_valid[k] = true;
         s->img_last = k;
         void* const d_cimg = s->d_cimg2[k];
