@@ -250,6 +250,39 @@ def test_incremental_rows_match_a_full_accumulation_every_pass(oracle, monkeypat
     assert bool(calls) == collective
 
 
+@pytest.mark.parametrize("few_div,expect", [("0", [True] * 5), ("1", [True, False, False, False, False])])
+def test_few_records_switch_the_level_to_the_burst(oracle, monkeypatch, few_div, expect):
+    """k_reduce_records publishes the pass's record count; below frames / ECOZ2_VQ_RECORDS_FEW_DIV the rest of the level adds
+    its contributions as the burst of atomics inside the sweep (round 4).  Forced here (divisor 1: any incremental pass) and
+    disabled (0): the two accumulates follow each other within a level and the rows equal the oracle's every pass."""
+    monkeypatch.setenv("ECOZ2_VQ_RECORDS_FEW_DIV", few_div)
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
+    M = 256
+    frames = _frames(20311, 9000)
+    refl = np.concatenate([_codebook(oracle, frames, M // 2, seed=11)] * 2, axis=0)
+    rc, st = oracle.data_stats(frames)
+    sh_r, _ = oracle.shifts(st.maxabs)
+    recorded = []
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.set_codebook(refl)
+        for it in range(5):
+            cq = oracle.reflections_to_cq(refl)
+            _sym, _dmin, rows_o = oracle.run_pass(cq, frames, sh_r, oracle.dist_exponent(cq, st.maxabs))
+            s.run_pass()
+            assert s.last_pass_info()[0]
+            assert oracle_lib.rows_match(s.get_rows(), rows_o, P), f"pass {it}"
+            s.pass_stats()
+            recorded.append(s.last_pass_records()[0])
+            refl, _failed = oracle.update(rows_o, P, sh_r, refl)
+            s.update()
+            assert np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64))
+        total = s.last_pass_records()[1]
+    assert recorded == expect, recorded
+    assert 0 <= total <= 2 * len(frames)
+
+
 @pytest.mark.parametrize("split_max_m", [-1, 0, 128, 4096])
 @pytest.mark.parametrize("collective", [False, True])
 @pytest.mark.parametrize("min_m", [64, 256])
