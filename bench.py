@@ -126,6 +126,135 @@ def cpu_baseline(e, np):
     }
 
 
+SMALL_CORPUS_T = 38265     # the one vq-learn run the reference documents: notes.md:122-153 (38 265 vectors, eps 0.05, M = 2 ... 2048)
+SMALL_CORPUS_M = 2048
+
+
+def small_corpus(e, np, with_cpu):
+    """Untimed extra (VERDICT r04 task 5): the workload a drop-in user runs first.  `ecoz2 vq learn` from a .prd file as a
+    fresh process (HIP start-up included) and warm through the same C entry point, wall time to the M = 2048 .cbook; the ladder
+    level by level on resident frames (passes, kernel and step time per pass: all launch latency at this size); `ecoz2 vq
+    quantize` of the same corpus split into ~100-frame files; and -- rank 0, next to it -- the CPU stand-in (the oracle source
+    with the reference's flags, all host threads) on the same frames."""
+    import shutil
+    import tempfile
+
+    T, MM = SMALL_CORPUS_T, SMALL_CORPUS_M
+    root = tempfile.mkdtemp(prefix="e2small_")
+    out = {"what": f"notes.md:122-153: {T} training vectors, eps 0.05, M = 2 ... {MM}, P = {P}; synthetic frames (seed {SEED})",
+           "frames": T, "max_codebook_size": MM}
+    try:
+        frames = e.synth.synth_frames(SEED, N_CLASSES, P, 0, T)
+        prd = os.path.join(root, "data", "predictors", "_", "corpus.prd")
+        e.formats.write_prd(prd, "_", frames)
+        env = dict(os.environ, ECOZ2_VQ_OUT_ROOT=root, ECOZ2_VQ_MAX_CODEBOOK_SIZE=str(MM), ECOZ2_VQ_QUIET="1")
+        cli = os.path.join(ROOT, "ecoz2rs_amd", "csrc", "ecoz2")
+        cold = []
+        for _ in range(3):  # a fresh process each (a child of this one; nothing is exec'ed over a GPU process)
+            shutil.rmtree(os.path.join(root, "data", "codebooks"), ignore_errors=True)
+            t0 = time.perf_counter()
+            subprocess.run([cli, "vq", "learn", "-P", str(P), "-e", "0.05", "--predictors", prd], env=env, check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            cold.append(time.perf_counter() - t0)
+        cb = os.path.join(root, "data", "codebooks", "_", f"eps_0.05_M_{MM:04d}.cbook")
+        out["cli_cold_seconds"] = [round(x, 4) for x in cold]
+        out["cli_wrote_codebook"] = os.path.exists(cb)
+        # warm: the reference's entry point in this process (device and library initialised)
+        saved = {k: os.environ.get(k) for k in ("ECOZ2_VQ_OUT_ROOT", "ECOZ2_VQ_MAX_CODEBOOK_SIZE")}
+        os.environ.update(ECOZ2_VQ_OUT_ROOT=root, ECOZ2_VQ_MAX_CODEBOOK_SIZE=str(MM))
+        warm = []
+        try:
+            import contextlib
+            import io
+
+            for _ in range(3):
+                t0 = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    e.vq_learn(None, P, 0.05, "_", [prd])
+                warm.append(time.perf_counter() - t0)
+            out["entry_point_warm_seconds"] = [round(x, 4) for x in warm]
+            # quantize: the corpus as ~100-frame files (383 files), cold CLI and warm entry point
+            small = []
+            for i in range(0, T, 100):
+                f = os.path.join(root, "data", "predictors", "q", f"{i // 100:05d}.prd")
+                e.formats.write_prd(f, "q", frames[i:i + 100])
+                small.append(f)
+            t0 = time.perf_counter()
+            subprocess.run([cli, "vq", "quantize", "--codebook", cb, "--predictors", os.path.join(root, "data", "predictors", "q")],
+                           env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            out["quantize_cli_cold_seconds"] = round(time.perf_counter() - t0, 4)
+            qw = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    e.vq_quantize(cb, small, False)
+                qw.append(time.perf_counter() - t0)
+            out["quantize_files"] = len(small)
+            out["quantize_entry_point_warm_seconds"] = [round(x, 4) for x in qw]
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        # the ladder on resident frames, level by level (one synchronisation per level)
+        levels = []
+        with e.VqSession(P, device=0) as s:
+            s.set_frames(frames)
+            s.prepare()
+            for rep in range(2):  # (the second repetition is the one reported: every kernel loaded)
+                levels = []
+                s.init_codebook()
+                s.synchronize()
+                t_all = time.perf_counter()
+                m = 2
+                while m <= MM:
+                    s.enable_timing(True)
+                    s.synchronize()
+                    t0 = time.perf_counter()
+                    lv = s.learn(0.05, m)[0]
+                    s.synchronize()
+                    wall = time.perf_counter() - t0
+                    kms, kn = s.timing_total()
+                    levels.append({"M": m, "passes": lv.passes, "kernel_us_per_pass": round(1e3 * kms / max(1, kn), 1),
+                                   "step_us_per_pass": round(1e6 * wall / lv.passes, 1)})
+                    m *= 2
+                t_all = time.perf_counter() - t_all
+                s.enable_timing(False)
+            s.init_codebook()
+            s.synchronize()
+            t0 = time.perf_counter()
+            whole = s.learn(0.05, MM)
+            s.synchronize()
+            out["resident_ladder_seconds"] = round(time.perf_counter() - t0, 5)
+            out["resident_ladder_passes"] = sum(x.passes for x in whole)
+            out["resident_ladder_us_per_pass"] = round(1e6 * (time.perf_counter() - t0) / max(1, out["resident_ladder_passes"]), 1)
+        out["levels"] = levels
+        if with_cpu:
+            from tests import oracle_lib
+
+            variant = "libvqoracle_fast_native.so" if os.path.exists(os.path.join(ROOT, "oracle", "_build", "libvqoracle_fast_native.so")) \
+                else "libvqoracle_fast.so"
+            fast = oracle_lib.load(variant)
+            best = None
+            for nt in (8, 16, 32):
+                fast.set_threads(nt)
+                t0 = time.perf_counter()
+                rc, lv_o, _cbs = fast.learn(frames, 0.05, MM)
+                dt = time.perf_counter() - t0
+                if rc == 0 and (best is None or dt < best[0]):
+                    best = (dt, nt, sum(x["passes"] for x in lv_o))
+            if best:
+                out["cpu_stand_in"] = {"seconds": round(best[0], 4), "threads": best[1], "passes": best[2], "kind": "port",
+                                       "what": f"the oracle source with the reference's flags ({variant}), whole ladder in memory "
+                                               "(no file I/O), fastest of 8 / 16 / 32 threads"}
+    except Exception as ex:  # informational: never fails the bench line
+        out["error"] = repr(ex)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (never an exec; this
     parent has made no GPU call), one per GPU -- LOCAL_RANK modulo the device count inside the child, so that a
@@ -644,6 +773,9 @@ def run(args, comm):
             except Exception as ex:  # (a box short of host memory: the figure is informational)
                 big = {"error": repr(ex)}
 
+    small = None
+    if extras and rank == 0 and world == 1 and M == 1024 and not os.environ.get("ECOZ2_BENCH_SKIP_SMALL"):
+        small = small_corpus(e, np, with_cpu=not args.no_cpu_baseline)
     if rank == 0:
         k_ms = kernel_ms_total / kernel_passes
         frames_per_launch = S
@@ -773,6 +905,7 @@ def run(args, comm):
                 },
                 "quantize_frames_per_sec_device_resident": q_rate,
                 "strong_scaling_16M": big,
+                "small_corpus": small,
             },
             "roofline": roofline,
             "roofline_algorithmic": roofline_algorithmic,

@@ -1361,13 +1361,18 @@ static inline int grid_for(long work_items, int per_block, int cap)
 
 // Every prediction order P = 4 .. 40 (NC = 5 .. 41) has an instantiation of the MFMA sweep: NC = 4k+1 runs the
 // trailing coefficient on the VALU, the others zero-pad the last k-step.  Larger P take k_pass_generic.
+// (overridable on the command line: tests/test_isa_guards.py compiles the P = 36 instantiations alone)
+#ifndef E2VQ_MFMA_NC_LIST
 #define E2VQ_MFMA_NC_LIST(X) \
     X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) \
     X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41)
+#endif
 // ... and, round 4, P = 41 .. 80 (NC = 42 .. 81) with half blocks per wave (assignment and global-atomic accumulate)
+#ifndef E2VQ_MFMA_WIDE_NC_LIST
 #define E2VQ_MFMA_WIDE_NC_LIST(X) \
     X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) \
     X(62) X(63) X(64) X(65) X(66) X(67) X(68) X(69) X(70) X(71) X(72) X(73) X(74) X(75) X(76) X(77) X(78) X(79) X(80) X(81)
+#endif
 bool uses_mfma(int NC) { return NC >= 5 && NC <= 81; }
 bool mfma_is_wide(int NC) { return NC > 41 && NC <= 81; }
 int mfma_hybrid_cells(int NC) { return mfma_hyb_cells(NC); }
