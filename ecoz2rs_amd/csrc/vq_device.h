@@ -90,6 +90,28 @@ int launch_reduce_records(int NC, const double* aos, const PassRecords& plan, bo
 bool accumulate_ranges_supported(int NC);
 int launch_accumulate_ranges(int NC, const double* aos, long T, const unsigned short* cells_new, const unsigned short* cells_old,
                              bool incremental, int M, const DevScalars* sc, long long* rows, hipStream_t s);
+// round 5 (vq_sweep.hip): the accumulating prefiltered pass as sort (once per level) + candidate sweep + finishing kernel +
+// launch_reduce_records.  sweep_supported: the order has a prefiltered sweep and its rows fit the finishing kernel's LDS.
+bool sweep_supported(int NC, int M);
+size_t sweep_frame_image_bytes(int NC, long nblocks64);
+// frame-major limb image (same limbs as launch_prefilter_frames, whose scales `ea` it uses) from the row-major resident copy
+void launch_sweep_frames(const double* aos, long T, long nblocks64, int NC, const int* ea, void* img, hipStream_t s);
+size_t sort_scratch_bytes();                 // zero it once; holds the sort's histogram / cursor and the sweep's counters
+void* sweep_counters_of(void* sort_scratch); // two unsigned 64-bit words: flagged jobs, jobs (added to by every two-stage sweep)
+// perm[slot] = frame, frames grouped by key (< nbins <= 8192); perm holds nblocks64 * 64 slots
+int launch_sort_by_cell(const unsigned short* key, long T, long nblocks64, int nbins, void* scratch, unsigned* perm, hipStream_t s);
+// cand[frame] = c1 | c2 << 13 | amb << 26 | cert << 27.  perm == nullptr: slots are frames.  home_mul: 0 = no home tile,
+// else the home codeword of a block is home_mul * prev_sym[its first frame] (1: cells of the previous pass, 2: of the parents)
+int launch_sweep_candidates(int NC, bool two_stage, const void* fimg, const unsigned* perm, long T, long nblocks, const void* cimg,
+                            const void* ps, int M, const unsigned short* prev_sym, int home_mul, unsigned* cand, void* counters,
+                            hipStream_t s);
+// incr: 0 full, 1 incremental, 2 seeded (as k_pass_pre_lds); the contributions are recorded for launch_reduce_records
+int launch_finish(int NC, const double* aos, long T, long nblocks, const unsigned* cand, void* ps, const double* cbq, int M,
+                  const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin, long long* rows,
+                  int* fb_list, unsigned short* prev_sym, int incr, const struct PassRecords* records, void* counters,
+                  void* host_counters, hipStream_t s);
+// (counters / host_counters: the device words of the two-stage sweep in front -- sweep_counters_of -- and two host-mapped
+// 64-bit words the kernel copies them to before it zeroes them; both null for a one-stage sweep)
 // resident_rowmajor (accumulating passes): a row-major copy of the training frames padded with zero rows to whole
 // 64-frame blocks; with it (and prefilter_lds_stage(NC)) the pass runs k_pass_pre_lds; prev_sym must then be padded
 // by 128 bytes

@@ -98,7 +98,7 @@ struct e2vq_session {
     bool spec_zeroed = false;  // the pass prologue zeroed d_l1max_spec and the shadow image's scalars
     hipEvent_t ev_stats = nullptr;
     bool stats_event = false;  // ECOZ2_VQ_STATS_EVENT=1: an event behind the statistics kernel instead of stream queries (A/B)
-    struct HostStats { i64 l[64 * 8]; u64 l1bits; volatile u64 seq; i64 failed; volatile u64 seq2; volatile u64 err; volatile i64 rec_total; }* h_stats = nullptr;  // pinned, host-mapped
+    struct HostStats { i64 l[64 * 8]; u64 l1bits; volatile u64 seq; i64 failed; volatile u64 seq2; volatile u64 err; volatile i64 rec_total; volatile u64 sw_flagged, sw_jobs; }* h_stats = nullptr;  // pinned, host-mapped
     long verified_passes = 0;
     bool verify_publish = false;  // ECOZ2_VQ_VERIFY_PUBLISH: recompute every published statistic on the host from the rows
     bool failed_pending = false;              // the failed-recursion count of stats_seq has not been read yet (seq2)
@@ -202,6 +202,21 @@ struct e2vq_session {
     void* d_recs = nullptr;
     size_t recs_cap = 0;
     int* d_rec_counts = nullptr;
+    // round 5 (vq_sweep.hip): recorded passes run as sort (once per level) + candidate sweep + finishing kernel + reduce.
+    // ECOZ2_VQ_SPLIT_SWEEP=0 keeps round 4's fused kernel (A/B).  The sweep's two-stage keys need the frames grouped by cell
+    // and data whose near codewords share tiles: the finishing kernel publishes the flagged fraction of every two-stage
+    // sweep, and above two_stage_max_frac the rest of the level (and the next one) runs the one-stage sweep.
+    bool sweep2_enabled = true;
+    bool two_stage_enabled = true;   // ECOZ2_VQ_TWO_STAGE=0: one-stage sweep always
+    double two_stage_max_frac = 0.45;
+    int two_stage_off_until_M = 0;   // one-stage sweeps while M <= this
+    bool sw_pending = false;         // a two-stage sweep's counters have not been read yet
+    void* d_fimgF = nullptr;         // frame-major limb image (gathered through d_perm)
+    unsigned* d_perm = nullptr;      // slot -> frame, grouped by the cell at the level's start
+    unsigned* d_cand = nullptr;      // per frame: the two candidates + flags
+    void* d_sort = nullptr;
+    int perm_M = 0;                  // codebook size d_perm was sorted for (0: none)
+    double last_flagged_frac = -1.0;
     i64* d_rows_local = nullptr;  // world > 1: the un-reduced rows (d_rows holds the all-reduced copy)
     int rows_local_cap = 0;
     // the seeded first pass of a level (vq_device.hip: k_seed_family): the rank's own rows of the last pass at the previous
@@ -344,6 +359,8 @@ static int session_init(e2vq_session* s)
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS_MIN_M")) s->rec_min_M = std::max(64, atoi(rc));
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS_MAX_MB")) s->rec_max_bytes = (size_t)std::max(0, atoi(rc)) << 20;
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS_FEW_DIV")) s->rec_few_div = std::max(0, atoi(rc));
+    if (const char* sw = getenv("ECOZ2_VQ_SPLIT_SWEEP")) s->sweep2_enabled = atoi(sw) != 0;
+    if (const char* sw = getenv("ECOZ2_VQ_TWO_STAGE")) s->two_stage_enabled = atoi(sw) != 0;
     // With the recorded accumulate the prefiltered pass also wins at M = 128 (0.36 vs 0.43 ms per pass on 2^21 frames; not
     // at 64: 0.30 vs 0.28), and a seeded first pass halves the records of every prefiltered level's first pass
     if (s->rec_enabled && e2vq::prefilter_lds_stage(s->NC)) {
@@ -396,7 +413,7 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     void* ptrs[] = {s->d_cbT, s->sv.refl, s->sv.rows, s->sv.rows_local, s->sv.cells, s->d_rows_parent, s->d_fam, s->d_aos, s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
-                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg2[0], s->d_cimg2[1], s->d_ps2[0], s->d_ps2[1], s->d_ps, s->d_fblist, s->d_prev_sym, s->d_cells_new, s->d_rows_local, s->d_recs, s->d_rec_counts,
+                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg2[0], s->d_cimg2[1], s->d_ps2[0], s->d_ps2[1], s->d_ps, s->d_fblist, s->d_prev_sym, s->d_cells_new, s->d_rows_local, s->d_recs, s->d_rec_counts, s->d_fimgF, s->d_perm, s->d_cand, s->d_sort,
                     s->d_ea_q, s->d_qfimg, s->d_qfg, s->d_qfblist, s->d_qcimg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -589,10 +606,39 @@ static int set_frames_device_impl(e2vq_session* s, const void* device_frames, in
                 s->d_aos = nullptr;
             }
         }
+        for (void** p : {(void**)&s->d_fimgF, (void**)&s->d_perm, (void**)&s->d_cand}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        s->perm_M = 0;
+        s->two_stage_off_until_M = 0;
+        s->sw_pending = false;
         if (fits) {
             e2vq::launch_prefilter_frames(s->d_blk, T, s->nblocks, s->NC, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg,
                                           s->stream);
             HIPCHK(hipGetLastError());
+            // round 5: the frame-major image the candidate sweep gathers from, the sorted list and the candidates (another
+            // 264 B per frame at P = 36); without them recorded passes keep to round 4's fused kernel
+            if (s->sweep2_enabled && s->d_aos && e2vq::sweep_supported(s->NC, 64)) {
+                const size_t slots = (size_t)s->nblocks * 64;
+                bool ok = hipMalloc(&s->d_fimgF, e2vq::sweep_frame_image_bytes(s->NC, s->nblocks)) == hipSuccess &&
+                          hipMalloc(&s->d_perm, slots * sizeof(unsigned)) == hipSuccess &&
+                          hipMalloc(&s->d_cand, slots * sizeof(unsigned)) == hipSuccess;
+                if (ok && !s->d_sort) {
+                    ok = hipMalloc(&s->d_sort, e2vq::sort_scratch_bytes()) == hipSuccess;
+                    if (ok) HIPCHK(hipMemsetAsync(s->d_sort, 0, e2vq::sort_scratch_bytes(), s->stream));
+                }
+                if (ok) {
+                    e2vq::launch_sweep_frames(s->d_aos, T, s->nblocks, s->NC, s->d_ea, s->d_fimgF, s->stream);
+                    HIPCHK(hipGetLastError());
+                } else {
+                    (void)hipGetLastError();
+                    for (void** p : {(void**)&s->d_fimgF, (void**)&s->d_perm, (void**)&s->d_cand}) {
+                        if (*p) (void)hipFree(*p);
+                        *p = nullptr;
+                    }
+                }
+            }
         } else {
             (void)hipGetLastError();  // clear the out-of-memory status
             for (void** p : {(void**)&s->d_fimg, (void**)&s->d_fg, (void**)&s->d_fblist, (void**)&s->d_prev_sym, (void**)&s->d_cells_new, (void**)&s->d_aos}) {
@@ -897,7 +943,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         if (!incremental) {
             s->rec_level_burst = false;
             s->rec_last_total = -1;
-        } else if (records && s->rec_few_div > 0 && e2vq::prefilter_burst_supported(s->NC) &&
+        } else if (records && !(s->sweep2_enabled && s->d_fimgF) && s->rec_few_div > 0 && e2vq::prefilter_burst_supported(s->NC) &&
                    (s->rec_level_burst || (s->rec_last_total >= 0 && s->rec_last_total < s->T / s->rec_few_div))) {
             s->rec_level_burst = true;
             records = false;
@@ -1019,6 +1065,49 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
                 HIPCHK(hipMemcpyAsync(s->d_prev_sym, device_sym, (size_t)s->T * sizeof(unsigned short), hipMemcpyDeviceToDevice, s->stream));
             else
                 std::swap(s->d_prev_sym, s->d_cells_new);
+        } else if (records && s->sweep2_enabled && s->d_fimgF && e2vq::sweep_supported(s->NC, s->M)) {
+            // round 5: [sort] -> candidate sweep -> finishing kernel (exact evaluation, outputs, records) -> reduce
+            const int incr = family ? 2 : (incremental ? 1 : 0);
+            s->n_pre_launches--;  // (counted below, behind the sort)
+            if (incr != 0 && (incr == 2 || s->perm_M != s->M)) {
+                if (e2vq::launch_sort_by_cell(s->d_prev_sym, s->T, s->nblocks, incr == 2 ? s->M / 2 : s->M, s->d_sort, s->d_perm,
+                                              s->stream))
+                    return e2vq_set_error("sort by cell: unsupported size");
+                s->perm_M = s->M;
+            }
+            const bool sorted = incr != 0 && s->perm_M == s->M;
+            const bool two = sorted && s->two_stage_enabled && s->M > s->two_stage_off_until_M;
+            if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));  // (again: the sweep kernel alone is what ev0..ev_mid brackets)
+            s->n_pre_launches++;
+            if (e2vq::launch_sweep_candidates(s->NC, two, s->d_fimgF, sorted ? s->d_perm : nullptr, s->T, s->nblocks, d_cimg, d_ps, s->M,
+                                              sorted ? s->d_prev_sym : nullptr, sorted ? incr : 0, s->d_cand,
+                                              two ? e2vq::sweep_counters_of(s->d_sort) : nullptr, s->stream))
+                return e2vq_set_error("candidate sweep: unsupported configuration");
+            if (s->timing) {
+                HIPCHK(hipEventRecord(s->ev_mid, s->stream));
+                s->timing_mid = true;
+            }
+            void* sw_host = nullptr;
+            if (two) {
+                HIPCHK(hipHostGetDevicePointer(&sw_host, (void*)&s->h_stats->sw_flagged, 0));
+                s->sw_pending = true;
+            }
+            if (e2vq::launch_finish(s->NC, s->d_aos, s->T, s->nblocks, s->d_cand, d_ps, s->d_cbq, s->M, s->d_sc, s->d_l1max,
+                                    (unsigned short*)device_sym, (double*)device_dmin, rows, s->d_fblist, s->d_prev_sym, incr,
+                                    &recplan, two ? e2vq::sweep_counters_of(s->d_sort) : nullptr, sw_host, s->stream))
+                return e2vq_set_error("finishing kernel: unsupported configuration");
+            if (e2vq::launch_reduce_records(s->NC, s->d_aos, recplan, incremental, s->d_sc, rows, family ? s->d_fam : nullptr,
+                                            s->stream))
+                return e2vq_set_error("k_reduce_records: unsupported configuration");
+            if (s->timing) {
+                HIPCHK(hipEventRecord(s->ev1, s->stream));
+                s->timed = true;
+                s->timing_pending = true;
+            }
+            e2vq::launch_pass_fallback(s->NC, true, s->d_blk, s->d_cbm, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
+                                       (double*)device_dmin, rows, s->d_fblist, e2vq::prefilter_fallback_count(d_ps), s->d_prev_sym,
+                                       incr, s->stream);
+            if (family) e2vq::launch_family_fixup(rows, s->d_fam, s->fam_M, s->NC, s->stream);
         } else {
         if (e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, d_cimg, d_ps,
                                           s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
@@ -1334,6 +1423,13 @@ static int pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_fai
     if (s->rec_pending) {  // (stored by the reduce kernel, which ran ahead of the statistics kernel on the same queue)
         s->rec_last_total = s->h_stats->rec_total;
         s->rec_pending = false;
+    }
+    if (s->sw_pending) {  // (stored by the finishing kernel of a two-stage sweep, likewise ahead on the queue)
+        const u64 fl = s->h_stats->sw_flagged, jobs = s->h_stats->sw_jobs;
+        s->sw_pending = false;
+        s->last_flagged_frac = jobs ? (double)fl / (double)jobs : -1.0;
+        // most tiles flagged: the coarse stage is wasted on this data -- one stage for the rest of this level and the next
+        if (jobs && s->last_flagged_frac > s->two_stage_max_frac) s->two_stage_off_until_M = 2 * s->M;
     }
     i64 l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int slot = 0; slot < 64; ++slot)

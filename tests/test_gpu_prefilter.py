@@ -257,6 +257,7 @@ def test_few_records_switch_the_level_to_the_burst(oracle, monkeypatch, few_div,
     disabled (0): the two accumulates follow each other within a level and the rows equal the oracle's every pass."""
     monkeypatch.setenv("ECOZ2_VQ_RECORDS_FEW_DIV", few_div)
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
+    monkeypatch.setenv("ECOZ2_VQ_SPLIT_SWEEP", "0")  # (round 4's fused kernel: the split pass of round 5 records throughout)
     M = 256
     frames = _frames(20311, 9000)
     refl = np.concatenate([_codebook(oracle, frames, M // 2, seed=11)] * 2, axis=0)
