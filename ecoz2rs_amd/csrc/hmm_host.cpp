@@ -824,6 +824,15 @@ extern "C" int ecoz2_hmm_classify_predictors(const char* const* model_filenames,
     const int workers = std::min(env_workers(), std::max(1, (int)units.size()));
     const int NC = P + 1;
     if (run_workers(workers, [&](int w) -> int {
+            // (any way out of this worker but the last line stops the others at their next unit)
+            struct FailGuard {
+                std::atomic<bool>& f;
+                bool ok = false;
+                ~FailGuard()
+                {
+                    if (!ok) f.store(true);
+                }
+            } fail_guard{failed};
             const int dev = workers == 1 ? device : device_of_worker(w);
             if (require_device(dev)) return 1;
             Stream st;
@@ -867,13 +876,15 @@ extern "C" int ecoz2_hmm_classify_predictors(const char* const* model_filenames,
             } slots[2];
             const size_t res_cap = (size_t)max_files * num_models;
             const size_t sym_cap = (size_t)std::max<i64>(CHUNK, max_T) + 64;
+            // (the staging slots hold a unit's frames: never more than the whole corpus has)
+            const i64 STAGE = std::max<i64>(64, std::min<i64>(CHUNK, offs[(size_t)S]));
             for (Slot& q : slots) {
-                HIPCHK(hipHostMalloc((void**)&q.h_frames, (size_t)CHUNK * NC * 8, hipHostMallocDefault));
+                HIPCHK(hipHostMalloc((void**)&q.h_frames, (size_t)STAGE * NC * 8, hipHostMallocDefault));
                 HIPCHK(hipHostMalloc((void**)&q.h_offs, (size_t)(max_files + 1) * 8, hipHostMallocDefault));
                 HIPCHK(hipHostMalloc((void**)&q.h_mant, res_cap * 8, hipHostMallocDefault));
                 HIPCHK(hipHostMalloc((void**)&q.h_exp, res_cap * 8, hipHostMallocDefault));
                 HIPCHK(hipHostMalloc((void**)&q.h_st, res_cap * 4, hipHostMallocDefault));
-                if (q.d_frames.alloc((size_t)CHUNK * NC) || q.d_sym.alloc(sym_cap) || q.d_offs.alloc((size_t)max_files + 1) ||
+                if (q.d_frames.alloc((size_t)STAGE * NC) || q.d_sym.alloc(sym_cap) || q.d_offs.alloc((size_t)max_files + 1) ||
                     q.d_mant.alloc(res_cap) || q.d_exp.alloc(res_cap) || q.d_st.alloc(res_cap))
                     return 1;
                 HIPCHK(hipEventCreateWithFlags(&q.done, hipEventDisableTiming));
@@ -969,11 +980,10 @@ extern "C" int ecoz2_hmm_classify_predictors(const char* const* model_filenames,
             for (int k = 0; k < 2; ++k)
                 if (harvest(slots[(turn + k) & 1])) return 1;
             HIPCHK(hipStreamSynchronize(st.s));
+            fail_guard.ok = !failed.load();
             return 0;
-        })) {
-        failed.store(true);
+        }))
         return 1;
-    }
     return classify_report(models, files, classes, lp, models[0].M, show_ranked != 0, classification_filename);
 }
 

@@ -26,6 +26,7 @@
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -249,6 +250,7 @@ struct e2vq_session {
     void* ar_user = nullptr;
     int rank = 0, world = 1;
     bool ar_force = false;  // call the hook even for one rank (a 1-rank RCCL group: exercises the plumbing on one GPU)
+    const volatile bool* group_failed = nullptr;  // in-process group: its failed flag (the statistics spin looks at it)
     // e2vq_enable_collective_timing: HIP events on the session's stream around every call of the hook
     bool ar_timing = false;
     struct ArTimed { hipEvent_t a, b; };
@@ -1252,8 +1254,20 @@ extern "C" int e2vq_last_pass_kernel_ms(e2vq_session* s, float* ms)
 // when a flag never arrived becomes an error here.
 static int spin_for_sequence(e2vq_session* s, volatile u64* word, const char* what)
 {
+    // No wall-clock limit by default (the wait also covers the sweep queued ahead, which may legitimately take minutes);
+    // ECOZ2_VQ_STATS_TIMEOUT_S sets one -- for hosts whose all-reduce hook can leave a collective pending for ever (a peer
+    // process that died).  A rank of an in-process group also gives up as soon as the group has failed.
+    static const double limit_s = getenv("ECOZ2_VQ_STATS_TIMEOUT_S") ? atof(getenv("ECOZ2_VQ_STATS_TIMEOUT_S")) : 0.0;
+    const auto t_start = std::chrono::steady_clock::now();
+    bool slow = false;  // after a few milliseconds: sleep between polls instead of burning a core
     for (unsigned long spins = 0; *word != s->stats_seq; ++spins) {
-        if ((spins & 0xfff) == 0xfff) {
+        if (slow) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if ((spins & 0xfff) == 0xfff || slow) {
+            if (s->group_failed && *s->group_failed) return e2vq_set_error("%s: another rank of the in-process group failed", what);
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+            slow = waited > 5e-3;
+            if (limit_s > 0.0 && waited > limit_s)
+                return e2vq_set_error("%s: no statistics after %.1f s (ECOZ2_VQ_STATS_TIMEOUT_S)", what, waited);
             // (the safety net: the stream has drained and the number never came.  A stream query, not an event recorded
             // behind the kernel: the event's marker packet sat between the update and the next kernel of the stream and
             // cost ~5 us of idle GPU per pass)
@@ -1977,23 +1991,26 @@ Rccl* rccl_api()
     return r.handle ? &r : nullptr;
 }
 
+struct RcclComms;
 struct RcclRank {
     LocalGroup* g;
-    void* comm;
+    RcclComms* comms;
     int rank, device;
     long calls = 0, bytes = 0;
 };
 
-// the communicators of an in-process group; abort() is the group's on_fail hook
+// the communicators of an in-process group; abort() is the group's on_fail hook.  A rank enqueues its collective under the
+// shared lock and takes its communicator from here, not from a cached pointer: abort_all (exclusive) cannot free a
+// communicator another rank's thread is about to hand to ncclAllReduce.
 struct RcclComms {
     std::vector<void*> comms;
-    std::mutex mu;
+    std::shared_mutex mu;
     bool aborted = false;
     static void abort_all(void* self_)
     {
         RcclComms* self = (RcclComms*)self_;
         Rccl* api = rccl_api();
-        std::lock_guard<std::mutex> lk(self->mu);
+        std::unique_lock<std::shared_mutex> lk(self->mu);
         if (self->aborted || !api || !api->comm_abort) return;
         self->aborted = true;  // (ncclCommAbort releases the communicator: no ncclCommDestroy afterwards)
         for (void*& c : self->comms)
@@ -2019,8 +2036,14 @@ int rccl_allreduce(void* user, void* buf, int64_t count, int op, void* stream_)
     // leave the others with a collective that never completes -- blocked in the next stream synchronisation for good.
     if (!rr->g->barrier()) return e2vq_set_error("in-process group: another rank failed");
     (void)hipGetLastError();  // (see ncclCommInitAll below: hipErrorNotReady of a polled event must not reach RCCL)
-    const int rc = api->all_reduce(buf, buf, (size_t)count, op == 0 ? Rccl::Int64 : Rccl::Uint64, op == 0 ? Rccl::Sum : Rccl::Max,
-                                   rr->comm, (hipStream_t)stream_);
+    int rc;
+    {
+        std::shared_lock<std::shared_mutex> lk(rr->comms->mu);
+        void* comm = rr->comms->aborted ? nullptr : rr->comms->comms[(size_t)rr->rank];
+        if (!comm) return e2vq_set_error("in-process group: another rank failed (communicators aborted)");
+        rc = api->all_reduce(buf, buf, (size_t)count, op == 0 ? Rccl::Int64 : Rccl::Uint64, op == 0 ? Rccl::Sum : Rccl::Max, comm,
+                             (hipStream_t)stream_);
+    }
     if (rc != 0) {
         e2vq_set_error("ncclAllReduce failed: %s", api->error_string ? api->error_string(rc) : "?");
         rr->g->fail();
@@ -2051,8 +2074,11 @@ struct GroupImpl {
         for (hipEvent_t ev : g.ev_done)
             if (ev) (void)hipEventDestroy(ev);
         if (g.failed) RcclComms::abort_all(&rc_comms);  // (a failed group may hold a collective that cannot complete)
-        std::lock_guard<std::mutex> lk(rc_comms.mu);
-        if (Rccl* api = rc_comms.comms.empty() ? nullptr : rccl_api())
+        std::unique_lock<std::shared_mutex> lk(rc_comms.mu);
+        Rccl* api = rc_comms.comms.empty() ? nullptr : rccl_api();
+        // (a failed group on an RCCL without ncclCommAbort: ncclCommDestroy could block on that collective for good --
+        // the communicators are leaked instead)
+        if (api && !(g.failed && !api->comm_abort))
             for (void* c : rc_comms.comms)
                 if (c) (void)api->comm_destroy(c);
     }
@@ -2143,7 +2169,7 @@ GroupImpl* group_create(int world, const int* devices, const std::string& coll, 
         G->g.on_fail = RcclComms::abort_all;
         G->g.on_fail_arg = &G->rc_comms;
         G->rranks.resize((size_t)world);
-        for (int r = 0; r < world; ++r) G->rranks[(size_t)r] = RcclRank{&G->g, G->rc_comms.comms[(size_t)r], r, devices[r]};
+        for (int r = 0; r < world; ++r) G->rranks[(size_t)r] = RcclRank{&G->g, &G->rc_comms, r, devices[r]};
     } else {
         char buf[160];
         snprintf(buf, sizeof buf, "peer-to-peer reduce-scatter + all-gather kernel (int64 sum) per LBG iteration over %d rank(s)", world);
@@ -2227,6 +2253,7 @@ extern "C" int e2vq_group_bind(e2vq_group* g, int rank, e2vq_session* s)
     group_hook(g->impl, rank, &fn, &user, &force);
     if (e2vq_set_allreduce(s, fn, user, rank, g->impl->world)) return 1;
     s->ar_force = force;
+    s->group_failed = &g->impl->g.failed;
     return 0;
 }
 
@@ -2773,6 +2800,18 @@ extern "C" int ecoz2_vq_quantize(const char* nom_raas, const char* const* predic
     const int dev0 = env_int("ECOZ2_VQ_DEVICE", 0);
     const char* root = env_str("ECOZ2_VQ_OUT_ROOT", ".");
     QShared sh(num_predictors);
+    // split files are written to <seq>.tmp and renamed at the end: whatever way this call ends short of that, the .tmp files
+    // it has created so far go away (a later file's bad header, a failed worker, a failed rename)
+    struct TmpGuard {
+        QShared& sh;
+        bool keep = false;
+        ~TmpGuard()
+        {
+            if (!keep)
+                for (const QFileResult& r : sh.results)
+                    if (!r.tmp_path.empty()) (void)remove(r.tmp_path.c_str());
+        }
+    } tmp_guard{sh};
     sh.files = predictor_filenames;
     sh.P = P;
     sh.M = M;
@@ -2807,11 +2846,7 @@ extern "C" int ecoz2_vq_quantize(const char* nom_raas, const char* const* predic
                 // (not at the final path: a run that fails later must not leave a well-formed .seq of zeros behind, nor
                 // overwrite an earlier good one)
                 r.tmp_path = r.seq_path + ".tmp";
-                if (e2vq_io::seq_create(r.tmp_path.c_str(), cls, M, T)) {
-                    for (const QFileResult& o : sh.results)
-                        if (!o.tmp_path.empty()) (void)remove(o.tmp_path.c_str());
-                    return 1;
-                }
+                if (e2vq_io::seq_create(r.tmp_path.c_str(), cls, M, T)) return 1;
                 for (i64 t0 = 0; t0 < T; t0 += sh.chunk) {
                     const i64 n = std::min<i64>(sh.chunk, T - t0);
                     cur.segs.push_back(QSegment{i, t0, n, 0, false});
@@ -2844,13 +2879,15 @@ extern "C" int ecoz2_vq_quantize(const char* nom_raas, const char* const* predic
     for (int w = 0; w < W; ++w)
         if (rcs[(size_t)w]) {
             if (w > 0) snprintf(g_err, sizeof g_err, "%s", errs[(size_t)w].c_str());
-            for (const QFileResult& r : sh.results)
-                if (!r.tmp_path.empty()) (void)remove(r.tmp_path.c_str());
             return rcs[(size_t)w];
         }
-    for (const QFileResult& r : sh.results)
-        if (!r.tmp_path.empty() && rename(r.tmp_path.c_str(), r.seq_path.c_str()) != 0)
-            return e2vq_set_error("%s: cannot move the finished sequence into place: %s", r.seq_path.c_str(), strerror(errno));
+    for (QFileResult& r : sh.results)
+        if (!r.tmp_path.empty()) {
+            if (rename(r.tmp_path.c_str(), r.seq_path.c_str()) != 0)
+                return e2vq_set_error("%s: cannot move the finished sequence into place: %s", r.seq_path.c_str(), strerror(errno));
+            r.tmp_path.clear();  // (in place: no longer the guard's business)
+        }
+    tmp_guard.keep = true;
     double total_e = 0.0;
     i64 total_T = 0;
     for (int i = 0; i < num_predictors; ++i) {

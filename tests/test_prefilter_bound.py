@@ -100,6 +100,60 @@ def test_limb_prefilter_bound_and_certification(oracle, kind):
     assert cert.mean() > (0.5 if kind != "twins" else 0.2)  # the prefilter certifies most ordinary frames
 
 
+@pytest.mark.parametrize("kind", ["plain", "rescaled", "twins", "codebook_scales"])
+def test_two_stage_coarse_bound_and_skip_rule(oracle, kind):
+    """Round 5 (vq_sweep.hip): stage 1 of the candidate sweep computes v2 = 512 W0 + W1 only.  Checked here:
+      * |2^27 sum xi eta - v2| <= 257 (g + ymax) + 129 NC + 2 + 2^-23 |v2|          (the bound in the kernel's header)
+      * the skip rule: with U = ANY coarse key already seen for the frame (here: the worst choice allowed, a random
+        codeword's, then the running minimum in sweep order), a codeword whose coarse key exceeds
+        U (1 + 2^-20) + 2.54 E2 is never the nearest -- so the nearest codeword is always among those not skipped."""
+    rng = np.random.default_rng(11)
+    T, M = 1500, 256
+    frames = e.synth.synth_frames(20270, 6, P, 0, T)
+    if kind == "rescaled":
+        frames = frames * 10.0 ** rng.integers(-9, 9, size=T)[:, None]
+    refl = _codebook(oracle, e.synth.synth_frames(20271, 5, P, 0, M))
+    if kind == "twins":
+        refl = oracle.grow(refl[: M // 2])
+    cq = oracle.reflections_to_cq(refl)
+    ea = (-(_ilogb(np.abs(cq).max(axis=0)) + 1) if kind == "codebook_scales" else _ilogb(np.abs(frames).max(axis=0)) + 1).astype(np.int64)
+    nz = frames != 0.0
+    eA = np.where(nz, _ilogb(np.where(nz, frames, 1.0)) - ea[None, :] + 1, -100000).max(axis=1)
+    xi = np.ldexp(frames, (-ea[None, :] - eA[:, None]).astype(np.int64))
+    eC = (_ilogb(np.where(cq != 0, cq, 1.0)) + ea[None, :] + 1)[cq != 0].max()
+    eta = np.ldexp(cq, (ea[None, :] - eC).astype(np.int64))
+    X, Y = _split(xi), _split(eta)
+    W0 = X[0] @ Y[0].T
+    W1 = X[0] @ Y[1].T + X[1] @ Y[0].T
+    v2 = (W0 * 512.0 + W1).astype(np.float32).astype(np.float64)  # (one rounding: the fma)
+    g = (np.abs(xi).sum(axis=1) * 1.000001).astype(np.float32).astype(np.float64)
+    ymax = float(np.float32(np.abs(eta).sum(axis=1).max() * 1.000001))
+    exact = (xi @ eta.T) * 2.0 ** 27
+    E2 = 257.0 * (g + ymax) + 129.0 * NC + 2.0
+    assert (np.abs(exact - v2) <= E2[:, None] + 2.0 ** -23 * np.abs(v2)).all(), "the two-limb bound does not hold"
+    d = frames @ cq.T
+    best = d.argmin(axis=1)
+    D = 2.54 * E2
+    # (a) U from an arbitrary codeword
+    pick = rng.integers(0, M, size=T)
+    U = v2[np.arange(T), pick]
+    thr = np.where(U > 0, U * 1.000001 + D, np.inf)
+    kept = ~(v2 > thr[:, None])
+    assert kept[np.arange(T), best].all(), "the nearest codeword was skipped (fixed U)"
+    # (b) the running minimum over 16-value groups in sweep order, as a lane keeps it
+    Urun = np.full(T, np.inf)
+    thr = np.full(T, np.inf)
+    kept = np.zeros((T, M), dtype=bool)
+    for c0 in range(0, M, 16):
+        m = v2[:, c0:c0 + 16].min(axis=1)
+        kept[:, c0:c0 + 16] = (~(m > thr))[:, None]
+        Urun = np.minimum(Urun, m)
+        thr = np.where(Urun > 0, Urun * 1.000001 + D, np.inf)
+    assert kept[np.arange(T), best].all(), "the nearest codeword was skipped (running U)"
+    if kind == "plain":  # the rule has to be worth something on ordinary data
+        assert kept.mean() < 0.9
+
+
 def _pack(NC, NL=3):
     """PrePack<NC> of vq_prefilter.hip restated: (pairs, steps, step -> (level, pair), slot(pair, h, e) -> (limb, n))"""
     G, R = NC // 16, NC % 16
