@@ -1070,7 +1070,6 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         } else if (records && s->sweep2_enabled && s->d_fimgF && e2vq::sweep_supported(s->NC, s->M)) {
             // round 5: [sort] -> candidate sweep -> finishing kernel (exact evaluation, outputs, records) -> reduce
             const int incr = family ? 2 : (incremental ? 1 : 0);
-            s->n_pre_launches--;  // (counted below, behind the sort)
             if (incr != 0 && (incr == 2 || s->perm_M != s->M)) {
                 if (e2vq::launch_sort_by_cell(s->d_prev_sym, s->T, s->nblocks, incr == 2 ? s->M / 2 : s->M, s->d_sort, s->d_perm,
                                               s->stream))
@@ -1078,9 +1077,9 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
                 s->perm_M = s->M;
             }
             const bool sorted = incr != 0 && s->perm_M == s->M;
-            const bool two = sorted && s->two_stage_enabled && s->M > s->two_stage_off_until_M;
+            // (two stages need tiles to skip: from eight tiles on; below, the home tile alone is a quarter or half of the codebook)
+            const bool two = sorted && s->two_stage_enabled && s->M >= 256 && s->M > s->two_stage_off_until_M;
             if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));  // (again: the sweep kernel alone is what ev0..ev_mid brackets)
-            s->n_pre_launches++;
             if (e2vq::launch_sweep_candidates(s->NC, two, s->d_fimgF, sorted ? s->d_perm : nullptr, s->T, s->nblocks, d_cimg, d_ps, s->M,
                                               sorted ? s->d_prev_sym : nullptr, sorted ? incr : 0, s->d_cand,
                                               two ? e2vq::sweep_counters_of(s->d_sort) : nullptr, s->stream))
@@ -1442,8 +1441,9 @@ static int pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_fai
         const u64 fl = s->h_stats->sw_flagged, jobs = s->h_stats->sw_jobs;
         s->sw_pending = false;
         s->last_flagged_frac = jobs ? (double)fl / (double)jobs : -1.0;
-        // most tiles flagged: the coarse stage is wasted on this data -- one stage for the rest of this level and the next
-        if (jobs && s->last_flagged_frac > s->two_stage_max_frac) s->two_stage_off_until_M = 2 * s->M;
+        // most tiles flagged: the coarse stage is wasted on this data -- one stage for the rest of this level (the next level's
+        // first pass tries again: finer cells, more tiles)
+        if (jobs && s->last_flagged_frac > s->two_stage_max_frac) s->two_stage_off_until_M = s->M;
     }
     i64 l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int slot = 0; slot < 64; ++slot)
@@ -1858,24 +1858,42 @@ struct LocalGroup {
     std::condition_variable cv;
     int arrived = 0;
     long generation = 0;
-    bool failed = false;
+    volatile bool failed = false;
     // exchange state: every rank publishes its buffer and records its events, then waits on the others'
     e2vq::PeerBuffers bufs{};
     std::vector<hipEvent_t> ev_ready, ev_done;
 
-    // reusable barrier; returns false if the group has failed
+    // Reusable barrier; returns false if the group has failed.  The ranks of a group run in lock step -- every collective is
+    // a rendezvous of host threads that arrive within microseconds of each other -- so a rank first SPINS on the generation
+    // counter (round 5: a condition-variable wake-up cost each of the two rendezvous of an exchange 20-50 us, most of what
+    // the exchange took at the small levels) and only blocks when the others are far behind (~50 us).
+    std::atomic<long> gen_spin{0};
     bool barrier()
     {
-        std::unique_lock<std::mutex> lk(mu);
-        if (failed) return false;
-        const long gen = generation;
-        if (++arrived == n) {
-            arrived = 0;
-            ++generation;
-            cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return generation != gen || failed; });
+        long gen;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            if (failed) return false;
+            gen = generation;
+            if (++arrived == n) {
+                arrived = 0;
+                ++generation;
+                gen_spin.store(generation, std::memory_order_release);
+                cv.notify_all();
+                return true;
+            }
         }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (gen_spin.load(std::memory_order_acquire) != gen) return !failed;
+            if (failed) return false;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+            if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(50)) break;
+        }
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return generation != gen || failed; });
         return !failed;
     }
     // first failing rank's message (g_err is thread-local: the workers' text would be lost with their threads)

@@ -1977,8 +1977,10 @@ bool prefilter_records_plan(int NC, int M, bool family, long nblocks, PassRecord
         if ((int)(((unsigned)c * magic) >> 22) != c / bc) return false;
     const int waves = pre_lds_waves(NC);  // waves per sweeping workgroup
     const int grid = pre_grid(nblocks, waves, 256);
-    const long blocks_per_wave = (nblocks + (long)grid * waves - 1) / ((long)grid * waves);
-    const long cap = 2 * waves * blocks_per_wave * 64;  // every frame of the workgroup twice in one bin: '+' and '-'
+    // every frame of a recording workgroup twice in one bin ('+' and '-'); a workgroup of w <= 16 waves that deals blocks (or
+    // half blocks) out wave by wave covers at most nblocks / grid + w blocks
+    (void)waves;
+    const long cap = 2 * 64 * ((nblocks + grid - 1) / grid + 16);
     if (cap >= (1L << 30)) return false;
     plan->grid = grid;
     plan->nbins = nb_rows + nb_fam;

@@ -228,6 +228,35 @@ __device__ __forceinline__ float sweep_coarse_job(const h8 (&A)[PrePack<NC>::NU]
     return m;
 }
 
+// ... software-pipelined: the NSTEP_C MFMAs of this job interleaved 1 : 4 with the epilogue of the PREVIOUS job (its 16 key
+// fmas and the minimum tree), so that a wave keeps issuing to the matrix pipe while it digests the last job's values -- run
+// one after the other (round 5, first version) a wave spent ~975 cycles per job where the pipe needs 256
+template <int NC>
+__device__ __forceinline__ float sweep_coarse_job_pinned(f16v (&ACC)[2], const h8 (&A)[PrePack<NC>::NU],
+                                                         const h8 (&BC)[PrePack<NC>::PAIRS], const f16v (&PREV)[2])
+{
+    typedef PrePack<NC> PK;
+    const f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < SweepImg<NC>::NSTEP_C; ++s) {
+        const int lv = PK::step_level(s);
+        ACC[lv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[PK::step_unique(s)], BC[PK::step_pair(s)],
+                                                         s == PK::level_first(lv) ? zero : ACC[lv], 0, 0, 0);
+    }
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = __builtin_fmaf(PREV[0][r], 512.f, PREV[1][r]);
+    float m = __builtin_fminf(v[0], v[1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) m = __builtin_fminf(m, __builtin_fminf(v[r], v[r + 1]));  // (v_min3_f32)
+#pragma unroll
+    for (int s = 0; s < SweepImg<NC>::NSTEP_C; ++s) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    }
+    return m;
+}
+
 template <int NC>
 __device__ __forceinline__ void sweep_full_job(const h8 (&A)[PrePack<NC>::NU], const h8 (&BC)[PrePack<NC>::PAIRS], int tile,
                                                float& k1, float& k2, float& k3, int maskv, float ninf)
@@ -243,6 +272,24 @@ __device__ __forceinline__ void sweep_full_job(const h8 (&A)[PrePack<NC>::NU], c
     }
     pre_epilogue<NC>(acc, tile, k1, k2, k3, maskv, ninf);
 }
+
+// ---- diagnostics (-DE2VQ_SWEEP_STAMP, tools/probe/sweep_stamps.py): where a sweeping wave's cycles go, phase by phase --------
+// s_memtime deltas summed per wave, added to a global table at the end; -DE2VQ_SWEEP_STAMP=1 also drains the vector-memory
+// counter at the phase ends so that a phase pays for the loads it waits on.  Never defined in the product build.
+#ifdef E2VQ_SWEEP_STAMP
+__device__ unsigned long long g_sweep_stamps[16];
+#define SW_STAMP_DECL unsigned long long sw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sw_t = __builtin_amdgcn_s_memtime(), sw_n = 0;
+#define SW_STAMP(i)                                                                          \
+    {                                                                                        \
+        if (E2VQ_SWEEP_STAMP == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+        const unsigned long long sw_now = __builtin_amdgcn_s_memtime();                     \
+        sw_acc[i] += sw_now - sw_t;                                                          \
+        sw_t = sw_now;                                                                       \
+    }
+#else
+#define SW_STAMP_DECL
+#define SW_STAMP(i)
+#endif
 
 struct SweepCounters {
     unsigned long long flagged;  // (tile, column block) jobs that ran stage 2
@@ -272,67 +319,125 @@ __global__ __launch_bounds__(512, 2) void k_sweep_cand(const unsigned char* __re
     const float pinf = __builtin_inff();
     const int col = lane & 31, h = lane >> 5;
     unsigned long long nflag = 0, njobs = 0;
+    SW_STAMP_DECL
 
-    for (long b = wave; b < nblocks; b += nwaves) {
-        // the block's slots -> frames; lane (h, col) holds lane half h of the granules of slots col and 32 + col
-        long s0 = b * 64 + col, s1 = s0 + 32;
+    // the block's slots -> frames; lane (h, col) holds lane half h of the granules of slots col and 32 + col.  Loop-carried:
+    // the frames, the home tile and the B operands of a block are requested while the block before it is still at work
+    // (three dependent global latencies -- list, home cell, granules -- would otherwise open every block)
+    auto slot_frames = [&](long blk, unsigned& fa, unsigned& fb) {
+        long s0 = blk * 64 + col, s1 = s0 + 32;
         s0 = s0 < T ? s0 : T - 1;
         s1 = s1 < T ? s1 : T - 1;
-        const unsigned f0 = perm ? perm[s0] : (unsigned)s0, f1 = perm ? perm[s1] : (unsigned)s1;
-        const unsigned char* p0 = fimg + (size_t)f0 * FS;
-        const unsigned char* p1 = fimg + (size_t)f1 * FS;
-        h8 B[2][PK::PAIRS];
+        fa = perm ? perm[s0] : (unsigned)s0;
+        fb = perm ? perm[s1] : (unsigned)s1;
+    };
+    auto home_of = [&](unsigned fa) {
+        int hm = 0;
+        if (TWO && home_mul) {
+            const unsigned fh = (unsigned)__builtin_amdgcn_readfirstlane((int)fa);
+            hm = (home_mul * (int)prev_sym[fh]) >> 5;
+            hm = __builtin_amdgcn_readfirstlane(hm < MT ? hm : MT - 1);
+        }
+        return hm;
+    };
+    h8 B[2][PK::PAIRS];
+    float g0 = 0.f, g1 = 0.f;
+    auto load_B = [&](unsigned fa, unsigned fb) {
+        const unsigned char* p0 = fimg + (size_t)fa * FS;
+        const unsigned char* p1 = fimg + (size_t)fb * FS;
 #pragma unroll
         for (int p = 0; p < PK::PAIRS; ++p) {
             B[0][p] = *(const h8*)(p0 + p * 32 + h * 16);
             B[1][p] = *(const h8*)(p1 + p * 32 + h * 16);
         }
-        const float g0 = *(const float*)(p0 + PK::PAIRS * 32), g1 = *(const float*)(p1 + PK::PAIRS * 32);
+        g0 = *(const float*)(p0 + PK::PAIRS * 32);
+        g1 = *(const float*)(p1 + PK::PAIRS * 32);
+    };
+    unsigned f0n = 0, f1n = 0;
+    int home_n = 0;
+    if (wave < nblocks) {
+        slot_frames(wave, f0n, f1n);
+        home_n = home_of(f0n);
+        load_B(f0n, f1n);
+    }
+    for (long b = wave; b < nblocks; b += nwaves) {
+        const unsigned f0 = f0n, f1 = f1n;
+        const int home = home_n;
+        const float gc0 = g0, gc1 = g1;
+        const long bn = b + nwaves < nblocks ? b + nwaves : b;  // (the wave's last block asks for itself again: no load is conditional)
+        SW_STAMP(0)  // the block's B operands (requested behind the previous block's stage 2) are there
+        slot_frames(bn, f0n, f1n);
         float k1[2], k2[2], k3[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) k1[cb] = k2[cb] = k3[cb] = __int_as_float(0x7f7fffff);
 
         if constexpr (TWO) {
             // ---- stage 1: every tile, weight levels 0 and 1; tiles in cyclic order from the block's home tile ---------------
-            int home = 0;
-            if (home_mul) {
-                const unsigned fh = (unsigned)__builtin_amdgcn_readfirstlane((int)f0);
-                home = (home_mul * (int)prev_sym[fh]) >> 5;
-                home = __builtin_amdgcn_readfirstlane(home < MT ? home : MT - 1);
-            }
             // 2 x 1.27 x E2 of the lane's two frames (coarse-key units; header)
-            const float D0 = 2.54f * (257.f * (g0 + ymax1) + (129.f * NC + 2.f));
-            const float D1 = 2.54f * (257.f * (g1 + ymax1) + (129.f * NC + 2.f));
+            const float D0 = 2.54f * (257.f * (gc0 + ymax1) + (129.f * NC + 2.f));
+            const float D1 = 2.54f * (257.f * (gc1 + ymax1) + (129.f * NC + 2.f));
             float U0 = pinf, U1 = pinf, thr0 = pinf, thr1 = pinf;
             int ntl = 0;
-            h8 Acur[NU], Anext[NU];
-            sweep_load_tile<NC>(Acur, cimg, home, lane, true);
-#pragma unroll 2
-            for (int i = 0; i < MT; ++i) {
-                const int tile = home + i < MT ? home + i : home + i - MT;
-                int tn = tile + 1 < MT ? tile + 1 : 0;
-                tn = i + 1 < MT ? tn : tile;  // (the last iteration reloads its own tile: no load is conditional)
-                sweep_load_tile<NC>(Anext, cimg, tn, lane, true);
-                const float m0 = sweep_coarse_job<NC>(Acur, B[0]);
-                const float m1 = sweep_coarse_job<NC>(Acur, B[1]);
-                // (negated comparisons: a NaN key flags its tile)
-                const bool fl0 = !(m0 > thr0), fl1 = !(m1 > thr1);
-                U0 = __builtin_fminf(U0, m0);
+            // Four register sets of coarse granules, three tiles requested ahead: a tile's MFMAs take ~0.3 us, its operands
+            // ~1 us to arrive from L2 -- with one tile of distance the loop ran at the latency, not at the matrix pipe.
+            auto tile_at = [&](int i) {
+                i = i < MT ? i : MT - 1;
+                return home + i < MT ? home + i : home + i - MT;
+            };
+            h8 A[4][NU];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sweep_load_tile<NC>(A[k], cimg, tile_at(k), lane, true);
+            // accumulators of the two column blocks; each job digests the other's previous values: the "previous" values
+            // of the very first job are huge (no flag), and one more epilogue follows the loop
+            f16v acc0[2], acc1[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f, acc1[1][r] = 3.0e38f;
+            unsigned bits_prev = 0u;  // column block 0's flag of the tile whose column block 1 is still being digested
+            int tile_prev = 0;
+            auto digest1 = [&](float m1) {  // column block 1 of tile_prev: flag, U, threshold; the tile's list entry
+                const bool fl1 = !(m1 > thr1);
                 U1 = __builtin_fminf(U1, m1);
-                thr0 = U0 > 0.f ? __builtin_fmaf(U0, 1.000001f, D0) : pinf;
                 thr1 = U1 > 0.f ? __builtin_fmaf(U1, 1.000001f, D1) : pinf;
-                const unsigned bits = (__ballot(fl0) != 0 ? 1u : 0u) | (__ballot(fl1) != 0 ? 2u : 0u);
+                const unsigned bits = bits_prev | (__ballot(fl1) != 0 ? 2u : 0u);
                 if (bits) {  // (wave-uniform; every lane stores the same word)
-                    tlist[ntl] = (unsigned)tile | bits << 16;
+                    tlist[ntl] = (unsigned)tile_prev | bits << 16;
                     ++ntl;
                 }
+            };
+            for (int i0 = 0; i0 < MT; i0 += 4) {
 #pragma unroll
-                for (int u = 0; u < NU; ++u)
-                    if (SweepImg<NC>::coarse_unique(u)) Acur[u] = Anext[u];
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k;
+                    sweep_load_tile<NC>(A[(k + 3) & 3], cimg, tile_at(i + 3), lane, true);
+                    if (i < MT) {  // (wave-uniform)
+                        const int tile = tile_at(i);
+                        const float m1 = sweep_coarse_job_pinned<NC>(acc0, A[k], B[0], acc1);  // (digests tile_prev, column block 1)
+                        if (i > 0) digest1(m1);
+                        const float m0 = sweep_coarse_job_pinned<NC>(acc1, A[k], B[1], acc0);  // (digests this tile, column block 0)
+                        // (negated comparisons: a NaN key flags its tile)
+                        const bool fl0 = !(m0 > thr0);
+                        U0 = __builtin_fminf(U0, m0);
+                        thr0 = U0 > 0.f ? __builtin_fmaf(U0, 1.000001f, D0) : pinf;
+                        bits_prev = __ballot(fl0) != 0 ? 1u : 0u;
+                        tile_prev = tile;
+                    }
+                }
+            }
+            {   // the last job's values
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = __builtin_fmaf(acc1[0][r], 512.f, acc1[1][r]);
+                float m = __builtin_fminf(v[0], v[1]);
+#pragma unroll
+                for (int r = 2; r < 16; r += 2) m = __builtin_fminf(m, __builtin_fminf(v[r], v[r + 1]));
+                digest1(m);
             }
             njobs += 2ull * MT;
+            SW_STAMP(1)  // stage 1
+            home_n = home_of(f0n);  // (the next block's list entries have long arrived)
             // ---- stage 2: the flagged tiles with all their k-steps and the key epilogue ---------------------------------------
             if (ntl > 0) {
+                h8 Acur[NU], Anext[NU];
                 unsigned e = tlist[0];
                 sweep_load_tile<NC>(Acur, cimg, (int)(e & 0xffffu), lane, false);
                 for (int j = 0; j < ntl; ++j) {
@@ -351,7 +456,6 @@ __global__ __launch_bounds__(512, 2) void k_sweep_cand(const unsigned char* __re
             // ---- one stage: every tile with all its k-steps (frames that are not grouped, or data that flags most tiles) ------
             h8 Acur[NU], Anext[NU];
             sweep_load_tile<NC>(Acur, cimg, 0, lane, false);
-#pragma unroll 2
             for (int t = 0; t < MT; ++t) {
                 sweep_load_tile<NC>(Anext, cimg, t + 1 < MT ? t + 1 : t, lane, false);
                 sweep_full_job<NC>(Acur, B[0], t, k1[0], k2[0], k3[0], maskv, ninf);
@@ -361,7 +465,11 @@ __global__ __launch_bounds__(512, 2) void k_sweep_cand(const unsigned char* __re
             }
             njobs += 2ull * MT;
             nflag += 2ull * MT;
+            home_n = 0;
         }
+        SW_STAMP(2)  // stage 2 (or the one-stage loop)
+        // the next block's B operands: their registers are free from here on
+        load_B(f0n, f1n);
 
         // ---- lane = slot b * 64 + lane: merge the two lane halves of its frame's keys, certify the top two ------------------
         const int hb = h << 2;
@@ -378,14 +486,31 @@ __global__ __launch_bounds__(512, 2) void k_sweep_cand(const unsigned char* __re
         const float t3 = med3f(a2, a3, b1), t2 = med3f(a1, a2, b1), t1 = med3f(a1, b1, ninf);
         const float u3 = med3f(t2, t3, b2), u2 = med3f(t1, t2, b2);
         const float w3 = med3f(u2, u3, b3);
-        const float g = h ? g1 : g0;
+        const float g = h ? gc1 : gc0;
         const unsigned f = h ? f1 : f0;
         const float tau = 1.27f * (512.f * (g + ymax1 + (NC + 4.0f)) + relk * t1);
         const bool cert = t1 >= 1.0e-30f && t1 < 1.0e37f && w3 > t1 + tau;
         const bool amb = !(u2 > t1 + tau);
         const unsigned c1 = (unsigned)(__float_as_int(t1) & ~idxmask), c2 = (unsigned)(__float_as_int(u2) & ~idxmask);
         if (b * 64 + lane < T) cand[f] = c1 | c2 << 13 | (amb ? CAND_AMB : 0u) | (cert ? CAND_CERT : 0u);
+#ifdef E2VQ_SWEEP_STAMP
+        {   // (merge, certification, store -- without the drain: the B loads just issued belong to the next block's stamp 0)
+            const unsigned long long sw_now = __builtin_amdgcn_s_memtime();
+            sw_acc[3] += sw_now - sw_t;
+            sw_t = sw_now;
+            sw_n += 1;
+        }
+#endif
     }
+#ifdef E2VQ_SWEEP_STAMP
+    if (lane == 0) {
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_sweep_stamps[k], sw_acc[k]);
+        atomicAdd(&g_sweep_stamps[8], sw_n);
+        atomicAdd(&g_sweep_stamps[9], 1ull);
+        atomicAdd(&g_sweep_stamps[10], nflag);
+        atomicAdd(&g_sweep_stamps[11], njobs);
+    }
+#endif
     if (counters && lane == 0 && njobs) {
         atomicAdd(&counters->flagged, nflag);
         atomicAdd(&counters->jobs, njobs);
@@ -393,12 +518,33 @@ __global__ __launch_bounds__(512, 2) void k_sweep_cand(const unsigned char* __re
 }
 
 // ---- k_finish ---------------------------------------------------------------------------------------------------------------
-// One wave = 64 consecutive frames (their natural order), lane = frame: the block's FP64 rows arrive in the wave's LDS region
-// by LDS-DMA (as in k_pass_pre_lds), the candidates' codeword rows are gathered from L2, the canonical chain
-// acc = fma(r[n], cq[n], acc), n ascending from +0.0, decides; outputs, distortion sums and the records of the frame's
-// contribution follow -- the statements of k_pass_pre_lds<.., 2> behind its certification, unchanged in what they compute.
+// Every frame once, in its natural order; bound by reading the FP64 rows (296 B per frame at P = 36) -- if enough of them are
+// in flight: twelve waves per CU (three per SIMD), each working on HALF blocks of 32 frames whose rows arrive in
+// the wave's LDS region by LDS-DMA (no registers).  Lanes 0..31 = the half block's frames evaluating their first candidate,
+// lanes 32..63 = the same frames' runner-up (only where its key was within reach): the canonical chain
+// acc = fma(r[n], cq[n], acc), n ascending from +0.0, r from the frame's LDS row, cq gathered from L2.
+// A wave's turn: gather the codeword rows (i) -> wait for them and for rows (i), requested a turn ago -> chains (i) -> request
+// rows (i + 1), load candidates (i + 1) -> outputs, distortion sums, records (i).  (Its vector-memory operations retire in
+// order: waiting for the short gathers behind a second buffer's requests would wait for those too -- the other eleven waves
+// of the CU are what keeps rows in flight.)
+// Outputs: symbol / distortion (or the fallback list); the distortion sums per lane, reduced once at the end of the kernel;
+// the frame's contribution to the cell sums as records -- (frame, cell within its bin, sign) into this workgroup's region of
+// the bin, the slot from one LDS atomic per record -- for k_reduce_records: the statements of k_pass_pre_lds<.., 2> behind its
+// certification, unchanged in what they compute.
 template <int NC>
-__global__ __launch_bounds__(512, 2) void k_finish(const double* __restrict__ aos, long T, long nblocks,
+struct FinLds {
+    static constexpr int HALF_BYTES = 32 * NC * 8;
+    static constexpr int K16 = HALF_BYTES / 1024, K4 = (HALF_BYTES - K16 * 1024) / 256;
+    static_assert(K16 * 1024 + K4 * 256 == HALF_BYTES, "a half block of frames is a whole number of 256-byte pieces");
+    static constexpr int WAVE_BYTES = HALF_BYTES + 256;  // + the cells of the previous pass (32 u16, fetched as 64 dwords)
+    // twelve waves per workgroup = three per SIMD: the codeword row of a lane is 2 * NH registers, and 128 of them do not
+    // hold the chains (the records' plan allows for any wave count up to sixteen: prefilter_records_plan)
+    static constexpr int WAVES = 12;
+    static_assert(WAVES * WAVE_BYTES + 512 <= E2VQ_LDS_BYTES || !PreLds<NC>::OK, "twelve half-block regions fit");
+};
+
+template <int NC>
+__global__ __launch_bounds__(FinLds<NC>::WAVES * 64) void k_finish(const double* __restrict__ aos, long T, long nblocks,
                                                    const unsigned* __restrict__ cand, PreScalars* __restrict__ ps,
                                                    const double* __restrict__ cbq, int MT, const DevScalars* __restrict__ sc,
                                                    const u64* __restrict__ l1max_bits, unsigned short* __restrict__ sym,
@@ -406,7 +552,9 @@ __global__ __launch_bounds__(512, 2) void k_finish(const double* __restrict__ ao
                                                    unsigned short* __restrict__ prev_sym, int incr, PreRec rec,
                                                    SweepCounters* __restrict__ counters, unsigned long long* host_counters)
 {
-    typedef PreLds<NC> PL;
+    typedef FinLds<NC> FL;
+    constexpr int W = FL::WAVES;
+    constexpr int RS = (2 * NC + 5 + 7) & ~7, NPAD = (NC + 7) & ~7, NH = (NC + 1) / 2;
     // the two-stage sweep in front of this kernel left its counters: to the host (it adapts), and zero for the next sweep
     if (counters && host_counters && blockIdx.x == 0 && threadIdx.x == 0) {
         __hip_atomic_store(host_counters, counters->flagged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -414,16 +562,14 @@ __global__ __launch_bounds__(512, 2) void k_finish(const double* __restrict__ ao
         counters->flagged = 0;
         counters->jobs = 0;
     }
-    constexpr int TPBM = PL::WAVES * 64;
-    constexpr int RS = (2 * NC + 5 + 7) & ~7, NPAD = (NC + 7) & ~7;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int ln = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long wave = (long)blockIdx.x * (TPBM >> 6) + wib;
-    const long nwaves = (long)gridDim.x * (TPBM >> 6);
-    unsigned char* wbase = smem + (size_t)wib * PL::WAVE_BYTES;
-    const double* stage = (const double*)wbase;
-    const unsigned short* prevs = (const unsigned short*)(wbase + PL::STAGE_BYTES + 256);
-    int* const rcnt = (int*)(smem + (size_t)PL::WAVES * PL::WAVE_BYTES);
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long wave = (long)blockIdx.x * W + wib;
+    const long nwaves = (long)gridDim.x * W;
+    const long nhalf = (T + 31) / 32;
+    (void)nblocks;
+    unsigned char* wbase = smem + (size_t)wib * FL::WAVE_BYTES;
+    int* const rcnt = (int*)(smem + (size_t)W * FL::WAVE_BYTES);
     if (threadIdx.x < 64) rcnt[threadIdx.x] = 0;
     __syncthreads();
     const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
@@ -431,78 +577,109 @@ __global__ __launch_bounds__(512, 2) void k_finish(const double* __restrict__ ao
     auto pow2 = [](int e) { return __longlong_as_double((long long)(1023 + e) << 52); };  // |e| <= 1000
     const bool fast_d = sh_d >= -1000 && sh_d <= 1000 && sh_d2 >= -1000 && sh_d2 <= 1000;
     const double scale_d = pow2(fast_d ? sh_d : 0), scale_d2 = pow2(fast_d ? sh_d2 : 0);
-    unsigned cd_next = 0u;
-    if (wave < nblocks) {
-        pre_lds_request<NC, false>(aos, nullptr, incr ? prev_sym : nullptr, wave, ln, wbase);
-        cd_next = wave * 64 + ln < T ? cand[wave * 64 + ln] : 0u;
+    const int fl = lane & 31;
+    const bool second = lane >= 32;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const unsigned lds_rows = (unsigned)(unsigned long long)(lptr_t)wbase;  // the region's LDS address (for the asm reads)
+    // rows of half block hb (the resident copy is padded with zero rows to whole 64-frame blocks) and its cells of the
+    // previous pass -> the wave's region
+    auto request = [&](long hb) {
+        const char* g = (const char*)(aos + hb * (long)(32 * NC));
+#pragma unroll
+        for (int k = 0; k < FL::K16; ++k)
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + k * 1024 + lane * 16), (lptr_t)(wbase + k * 1024), 16, 0, 0);
+#pragma unroll
+        for (int k = 0; k < FL::K4; ++k)
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + FL::K16 * 1024 + k * 256 + lane * 4), (lptr_t)(wbase + FL::K16 * 1024 + k * 256),
+                                             4, 0, 0);
+        if (incr)  // (64 dwords: the half block's 32 cells and 192 bytes beyond them, which the array is padded for)
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)(prev_sym + hb * 32) + lane * 4), (lptr_t)(wbase + FL::HALF_BYTES), 4, 0,
+                                             0);
+    };
+    auto load_cand = [&](long hb) { return hb < nhalf && hb * 32 + fl < T ? cand[hb * 32 + fl] : 0u; };
+    // this lane's codeword row of the half block whose candidates are `cd` (the runner-up's only where it can matter)
+    double2 x[NH];
+    auto gather = [&](unsigned cd) {
+        const int c = (int)(second ? (cd >> 13) & 0x1fffu : cd & 0x1fffu);
+        const double2* r = (const double2*)(cbq + (long)c * NPAD);
+        // (the runner-up's row only where its value will be looked at: the gathers -- 64 lanes x 16 bytes out of 64 different
+        // rows per instruction -- are what this kernel is bound by, not the rows from HBM)
+#pragma unroll
+        for (int n2 = 0; n2 < NH; ++n2) x[n2] = make_double2(0.0, 0.0);
+        if (!second || (cd & CAND_AMB) != 0) {
+#pragma unroll
+            for (int n2 = 0; n2 < NH; ++n2) x[n2] = r[n2];  // (rows are padded to a multiple of 8 doubles)
+        }
+    };
+    i64 dacc0 = 0, dacc1 = 0, dacc2 = 0, dacc3 = 0;
+    unsigned cd_nxt = 0u;
+    if (wave < nhalf) {
+        request(wave);
+        cd_nxt = load_cand(wave);
     }
-    for (long b = wave; b < nblocks; b += nwaves) {
-        const long t = b * 64 + ln;
+    for (long hb = wave; hb < nhalf; hb += nwaves) {
+        const long t = hb * 32 + fl;
         const bool live = t < T;
-        const unsigned cd = cd_next;
+        const unsigned cd = cd_nxt;
         const bool cert = (cd & CAND_CERT) != 0, amb = (cd & CAND_AMB) != 0;
         const int c1 = (int)(cd & 0x1fffu), c2 = (int)((cd >> 13) & 0x1fffu);
-        double best;
-        int idx;
-        {
-            constexpr int NH = (NC + 1) / 2;
-            const double2* r1 = (const double2*)(cbq + (long)c1 * NPAD);
-            const double2* r2 = (const double2*)(cbq + (long)c2 * NPAD);
-            double2 x[NH], y[NH];
+        // ---- chains: this lane's codeword row from L2; the half's rows, requested an iteration ago, land meanwhile (the
+        // compiler waits for the LDS-DMA in front of the LDS reads itself) ----
+        gather(cd);
+        // everything requested so far has arrived: the codeword rows, and -- older -- this half's rows (LDS-DMA: the compiler
+        // does not order LDS reads behind it by itself)
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        asm volatile("" ::: "memory");
+        // The frame's coefficients come from its LDS row eight at a time, by inline asm with its own counter wait: left to
+        // the compiler all 37 reads are hoisted in front of the chain -- 74 registers beside the 74 of the codeword row.
+        double d = 0.0;
+        const unsigned la = lds_rows + (unsigned)(fl * NC * 8);
 #pragma unroll
-            for (int n2 = 0; n2 < NH; ++n2) x[n2] = r1[n2];  // (rows are padded to a multiple of 8 doubles)
+        for (int b0 = 0; b0 < NC; b0 += 8) {
+            double f[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int n2 = 0; n2 < NH; ++n2) y[n2] = make_double2(0.0, 0.0);
-            if (amb) {
+            for (int k = 0; k < 8; ++k)
+                if (b0 + k < NC) asm volatile("ds_read_b64 %0, %1" : "=v"(f[k]) : "v"(la + (unsigned)((b0 + k) * 8)));
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]));
 #pragma unroll
-                for (int n2 = 0; n2 < NH; ++n2) y[n2] = r2[n2];
-            }
-            // the block's rows (and its cells of the previous pass) have landed: everything older than the codeword gathers
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            asm volatile("" ::: "memory");
-            const double* fr = stage + ln * NC;
-            double d1 = 0.0, d2 = 0.0;
-#pragma unroll
-            for (int n2 = 0; n2 < NH; ++n2) {
-                if ((n2 & 3) == 0) asm volatile("" ::: "memory");
-                const double f0 = fr[2 * n2];
-                d1 = __builtin_fma(f0, x[n2].x, d1);
-                d2 = __builtin_fma(f0, y[n2].x, d2);
-                if (2 * n2 + 1 < NC) {
-                    const double f1 = fr[2 * n2 + 1];
-                    d1 = __builtin_fma(f1, x[n2].y, d1);
-                    d2 = __builtin_fma(f1, y[n2].y, d2);
-                }
-            }
-            const bool take_b = amb && (d2 < d1 || (d2 == d1 && c2 < c1));
-            best = take_b ? d2 : d1;
-            idx = take_b ? c2 : c1;
+            for (int k = 0; k < 8; ++k)
+                if (b0 + k < NC) d = __builtin_fma(f[k], ((b0 + k) & 1) ? x[(b0 + k) >> 1].y : x[(b0 + k) >> 1].x, d);
+            asm volatile("" : "+v"(d));  // (pins this batch's fmas in front of the next batch's reads: volatile asm keeps its
+                                         // order, plain arithmetic does not -- the optimiser sank all 37 behind the last read)
         }
-        const int old = incr ? (incr == 2 ? 2 : 1) * (int)prevs[ln] : 0;
-        const bool skip = !cert;
-        idx = skip ? 0 : idx;
-        // the next block's rows: the LDS region is free once this block's reads are done
+        int old = 0;
+        if (incr) {
+            unsigned o16;
+            asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(o16) : "v"(lds_rows + (unsigned)(FL::HALF_BYTES + 2 * fl)));
+            old = (incr == 2 ? 2 : 1) * (int)o16;
+        }
+        // ---- the next half: its rows (the region's reads are done) and its candidates ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (b + nwaves < nblocks) {
-            pre_lds_request<NC, false>(aos, nullptr, incr ? prev_sym : nullptr, b + nwaves, ln, wbase);
-            cd_next = (b + nwaves) * 64 + ln < T ? cand[(b + nwaves) * 64 + ln] : 0u;
+        const long hn = hb + nwaves;
+        if (hn < nhalf) {  // (wave-uniform)
+            request(hn);
+            cd_nxt = load_cand(hn);
         }
+        const double dB = __shfl(d, fl + 32, 64);  // (lanes 0..31: their frame's runner-up)
+        const bool take_b = amb && (dB < d || (dB == d && c2 < c1));
+        const double best = take_b ? dB : d;
+        int idx = take_b ? c2 : c1;
+        const bool skip = !cert;
+        idx = skip ? 0 : idx;
+        const bool own = !second && live;  // this lane speaks for a frame
         // ---- outputs; uncertified frames go to the fallback list -----------------------------------------------------------
-        if (live) {
+        if (own) {
             if (skip) {
                 fb_list[atomicAdd(&ps->fb_count, 1)] = (int)t;
             } else {
                 if (sym) sym[t] = (unsigned short)idx;
                 if (dmin) dmin[t] = best;
-            }
-        }
-        i64 dsum;
-        {
-            int h0 = 0, l0 = 0, h1 = 0, l1 = 0;
-            if (live && !skip) {
                 const double e = best - 1.0;
+                int h0, l0, h1, l1;
                 if (fast_d) {  // (kernel-uniform; same limbs as fix2: vq_fixed.h)
                     fix2_mul(e, scale_d, h0, l0);
                     fix2_mul(e * e, scale_d2, h1, l1);
@@ -510,55 +687,57 @@ __global__ __launch_bounds__(512, 2) void k_finish(const double* __restrict__ ao
                     fix2(e, sh_d, h0, l0);
                     fix2(e * e, sh_d2, h1, l1);
                 }
+                dacc0 += h0;
+                dacc1 += l0;
+                dacc2 += h1;
+                dacc3 += l1;
             }
-            i64 d0 = h0, d1 = l0, d2 = h1, d3 = l1;
-            for (int d = 32; d >= 1; d >>= 1) {
-                d0 += __shfl_xor(d0, d, 64);
-                d1 += __shfl_xor(d1, d, 64);
-                d2 += __shfl_xor(d2, d, 64);
-                d3 += __shfl_xor(d3, d, 64);
-            }
-            dsum = ln == 0 ? d0 : ln == 1 ? d1 : ln == 2 ? d2 : d3;
         }
-        // ---- records: (frame, cell within its bin, sign) into this workgroup's region of the bin (k_pass_pre_lds, ACC = 2) ---
-        const bool mov = live && !skip && (!incr || old != idx);
-        {
+        if (own && !skip && prev_sym) prev_sym[t] = (unsigned short)idx;
+        // ---- records: '+' for the cell the frame is in now -- the side table's row when it landed in the odd child of its
+        // family (seeded pass) --, '-' for the cell an incremental mover left ---------------------------------------------------
+        const bool mov = own && !skip && (!incr || old != idx);
+        if (mov) {
             const bool infam = incr == 2 && idx == old + 1;
             const int vN = infam ? rec.nbins_rows * rec.bin_cells + (old >> 1) : idx;
-            const bool hasN = mov, hasO = mov && incr != 0 && !infam;
-            const int binN = (int)(((unsigned)vN * rec.magic) >> 22), binO = (int)(((unsigned)old * rec.magic) >> 22);
-            int rankN = 0, rankO = 0, cntv = 0;
-            u64 pn = __ballot(hasN), po = __ballot(hasO);
-            while ((pn | po) != 0) {
-                const int r = pn != 0 ? __builtin_amdgcn_readlane(binN, (int)__builtin_ctzll(pn))
-                                      : __builtin_amdgcn_readlane(binO, (int)__builtin_ctzll(po));
-                const bool inN = hasN && binN == r, inO = hasO && binO == r;
-                const u64 sn = __ballot(inN), so = __ballot(inO);
-                const int cn = __builtin_popcountll(sn);
-                if (inN) rankN = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sn >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sn, 0u));
-                if (inO) rankO = cn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(so >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)so, 0u));
-                if (ln == r) cntv = cn + __builtin_popcountll(so);
-                pn &= ~sn;
-                po &= ~so;
-            }
-            int basev = 0;
-            if (cntv > 0) basev = __hip_atomic_fetch_add(&rcnt[ln], cntv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int baseN = __shfl(basev, binN, 64), baseO = __shfl(basev, binO, 64);
+            const int binN = (int)(((unsigned)vN * rec.magic) >> 22);
             uint2* const region0 = rec.recs + (size_t)blockIdx.x * (size_t)rec.nbins * (size_t)rec.cap;
-            if (hasN)
-                region0[(size_t)binN * rec.cap + (baseN + rankN)] = make_uint2((unsigned)t, (unsigned)(vN - binN * rec.bin_cells));
-            if (hasO)
-                region0[(size_t)binO * rec.cap + (baseO + rankO)] =
-                    make_uint2((unsigned)t, (unsigned)(old - binO * rec.bin_cells) | 0x10000u);
+            const int pN = __hip_atomic_fetch_add(&rcnt[binN], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            region0[(size_t)binN * rec.cap + pN] = make_uint2((unsigned)t, (unsigned)(vN - binN * rec.bin_cells));
+            if (incr != 0 && !infam) {
+                const int binO = (int)(((unsigned)old * rec.magic) >> 22);
+                const int pO = __hip_atomic_fetch_add(&rcnt[binO], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                region0[(size_t)binO * rec.cap + pO] = make_uint2((unsigned)t, (unsigned)(old - binO * rec.bin_cells) | 0x10000u);
+            }
         }
-        if (ln < 4 && dsum != 0) atomicAdd((u64*)&rows[(long)(b % (32 * MT)) * RS + 2 * NC + 1 + ln], (u64)dsum);
-        if (prev_sym && live && !skip) prev_sym[t] = (unsigned short)idx;
+    }
+    // the wave's distortion sums -> the distortion columns of one row (any row: only their column totals are ever used)
+    {
+        i64 v[4] = {dacc0, dacc1, dacc2, dacc3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            for (int dd = 32; dd >= 1; dd >>= 1) v[k] += __shfl_xor(v[k], dd, 64);
+            if (lane == 0 && v[k] != 0) atomicAdd((u64*)&rows[(long)(wave % (32 * MT)) * RS + 2 * NC + 1 + k], (u64)v[k]);
+        }
     }
     __syncthreads();
     if ((int)threadIdx.x < rec.nbins) rec.counts[(size_t)blockIdx.x * rec.nbins + threadIdx.x] = rcnt[threadIdx.x];
 }
 
 // ---- launch wrappers ----------------------------------------------------------------------------------------------------------
+#ifdef E2VQ_SWEEP_STAMP
+}  // namespace e2vq
+extern "C" int e2vq_debug_sweep_stamps(unsigned long long* out16, int reset)
+{
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(e2vq::g_sweep_stamps), 16 * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(e2vq::g_sweep_stamps), z, 16 * 8) != hipSuccess) return 1;
+    }
+    return 0;
+}
+namespace e2vq {
+#endif
 static bool sweep_has_nc(int NC)
 {
     switch (NC) {
@@ -677,7 +856,7 @@ static int launch_finish_t(const double* aos, long T, long nblocks, const unsign
         rec.cap = records->cap;
         rec.magic = records->magic;
         (void)hipFuncSetAttribute((const void*)k_finish<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, E2VQ_LDS_BYTES);
-        hipLaunchKernelGGL((k_finish<NC>), dim3(grid), dim3(WAVES * 64), (size_t)WAVES * PreLds<NC>::WAVE_BYTES + 256, s, aos, T,
+        hipLaunchKernelGGL((k_finish<NC>), dim3(grid), dim3(FinLds<NC>::WAVES * 64), (size_t)FinLds<NC>::WAVES * FinLds<NC>::WAVE_BYTES + 256, s, aos, T,
                            nblocks, cand, (PreScalars*)ps, cbq, M / 32, sc, (const u64*)l1max_bits, sym, dmin, (i64*)rows, fb_list,
                            prev_sym, incr, rec, (SweepCounters*)counters, (unsigned long long*)host_counters);
         return 0;
