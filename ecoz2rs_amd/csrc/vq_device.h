@@ -105,6 +105,16 @@ int launch_sort_by_cell(const unsigned short* key, long T, long nblocks64, int n
 int launch_sweep_candidates(int NC, bool two_stage, const void* fimg, const unsigned* perm, long T, long nblocks, const void* cimg,
                             const void* ps, int M, const unsigned short* prev_sym, int home_mul, unsigned* cand, void* counters,
                             hipStream_t s);
+// the FUSED pass over grouped frames (perm != nullptr, incr 1 or 2): sweep + exact evaluation + outputs + the cell sums
+// reduced in the block, one kernel; `cells`: every frame's cell, read as the old one and written with the new one.
+// counters: sweep_counters_of(sort scratch) or nullptr (left for the host to fetch: launch_sweep_counters_out)
+int launch_pass_sorted(int NC, bool two_stage, const void* fimg, const unsigned* perm, long T, long nblocks, const void* cimg, void* ps,
+                       const double* cbq, int M, const double* aos, const DevScalars* sc, const unsigned long long* l1max_bits,
+                       unsigned short* sym, double* dmin, long long* rows, long long* fam, int* fb_list, unsigned short* cells, int incr,
+                       void* counters, hipStream_t s);
+// copies the two-stage sweep's counters to two host-mapped 64-bit words and zeroes them (k_finish does the same for the
+// split pass)
+void launch_sweep_counters_out(void* counters, void* host_counters, hipStream_t s);
 // incr: 0 full, 1 incremental, 2 seeded (as k_pass_pre_lds); the contributions are recorded for launch_reduce_records
 int launch_finish(int NC, const double* aos, long T, long nblocks, const unsigned* cand, void* ps, const double* cbq, int M,
                   const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin, long long* rows,

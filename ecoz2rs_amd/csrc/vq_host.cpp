@@ -208,6 +208,7 @@ struct e2vq_session {
     // and data whose near codewords share tiles: the finishing kernel publishes the flagged fraction of every two-stage
     // sweep, and above two_stage_max_frac the rest of the level (and the next one) runs the one-stage sweep.
     bool sweep2_enabled = true;
+    bool fused_enabled = true;       // ECOZ2_VQ_FUSED_SORTED=0: grouped passes as sweep + finishing kernel + reduce too (A/B)
     bool two_stage_enabled = true;   // ECOZ2_VQ_TWO_STAGE=0: one-stage sweep always
     double two_stage_max_frac = 0.45;
     int two_stage_off_until_M = 0;   // one-stage sweeps while M <= this
@@ -363,6 +364,7 @@ static int session_init(e2vq_session* s)
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS_FEW_DIV")) s->rec_few_div = std::max(0, atoi(rc));
     if (const char* sw = getenv("ECOZ2_VQ_SPLIT_SWEEP")) s->sweep2_enabled = atoi(sw) != 0;
     if (const char* sw = getenv("ECOZ2_VQ_TWO_STAGE")) s->two_stage_enabled = atoi(sw) != 0;
+    if (const char* sw = getenv("ECOZ2_VQ_FUSED_SORTED")) s->fused_enabled = atoi(sw) != 0;
     // With the recorded accumulate the prefiltered pass also wins at M = 128 (0.36 vs 0.43 ms per pass on 2^21 frames; not
     // at 64: 0.30 vs 0.28), and a seeded first pass halves the records of every prefiltered level's first pass
     if (s->rec_enabled && e2vq::prefilter_lds_stage(s->NC)) {
@@ -599,7 +601,7 @@ static int set_frames_device_impl(e2vq_session* s, const void* device_frames, in
                 *adopt = true;
                 if (rows > have) HIPCHK(hipMemsetAsync(s->d_aos + have * s->NC, 0, (rows - have) * s->NC * 8, s->stream));
                 HIPCHK(hipMemsetAsync(s->d_fg, 0, (size_t)s->nblocks * 64 * sizeof(float), s->stream));
-            } else if (hipMalloc(&s->d_aos, rows * s->NC * 8) == hipSuccess) {
+            } else if (hipMalloc(&s->d_aos, rows * s->NC * 8 + 16) == hipSuccess) {  // (+ 16: the fused pass fetches rows in 16-byte pieces)
                 HIPCHK(hipMemcpyAsync(s->d_aos, device_frames, have * s->NC * 8, hipMemcpyDeviceToDevice, s->stream));
                 if (rows > have) HIPCHK(hipMemsetAsync(s->d_aos + have * s->NC, 0, (rows - have) * s->NC * 8, s->stream));
                 HIPCHK(hipMemsetAsync(s->d_fg, 0, (size_t)s->nblocks * 64 * sizeof(float), s->stream));
@@ -935,10 +937,16 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     // the first pass after a split, seeded with the parents' sums (e2vq_grow stashed them): k_seed_family
     bool family = s->fam_pending && keep && !incremental && !split && s->d_aos && 2 * s->fam_M == s->M && mode != 0;
     s->fam_pending = false;
+    // round 5: the frames are grouped by cell (a seeded first pass, or an incremental one) -> the fused sorted pass: sweep,
+    // exact evaluation, outputs and the cell sums reduced in the block, one kernel (vq_sweep.hip); no records
+    const bool fused = keep && !split && mode != 0 && (family || incremental) && s->sweep2_enabled && s->fused_enabled && s->d_fimgF &&
+                       s->d_aos && e2vq::sweep_supported(s->NC, s->M);
     // round 4: contributions recorded by the sweep, folded into the rows by k_reduce_records
     e2vq::PassRecords recplan{};
     bool records = false;
-    if (keep && !split && mode != 0) {
+    if (fused) {
+        s->last_recorded = false;
+    } else if (keep && !split && mode != 0) {
         size_t bytes = 0;
         records = records_plan(s, s->M, family, &recplan, &bytes);
         // few records on the last pass of this level: the rest of the level adds its contributions as a burst
@@ -982,11 +990,11 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         }
     }
     // (P = 40: rows of 83 elements are seeded only where the contributions are recorded -- the burst cannot add them)
-    if (family && !records && !e2vq::prefilter_burst_supported(s->NC)) family = false;
+    if (family && !records && !fused && !e2vq::prefilter_burst_supported(s->NC)) family = false;
     // The first pass of a level accumulates in full.  For the smallest prefiltered sizes that is cheaper on the plain
     // FP64 sweep with its workgroup-local LDS table (hybrid accumulate: 0.92 vs 1.5 ms at M = 256, where 2^21 frames
     // hammer 256 rows with global atomics); it records the cells for the incremental passes that follow.
-    const bool plain_first = s->plain_first && keep && !incremental && !family && !split && !records && mode == 5 && s->M <= 384;
+    const bool plain_first = s->plain_first && keep && !incremental && !family && !split && !records && !fused && mode == 5 && s->M <= 384;
     if (s->last_prefiltered && !plain_first && ensure_codebook_image(s)) return 1;
     {
         // one prologue launch: the rows (all of them, or the distortion columns of an incremental pass), the fallback
@@ -1067,6 +1075,40 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
                 HIPCHK(hipMemcpyAsync(s->d_prev_sym, device_sym, (size_t)s->T * sizeof(unsigned short), hipMemcpyDeviceToDevice, s->stream));
             else
                 std::swap(s->d_prev_sym, s->d_cells_new);
+        } else if (fused) {
+            // round 5, frames grouped: [sort] -> ONE kernel (two-stage sweep, exact evaluation, outputs, cell sums in the block)
+            const int incr = family ? 2 : 1;
+            if (incr == 2 || s->perm_M != s->M) {
+                if (e2vq::launch_sort_by_cell(s->d_prev_sym, s->T, s->nblocks, incr == 2 ? s->M / 2 : s->M, s->d_sort, s->d_perm,
+                                              s->stream))
+                    return e2vq_set_error("sort by cell: unsupported size");
+                s->perm_M = s->M;
+            }
+            // (two stages need tiles to skip: from eight tiles on; below, the home tile alone is a quarter or half of the codebook)
+            const bool two = s->two_stage_enabled && s->M >= 256 && s->M > s->two_stage_off_until_M;
+            // the flagged fraction is looked at once per level: on its first pass
+            const bool count = two && incr == 2;
+            if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));  // (again: behind the sort)
+            if (e2vq::launch_pass_sorted(s->NC, two, s->d_fimgF, s->d_perm, s->T, s->nblocks, d_cimg, d_ps, s->d_cbq, s->M, s->d_aos,
+                                         s->d_sc, s->d_l1max, (unsigned short*)device_sym, (double*)device_dmin, rows,
+                                         family ? s->d_fam : nullptr, s->d_fblist, s->d_prev_sym, incr,
+                                         count ? e2vq::sweep_counters_of(s->d_sort) : nullptr, s->stream))
+                return e2vq_set_error("fused sorted pass: unsupported configuration");
+            if (s->timing) {
+                HIPCHK(hipEventRecord(s->ev1, s->stream));
+                s->timed = true;
+                s->timing_pending = true;
+            }
+            if (count) {
+                void* sw_host = nullptr;
+                HIPCHK(hipHostGetDevicePointer(&sw_host, (void*)&s->h_stats->sw_flagged, 0));
+                e2vq::launch_sweep_counters_out(e2vq::sweep_counters_of(s->d_sort), sw_host, s->stream);
+                s->sw_pending = true;
+            }
+            e2vq::launch_pass_fallback(s->NC, true, s->d_blk, s->d_cbm, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
+                                       (double*)device_dmin, rows, s->d_fblist, e2vq::prefilter_fallback_count(d_ps), s->d_prev_sym,
+                                       incr, s->stream);
+            if (family) e2vq::launch_family_fixup(rows, s->d_fam, s->fam_M, s->NC, s->stream);
         } else if (records && s->sweep2_enabled && s->d_fimgF && e2vq::sweep_supported(s->NC, s->M)) {
             // round 5: [sort] -> candidate sweep -> finishing kernel (exact evaluation, outputs, records) -> reduce
             const int incr = family ? 2 : (incremental ? 1 : 0);
@@ -2441,7 +2483,7 @@ static int upload_predictors(e2vq_session* s, const PrdSet& ps, i64 lo, i64 hi)
         tl = t1;
     };
     const i64 CH = std::min<i64>(T, 1 << 18);  // 78 MB of predictor vectors per chunk at P = 36
-    HIPCHK(hipMalloc(&r.d, (size_t)((T + 63) / 64 * 64) * NC * 8));  // (whole blocks: the session may keep the buffer)
+    HIPCHK(hipMalloc(&r.d, (size_t)((T + 63) / 64 * 64) * NC * 8 + 16));  // (whole blocks + 16 bytes: the session may keep the buffer)
     HIPCHK(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k) {
         r.h[k] = (double*)pinned_pool().acquire((size_t)CH * NC * 8, &r.hb[k]);

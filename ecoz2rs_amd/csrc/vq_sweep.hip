@@ -296,20 +296,87 @@ struct SweepCounters {
     unsigned long long jobs;     // (tile, column block) jobs in all
 };
 
-template <int NC, bool TWO>
-__global__ __launch_bounds__(512, 2) void k_sweep_cand(const unsigned char* __restrict__ fimg, const unsigned* __restrict__ perm,
-                                                       long T, long nblocks, const h8* __restrict__ cimg,
-                                                       const PreScalars* __restrict__ ps, int MT, int idxmask,
-                                                       const unsigned short* __restrict__ prev_sym, int home_mul,
-                                                       unsigned* __restrict__ cand, SweepCounters* __restrict__ counters)
+// FUSE (the frames are grouped): the same kernel also finishes its frames -- what k_finish and k_reduce_records do for a
+// sweep over ungrouped frames, at a fraction of their cost because a block's frames share their cells:
+//   * the block's FP64 rows are gathered into the wave's LDS region by LDS-DMA when the block begins (one frame at a time:
+//     2 NC dwords from a uniform base -- they land during stage 1);
+//   * behind the certification each lane evaluates ITS frame's candidates with the canonical chain -- the codeword rows
+//     gathered from L2, where most lanes of a block ask for the same row --, writes symbol / distortion / the frame's new
+//     cell (or lists the frame for the fallback sweep), and keeps the distortion sums in registers;
+//   * the contributions to the cell sums -- '+' new cell (the family side table's row for the odd child of a seeded pass),
+//     '-' old cell of a mover -- are reduced IN THE BLOCK: per distinct row among them the wave sums the limbs of the
+//     contributing frames' LDS rows (lane = coefficient) and adds the 2 NC + 1 totals to the row with one atomic each.
+//     A handful of rows per block where the frames are grouped (any number where they are not: still exact, only slow).
+// Exact 64-bit integers: the rows equal those of every other accumulate bit for bit.
+struct SweepFuse {
+    const double* aos;          // row-major resident frames, padded with zero rows to whole blocks
+    const double* cbq;
+    const DevScalars* sc;
+    const u64* l1max_bits;
+    unsigned short* sym;        // (optional) outputs by frame
+    double* dmin;
+    i64* rows;
+    i64* fam;                   // side table of a seeded pass (incr == 2)
+    int* fb_list;
+    unsigned short* cells;      // every frame's cell: read (old) and written (new)
+    int incr;                   // 0 full, 1 incremental, 2 seeded
+    int M;
+};
+
+template <int NC>
+struct SweepLds {
+    // a frame's row in the wave's LDS region: RP pieces of 16 bytes -- the row's NC * 8 bytes rounded up to whole pieces, plus one
+    // more piece where that makes the stride 4 * odd dwords (an 8-byte read per lane then meets a 4-way bank conflict at
+    // worst; 4 * even would be 8-way or more).  The LDS-DMA that fills it fetches whole 16-byte pieces: the last piece of a row
+    // may reach 8 bytes into the next row (the resident copy is padded by 16 bytes for the last one).
+    static constexpr int RP0 = (NC * 8 + 15) / 16;
+    static constexpr int RP = (RP0 & 1) ? RP0 : RP0 + 1;
+    static constexpr int ROW_BYTES = RP * 16;
+    static constexpr int ROWS_BYTES = 64 * ROW_BYTES;
+    static constexpr int WAVE_BYTES_FUSE = ROWS_BYTES + 512;  // + the list of flagged tiles (16 bits each)
+    static constexpr int FIT = (E2VQ_LDS_BYTES - 256) / WAVE_BYTES_FUSE;
+    static constexpr int WAVES_FUSE = FIT >= 8 ? 8 : FIT;
+    static constexpr bool FUSE_OK = WAVES_FUSE >= 6 && NC < 64;
+};
+
+template <int NC, bool TWO, bool FUSE>
+__global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void k_sweep_cand(
+    const unsigned char* __restrict__ fimg, const unsigned* __restrict__ perm, long T, long nblocks, const h8* __restrict__ cimg,
+    PreScalars* __restrict__ ps, int MT, int idxmask, const unsigned short* __restrict__ prev_sym, int home_mul,
+    unsigned* __restrict__ cand, SweepCounters* __restrict__ counters, SweepFuse fz)
 {
     typedef PrePack<NC> PK;
     constexpr int NU = PK::NU, FS = SweepImg<NC>::FS;
+    typedef SweepLds<NC> SL;
+    constexpr int WAVES = FUSE ? SweepLds<NC>::WAVES_FUSE : 8;
+    constexpr int WAVE_LDS = FUSE ? SweepLds<NC>::WAVE_BYTES_FUSE : 512;
+    constexpr int RS = (2 * NC + 5 + 7) & ~7, NPAD = (NC + 7) & ~7, NH = (NC + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long wave = (long)blockIdx.x * 8 + wib;
-    const long nwaves = (long)gridDim.x * 8;
-    unsigned* tlist = (unsigned*)smem + wib * 256;  // flagged tiles of the block: tile | column-block bits << 16 (MT <= 256)
+    const long wave = (long)blockIdx.x * WAVES + wib;
+    const long nwaves = (long)gridDim.x * WAVES;
+    unsigned char* const wlds = smem + (size_t)wib * WAVE_LDS;
+    unsigned short* tlist = (unsigned short*)(wlds + (FUSE ? SweepLds<NC>::ROWS_BYTES : 0));  // flagged tiles: tile | column-block bits << 8 (MT <= 256)
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const unsigned lds_rows = (unsigned)(unsigned long long)(lptr_t)wlds;  // (the region's LDS address, for the asm reads)
+    // FUSE: fixed-point scales of the cell sums and of the distortion sums (as k_pass_pre_lds)
+    int sh_r = 0, sh_d = 0, sh_d2 = 0;
+    bool fast_fix = true, fast_d = true;
+    double scale_r = 1.0, scale_d = 1.0, scale_d2 = 1.0;
+    i64 dacc0 = 0, dacc1 = 0, dacc2 = 0, dacc3 = 0;
+    if constexpr (FUSE) {
+        sh_r = fz.sc->sh_r;
+        const int Ed = dist_exponent(fz.sc->maxabs, __longlong_as_double((i64)*fz.l1max_bits));
+        sh_d = 30 - Ed;
+        sh_d2 = 30 - 2 * Ed;
+        auto pow2 = [](int e) { return __longlong_as_double((long long)(1023 + e) << 52); };  // |e| <= 1000
+        fast_fix = sh_r >= -1000 && sh_r <= 1000;
+        fast_d = sh_d >= -1000 && sh_d <= 1000 && sh_d2 >= -1000 && sh_d2 <= 1000;
+        scale_r = pow2(fast_fix ? sh_r : 0);
+        scale_d = pow2(fast_d ? sh_d : 0);
+        scale_d2 = pow2(fast_d ? sh_d2 : 0);
+    }
     const float ymax1 = __int_as_float(ps->ymax_bits);
     const float relk = __int_as_float((127 + __builtin_popcount(~idxmask) - 21) << 23);  // 2 rho, rho = 2^-(22-idxbits)
     int maskv = idxmask;
@@ -367,6 +434,36 @@ __global__ __launch_bounds__(512, 2) void k_sweep_cand(const unsigned char* __re
         const long bn = b + nwaves < nblocks ? b + nwaves : b;  // (the wave's last block asks for itself again: no load is conditional)
         SW_STAMP(0)  // the block's B operands (requested behind the previous block's stage 2) are there
         slot_frames(bn, f0n, f1n);
+        const unsigned fs = h ? f1 : f0;  // the frame of slot b * 64 + lane
+        unsigned short oldraw = 0;  // (turned into the old cell further down: a use up here would wait for the requests below)
+        if constexpr (FUSE) {
+            // the block's FP64 rows -> the wave's LDS region, frame by frame (the previous block's reads of it are complete);
+            // they are needed behind stage 2 -- in this wave's in-order queue they only delay the first tile's operands
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (fz.incr) oldraw = fz.cells[fs];
+            // (RP instructions of 64 pieces of 16 bytes -- an LDS-DMA instruction costs its ~100 cycles of issue whatever its
+            // width: fetched dword by dword the request took 18 k cycles per block --: lane -> piece q = 64 k + lane of the
+            // block's padded row-major image = piece q % RP of slot q / RP, whose frame number comes from that slot's lane)
+            // (the lane index afresh from the hardware: computed from the kernel's `lane`, every instruction's slot and piece
+            // are invariants of the block loop -- hoisted, kept in 2 RP registers for the whole kernel, and spilled)
+            const int lane_q = pre_fresh_lane();
+#pragma unroll
+            for (int k = 0; k < SL::RP; ++k) {
+                const unsigned q = (unsigned)(k * 64 + lane_q);
+                const unsigned slot = q / (unsigned)SL::RP, pc = q - slot * (unsigned)SL::RP;
+                const unsigned fr_ = (unsigned)__shfl((int)fs, (int)slot, 64);
+                // (a padding piece fetches the row's first piece again: any valid address)
+                const char* g = (const char*)fz.aos + ((size_t)fr_ * (size_t)(NC * 8) + (size_t)((pc < (unsigned)SL::RP0 ? pc : 0u) * 16u));
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(wlds + k * 1024), 16, 0, 0);
+            }
+#ifdef E2VQ_SWEEP_STAMP
+            {   // (issue side of the requests only: no drain)
+                const unsigned long long sw_now = __builtin_amdgcn_s_memtime();
+                sw_acc[4] += sw_now - sw_t;
+                sw_t = sw_now;
+            }
+#endif
+        }
         float k1[2], k2[2], k3[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) k1[cb] = k2[cb] = k3[cb] = __int_as_float(0x7f7fffff);
@@ -378,15 +475,17 @@ __global__ __launch_bounds__(512, 2) void k_sweep_cand(const unsigned char* __re
             const float D1 = 2.54f * (257.f * (gc1 + ymax1) + (129.f * NC + 2.f));
             float U0 = pinf, U1 = pinf, thr0 = pinf, thr1 = pinf;
             int ntl = 0;
-            // Four register sets of coarse granules, three tiles requested ahead: a tile's MFMAs take ~0.3 us, its operands
-            // ~1 us to arrive from L2 -- with one tile of distance the loop ran at the latency, not at the matrix pipe.
+            // Two register sets of coarse granules, one tile requested ahead (measured: one, two or three tiles of distance
+            // make no difference -- the stage runs at what the matrix pipe delivers at this clock -- and the registers are
+            // needed by what lives across the whole block in the fused kernel)
             auto tile_at = [&](int i) {
                 i = i < MT ? i : MT - 1;
                 return home + i < MT ? home + i : home + i - MT;
             };
-            h8 A[4][NU];
+            constexpr int ND = 2;  // register sets
+            h8 A[ND][NU];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) sweep_load_tile<NC>(A[k], cimg, tile_at(k), lane, true);
+            for (int k = 0; k < ND - 1; ++k) sweep_load_tile<NC>(A[k], cimg, tile_at(k), lane, true);
             // accumulators of the two column blocks; each job digests the other's previous values: the "previous" values
             // of the very first job are huge (no flag), and one more epilogue follows the loop
             f16v acc0[2], acc1[2];
@@ -400,15 +499,15 @@ __global__ __launch_bounds__(512, 2) void k_sweep_cand(const unsigned char* __re
                 thr1 = U1 > 0.f ? __builtin_fmaf(U1, 1.000001f, D1) : pinf;
                 const unsigned bits = bits_prev | (__ballot(fl1) != 0 ? 2u : 0u);
                 if (bits) {  // (wave-uniform; every lane stores the same word)
-                    tlist[ntl] = (unsigned)tile_prev | bits << 16;
+                    tlist[ntl] = (unsigned short)((unsigned)tile_prev | bits << 8);
                     ++ntl;
                 }
             };
-            for (int i0 = 0; i0 < MT; i0 += 4) {
+            for (int i0 = 0; i0 < MT; i0 += ND) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < ND; ++k) {
                     const int i = i0 + k;
-                    sweep_load_tile<NC>(A[(k + 3) & 3], cimg, tile_at(i + 3), lane, true);
+                    sweep_load_tile<NC>(A[(k + ND - 1) % ND], cimg, tile_at(i + ND - 1), lane, true);
                     if (i < MT) {  // (wave-uniform)
                         const int tile = tile_at(i);
                         const float m1 = sweep_coarse_job_pinned<NC>(acc0, A[k], B[0], acc1);  // (digests tile_prev, column block 1)
@@ -439,14 +538,14 @@ __global__ __launch_bounds__(512, 2) void k_sweep_cand(const unsigned char* __re
             if (ntl > 0) {
                 h8 Acur[NU], Anext[NU];
                 unsigned e = tlist[0];
-                sweep_load_tile<NC>(Acur, cimg, (int)(e & 0xffffu), lane, false);
+                sweep_load_tile<NC>(Acur, cimg, (int)(e & 0xffu), lane, false);
                 for (int j = 0; j < ntl; ++j) {
                     const unsigned en = tlist[j + 1 < ntl ? j + 1 : j];
-                    sweep_load_tile<NC>(Anext, cimg, (int)(en & 0xffffu), lane, false);
-                    const int tile = (int)(e & 0xffffu);
-                    if (e & 0x10000u) sweep_full_job<NC>(Acur, B[0], tile, k1[0], k2[0], k3[0], maskv, ninf);
-                    if (e & 0x20000u) sweep_full_job<NC>(Acur, B[1], tile, k1[1], k2[1], k3[1], maskv, ninf);
-                    nflag += ((e >> 16) & 1u) + ((e >> 17) & 1u);
+                    sweep_load_tile<NC>(Anext, cimg, (int)(en & 0xffu), lane, false);
+                    const int tile = (int)(e & 0xffu);
+                    if (e & 0x100u) sweep_full_job<NC>(Acur, B[0], tile, k1[0], k2[0], k3[0], maskv, ninf);
+                    if (e & 0x200u) sweep_full_job<NC>(Acur, B[1], tile, k1[1], k2[1], k3[1], maskv, ninf);
+                    nflag += ((e >> 8) & 1u) + ((e >> 9) & 1u);
 #pragma unroll
                     for (int u = 0; u < NU; ++u) Acur[u] = Anext[u];
                     e = en;
@@ -468,8 +567,8 @@ __global__ __launch_bounds__(512, 2) void k_sweep_cand(const unsigned char* __re
             home_n = 0;
         }
         SW_STAMP(2)  // stage 2 (or the one-stage loop)
-        // the next block's B operands: their registers are free from here on
-        load_B(f0n, f1n);
+        // the next block's B operands: their registers are free from here on (FUSE: requested further down)
+        if constexpr (!FUSE) load_B(f0n, f1n);
 
         // ---- lane = slot b * 64 + lane: merge the two lane halves of its frame's keys, certify the top two ------------------
         const int hb = h << 2;
@@ -492,7 +591,167 @@ __global__ __launch_bounds__(512, 2) void k_sweep_cand(const unsigned char* __re
         const bool cert = t1 >= 1.0e-30f && t1 < 1.0e37f && w3 > t1 + tau;
         const bool amb = !(u2 > t1 + tau);
         const unsigned c1 = (unsigned)(__float_as_int(t1) & ~idxmask), c2 = (unsigned)(__float_as_int(u2) & ~idxmask);
-        if (b * 64 + lane < T) cand[f] = c1 | c2 << 13 | (amb ? CAND_AMB : 0u) | (cert ? CAND_CERT : 0u);
+        const bool live = b * 64 + lane < T;
+        if constexpr (!FUSE) {
+            if (live) cand[f] = c1 | c2 << 13 | (amb ? CAND_AMB : 0u) | (cert ? CAND_CERT : 0u);
+        } else {
+            // ---- exact evaluation: the canonical chain acc = fma(r[n], cq[n], acc), n ascending from +0.0; r from the frame's
+            // LDS row (inline asm, eight at a time, the fmas pinned behind them: see k_finish), cq gathered from L2 ----------
+            double2 x[NH], y[NH];
+            const unsigned la = lds_rows + (unsigned)(lane * SL::ROW_BYTES);
+            {
+                const double2* r1 = (const double2*)(fz.cbq + (size_t)c1 * NPAD);
+                const double2* r2 = (const double2*)(fz.cbq + (size_t)c2 * NPAD);
+#pragma unroll
+                for (int n2 = 0; n2 < NH; ++n2) x[n2] = r1[n2];  // (rows are padded to a multiple of 8 doubles)
+                // (the runner-up's row only where it can matter: a gather costs the texture path a request per lane)
+#pragma unroll
+                for (int n2 = 0; n2 < NH; ++n2) y[n2] = make_double2(0.0, 0.0);
+                if (amb) {
+#pragma unroll
+                    for (int n2 = 0; n2 < NH; ++n2) y[n2] = r2[n2];
+                }
+            }
+            // the codeword rows -- and, older, this block's rows (LDS-DMA) -- have arrived
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            asm volatile("" ::: "memory");
+            double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int b0 = 0; b0 < NC; b0 += 8) {
+                double fv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (b0 + k < NC) asm volatile("ds_read_b64 %0, %1" : "=v"(fv[k]) : "v"(la + (unsigned)((b0 + k) * 8)));
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(fv[0]), "+v"(fv[1]), "+v"(fv[2]), "+v"(fv[3]), "+v"(fv[4]), "+v"(fv[5]), "+v"(fv[6]), "+v"(fv[7]));
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (b0 + k < NC) {
+                        d1 = __builtin_fma(fv[k], ((b0 + k) & 1) ? x[(b0 + k) >> 1].y : x[(b0 + k) >> 1].x, d1);
+                        d2 = __builtin_fma(fv[k], ((b0 + k) & 1) ? y[(b0 + k) >> 1].y : y[(b0 + k) >> 1].x, d2);
+                    }
+                asm volatile("" : "+v"(d1), "+v"(d2));
+            }
+            const bool take_b = amb && (d2 < d1 || (d2 == d1 && c2 < c1));
+            const double best = take_b ? d2 : d1;
+            int idx = take_b ? (int)c2 : (int)c1;
+            // the next block's B operands: the codeword rows' registers are free now
+            load_B(f0n, f1n);
+            const bool skip = !cert;
+            idx = skip ? 0 : idx;
+#ifdef E2VQ_SWEEP_STAMP
+            {
+                const unsigned long long sw_now = __builtin_amdgcn_s_memtime();
+                sw_acc[5] += sw_now - sw_t;
+                sw_t = sw_now;
+            }
+#endif
+            // ---- outputs; uncertified frames go to the fallback list ----
+            if (live) {
+                if (skip) {
+                    fz.fb_list[atomicAdd(&ps->fb_count, 1)] = (int)f;
+                } else {
+                    if (fz.sym) fz.sym[f] = (unsigned short)idx;
+                    if (fz.dmin) fz.dmin[f] = best;
+                    fz.cells[f] = (unsigned short)idx;
+                    const double e = best - 1.0;
+                    int h0, l0, h1, l1;
+                    if (fast_d) {  // (kernel-uniform; same limbs as fix2: vq_fixed.h)
+                        fix2_mul(e, scale_d, h0, l0);
+                        fix2_mul(e * e, scale_d2, h1, l1);
+                    } else {
+                        fix2(e, sh_d, h0, l0);
+                        fix2(e * e, sh_d2, h1, l1);
+                    }
+                    dacc0 += h0;
+                    dacc1 += l0;
+                    dacc2 += h1;
+                    dacc3 += l1;
+                }
+            }
+#ifdef E2VQ_SWEEP_STAMP
+            {
+                const unsigned long long sw_now = __builtin_amdgcn_s_memtime();
+                sw_acc[6] += sw_now - sw_t;
+                sw_t = sw_now;
+            }
+#endif
+            // ---- the block's contributions to the cell sums, reduced in the block ----
+            {
+                const int incr = fz.incr;
+                const int oldc = (incr == 2 ? 2 : 1) * (int)oldraw;
+                const bool mov = live && !skip && (!incr || oldc != idx);
+                const bool infam = incr == 2 && idx == oldc + 1;
+                const int keyN = infam ? fz.M + (oldc >> 1) : idx;  // (rows of the side table: behind the codebook's)
+                const bool hasN = mov, hasO = mov && incr != 0 && !infam;
+                u64 mN = __ballot(hasN), mO = __ballot(hasO);
+                // every contributing lane turns ITS frame's row into limb pairs in place (8 bytes either way): the conversion
+                // -- six FP64 operations per value -- is paid once per block with all lanes at work, and adding a frame to
+                // a row is then one 4-byte LDS read and one 64-bit add per lane
+                if (mov) {
+                    double* fr = (double*)(wlds + lane * SL::ROW_BYTES);
+                    if (fast_fix) {
+#pragma unroll 4
+                        for (int n = 0; n < NC; ++n) {
+                            int hh, ll;
+                            fix2_mul(fr[n], scale_r, hh, ll);
+                            *(int2*)&fr[n] = make_int2(hh, ll);
+                        }
+                    } else {
+#pragma unroll 1
+                        for (int n = 0; n < NC; ++n) {
+                            int hh, ll;
+                            fix2(fr[n], sh_r, hh, ll);
+                            *(int2*)&fr[n] = make_int2(hh, ll);
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // lane n < NC: the limb pair of coefficient n; four member frames at a time, their reads in flight together
+                const int2* lrows = (const int2*)wlds;
+                constexpr int RW = SL::ROW_BYTES / 8;
+                while ((mN | mO) != 0) {
+                    const int key = mN != 0 ? __builtin_amdgcn_readlane(keyN, (int)__builtin_ctzll(mN))
+                                            : __builtin_amdgcn_readlane(oldc, (int)__builtin_ctzll(mO));
+                    const u64 sN = __ballot(hasN && keyN == key), sO = __ballot(hasO && oldc == key);
+                    i64 a0 = 0, a1 = 0;
+                    for (int sgn = 0; sgn < 2; ++sgn) {
+                        u64 w = sgn ? sO : sN;
+                        while (w != 0) {
+                            int2 v[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const bool on = w != 0;  // (wave-uniform)
+                                const int j = on ? (int)__builtin_ctzll(w) : 0;
+                                w = on ? (w & (w - 1)) : w;
+                                v[k] = (on && lane < NC) ? lrows[j * RW + lane] : make_int2(0, 0);
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                a0 += sgn ? -(i64)v[k].x : (i64)v[k].x;
+                                a1 += sgn ? -(i64)v[k].y : (i64)v[k].y;
+                            }
+                        }
+                    }
+                    i64* dst = key < fz.M ? fz.rows + (size_t)key * RS : fz.fam + (size_t)(key - fz.M) * RS;
+                    if (lane < NC) {
+                        if (a0 != 0) atomicAdd((u64*)&dst[2 * lane], (u64)a0);
+                        if (a1 != 0) atomicAdd((u64*)&dst[2 * lane + 1], (u64)a1);
+                    } else if (lane == NC) {
+                        const i64 cnt = (i64)__builtin_popcountll(sN) - (i64)__builtin_popcountll(sO);
+                        if (cnt != 0) atomicAdd((u64*)&dst[2 * NC], (u64)cnt);
+                    }
+                    mN &= ~sN;
+                    mO &= ~sO;
+#ifdef E2VQ_SWEEP_STAMP
+                    sw_acc[7] += 1;  // (rows added to: a count, not cycles)
+#endif
+                }
+            }
+        }
 #ifdef E2VQ_SWEEP_STAMP
         {   // (merge, certification, store -- without the drain: the B loads just issued belong to the next block's stamp 0)
             const unsigned long long sw_now = __builtin_amdgcn_s_memtime();
@@ -514,6 +773,14 @@ __global__ __launch_bounds__(512, 2) void k_sweep_cand(const unsigned char* __re
     if (counters && lane == 0 && njobs) {
         atomicAdd(&counters->flagged, nflag);
         atomicAdd(&counters->jobs, njobs);
+    }
+    if constexpr (FUSE) {  // the wave's distortion sums -> the distortion columns of one row (any row: totals only)
+        i64 v[4] = {dacc0, dacc1, dacc2, dacc3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            for (int dd = 32; dd >= 1; dd >>= 1) v[k] += __shfl_xor(v[k], dd, 64);
+            if (lane == 0 && v[k] != 0) atomicAdd((u64*)&fz.rows[(long)(wave % (32 * MT)) * RS + 2 * NC + 1 + k], (u64)v[k]);
+        }
     }
 }
 
@@ -785,6 +1052,18 @@ void launch_sweep_frames(const double* aos, long T, long nblocks64, int NC, cons
     }
 }
 
+__global__ void k_sweep_counters_out(SweepCounters* counters, unsigned long long* host)
+{
+    __hip_atomic_store(host, counters->flagged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host + 1, counters->jobs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    counters->flagged = 0;
+    counters->jobs = 0;
+}
+void launch_sweep_counters_out(void* counters, void* host_counters, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sweep_counters_out, dim3(1), dim3(1), 0, s, (SweepCounters*)counters, (unsigned long long*)host_counters);
+}
+
 size_t sort_scratch_bytes() { return (size_t)2 * SORT_MAX_BINS * sizeof(int) + sizeof(SweepCounters); }
 
 // scratch: sort_scratch_bytes() bytes, zeroed once by the caller when it is allocated (the kernels leave the histogram zeroed)
@@ -818,18 +1097,77 @@ int launch_sweep_candidates(int NC, bool two_stage, const void* fimg, const unsi
     if (MT > 256) return 1;
     long g = (nblocks + 7) / 8;
     const int grid = (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+    const SweepFuse none{};
     switch (NC) {
 #define X(N)                                                                                                           \
     case N:                                                                                                            \
         if (two_stage)                                                                                                 \
-            hipLaunchKernelGGL((k_sweep_cand<N, true>), dim3(grid), dim3(512), 8 * 256 * 4, s, (const unsigned char*)fimg, perm, T, \
-                               nblocks, (const h8*)cimg, (const PreScalars*)ps, MT, idxmask, prev_sym, home_mul, cand,  \
-                               (SweepCounters*)counters);                                                              \
+            hipLaunchKernelGGL((k_sweep_cand<N, true, false>), dim3(grid), dim3(512), 8 * 512, s, (const unsigned char*)fimg, perm, T, \
+                               nblocks, (const h8*)cimg, (PreScalars*)ps, MT, idxmask, prev_sym, home_mul, cand,       \
+                               (SweepCounters*)counters, none);                                                        \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_sweep_cand<N, false>), dim3(grid), dim3(512), 8 * 256 * 4, s, (const unsigned char*)fimg, perm, T, \
-                               nblocks, (const h8*)cimg, (const PreScalars*)ps, MT, idxmask, prev_sym, home_mul, cand,  \
-                               (SweepCounters*)counters);                                                              \
+            hipLaunchKernelGGL((k_sweep_cand<N, false, false>), dim3(grid), dim3(512), 8 * 512, s, (const unsigned char*)fimg, perm, T, \
+                               nblocks, (const h8*)cimg, (PreScalars*)ps, MT, idxmask, prev_sym, home_mul, cand,       \
+                               (SweepCounters*)counters, none);                                                        \
         return 0;
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        default: return 1;
+    }
+}
+
+// the fused pass over grouped frames (perm from launch_sort_by_cell): sweep, exact evaluation, outputs, cell sums.  `cells`
+// holds every frame's cell of the previous pass (incr 1) or of the parents (incr 2) and receives the new ones.
+template <int NC>
+static int launch_pass_sorted_t(bool two_stage, const void* fimg, const unsigned* perm, long T, long nblocks, const void* cimg, void* ps,
+                                int M, const SweepFuse& fz, void* counters, hipStream_t s)
+{
+    if constexpr (SweepLds<NC>::FUSE_OK) {
+        int bits = 0;
+        while ((1 << bits) < M) ++bits;
+        const int idxmask = ~((1 << bits) - 1);
+        const int MT = M / 32;
+        constexpr int W = SweepLds<NC>::WAVES_FUSE;
+        long g = (nblocks + W - 1) / W;
+        const int grid = (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+        const size_t lds = (size_t)W * SweepLds<NC>::WAVE_BYTES_FUSE;
+        auto go = [&](auto kernel) {
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E2VQ_LDS_BYTES);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(W * 64), lds, s, (const unsigned char*)fimg, perm, T, nblocks, (const h8*)cimg,
+                               (PreScalars*)ps, MT, idxmask, (const unsigned short*)fz.cells, fz.incr, (unsigned*)nullptr,
+                               (SweepCounters*)counters, fz);
+        };
+        if (two_stage)
+            go(k_sweep_cand<NC, true, true>);
+        else
+            go(k_sweep_cand<NC, false, true>);
+        return 0;
+    }
+    return 1;
+}
+
+int launch_pass_sorted(int NC, bool two_stage, const void* fimg, const unsigned* perm, long T, long nblocks, const void* cimg, void* ps,
+                       const double* cbq, int M, const double* aos, const DevScalars* sc, const unsigned long long* l1max_bits,
+                       unsigned short* sym, double* dmin, long long* rows, long long* fam, int* fb_list, unsigned short* cells, int incr,
+                       void* counters, hipStream_t s)
+{
+    if (!sweep_supported(NC, M) || M / 32 > 256 || !perm || !cells || incr == 0 || (incr == 2 && !fam)) return 1;
+    SweepFuse fz{};
+    fz.aos = aos;
+    fz.cbq = cbq;
+    fz.sc = sc;
+    fz.l1max_bits = (const u64*)l1max_bits;
+    fz.sym = sym;
+    fz.dmin = dmin;
+    fz.rows = (i64*)rows;
+    fz.fam = (i64*)fam;
+    fz.fb_list = fb_list;
+    fz.cells = cells;
+    fz.incr = incr;
+    fz.M = M;
+    switch (NC) {
+#define X(N) \
+    case N: return launch_pass_sorted_t<N>(two_stage, fimg, perm, T, nblocks, cimg, ps, M, fz, counters, s);
         E2VQ_PRE_NC_LIST(X)
 #undef X
         default: return 1;

@@ -20,7 +20,7 @@ with e.VqSession(P) as s:
     s.prepare()
     s.init_codebook()
     s.learn(0.05, 64)
-    names = ["wait for B", "stage 1", "stage 2", "merge+store"]
+    names = ["wait for B", "stage 1", "stage 2", "rest of the block (fused: reduction)", "rows request", "evaluation", "outputs"]
     for M in (128, 256, 512, 1024):
         s.grow()
         for p in range(3):
@@ -33,9 +33,9 @@ with e.VqSession(P) as s:
             st = s.pass_stats()
             s.update()
             n = max(1, buf[8])
-            per = [buf[k] / n for k in range(4)]
+            per = [buf[k] / n for k in range(7)]
             tot = sum(per)
-            print(f"M {M:5d} pass {p + 1}: pass kernels {ms:.3f} ms; cycles per block and wave (s_memtime ticks, 100 MHz): " +
-                  ", ".join(f"{nm} {v:8.1f}" for nm, v in zip(names, per)) + f"; total {tot:8.1f}; flagged jobs {buf[10] / max(1, buf[11]):.3f}",
-                  flush=True)
+            print(f"M {M:5d} pass {p + 1}: pass kernels {ms:.3f} ms; cycles per block and wave: " +
+                  ", ".join(f"{nm} {v:8.1f}" for nm, v in zip(names, per)) + f"; total {tot:8.1f}; rows added to per block {buf[7] / n:.2f}; "
+                  f"flagged jobs {buf[10] / max(1, buf[11]):.3f}", flush=True)
         s.set_prev_distortion(st.DD)
