@@ -91,6 +91,7 @@ _sig("e2vq_timing_sweep_total", C.c_int, C.c_void_p, C.POINTER(C.c_double), C.PO
 _sig("e2vq_iterate", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LevelStatsC))
 _sig("e2vq_last_pass_info", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64))
 _sig("e2vq_last_pass_records", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64))
+_sig("e2vq_last_pass_sweep", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double))
 _sig("e2vq_set_prev_distortion", C.c_int, C.c_void_p, C.c_double)
 _sig("e2vq_get_prev_distortion", C.c_int, C.c_void_p, C.POINTER(C.c_double))
 _sig("e2vq_sweep_launch_counts", C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))

@@ -209,6 +209,7 @@ struct e2vq_session {
     // sweep, and above two_stage_max_frac the rest of the level (and the next one) runs the one-stage sweep.
     bool sweep2_enabled = true;
     bool fused_enabled = true;       // ECOZ2_VQ_FUSED_SORTED=0: grouped passes as sweep + finishing kernel + reduce too (A/B)
+    int fused_min_M = 256;           // ECOZ2_VQ_FUSED_MIN_M
     bool two_stage_enabled = true;   // ECOZ2_VQ_TWO_STAGE=0: one-stage sweep always
     double two_stage_max_frac = 0.45;
     int two_stage_off_until_M = 0;   // one-stage sweeps while M <= this
@@ -219,6 +220,8 @@ struct e2vq_session {
     void* d_sort = nullptr;
     int perm_M = 0;                  // codebook size d_perm was sorted for (0: none)
     double last_flagged_frac = -1.0;
+    int last_kind = 0;               // e2vq_last_pass_sweep
+    bool last_two_stage = false;
     i64* d_rows_local = nullptr;  // world > 1: the un-reduced rows (d_rows holds the all-reduced copy)
     int rows_local_cap = 0;
     // the seeded first pass of a level (vq_device.hip: k_seed_family): the rank's own rows of the last pass at the previous
@@ -365,6 +368,7 @@ static int session_init(e2vq_session* s)
     if (const char* sw = getenv("ECOZ2_VQ_SPLIT_SWEEP")) s->sweep2_enabled = atoi(sw) != 0;
     if (const char* sw = getenv("ECOZ2_VQ_TWO_STAGE")) s->two_stage_enabled = atoi(sw) != 0;
     if (const char* sw = getenv("ECOZ2_VQ_FUSED_SORTED")) s->fused_enabled = atoi(sw) != 0;
+    if (const char* sw = getenv("ECOZ2_VQ_FUSED_MIN_M")) s->fused_min_M = std::max(64, atoi(sw));
     // With the recorded accumulate the prefiltered pass also wins at M = 128 (0.36 vs 0.43 ms per pass on 2^21 frames; not
     // at 64: 0.30 vs 0.28), and a seeded first pass halves the records of every prefiltered level's first pass
     if (s->rec_enabled && e2vq::prefilter_lds_stage(s->NC)) {
@@ -918,6 +922,8 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     }
     const int mode = pass_mode(s);
     s->last_prefiltered = use_prefilter(s, mode);
+    s->last_kind = s->last_prefiltered ? 1 : 0;  // (the split / fused branches below set 2 / 3)
+    s->last_two_stage = false;
     const bool collective = s->allreduce && (s->world > 1 || s->ar_force || getenv("ECOZ2_VQ_FORCE_ALLREDUCE"));
     const bool keep = s->last_prefiltered && mode != 0 && s->incr_enabled;  // rows and cells persist for the next pass
     i64* rows = s->d_rows;
@@ -939,8 +945,10 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     s->fam_pending = false;
     // round 5: the frames are grouped by cell (a seeded first pass, or an incremental one) -> the fused sorted pass: sweep,
     // exact evaluation, outputs and the cell sums reduced in the block, one kernel (vq_sweep.hip); no records
+    // (from fused_min_M codewords on: at M = 128 a pass is bound by reading its frames, which round 4's kernel does in
+    // their natural order -- 0.35 against 0.40 ms on 2^21 frames; at 256 the two are level, beyond it the sorted pass wins)
     const bool fused = keep && !split && mode != 0 && (family || incremental) && s->sweep2_enabled && s->fused_enabled && s->d_fimgF &&
-                       s->d_aos && e2vq::sweep_supported(s->NC, s->M);
+                       s->d_aos && s->M >= s->fused_min_M && e2vq::sweep_supported(s->NC, s->M);
     // round 4: contributions recorded by the sweep, folded into the rows by k_reduce_records
     e2vq::PassRecords recplan{};
     bool records = false;
@@ -953,7 +961,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         if (!incremental) {
             s->rec_level_burst = false;
             s->rec_last_total = -1;
-        } else if (records && !(s->sweep2_enabled && s->d_fimgF) && s->rec_few_div > 0 && e2vq::prefilter_burst_supported(s->NC) &&
+        } else if (records && !(s->sweep2_enabled && s->d_fimgF && s->M >= s->fused_min_M) && s->rec_few_div > 0 && e2vq::prefilter_burst_supported(s->NC) &&
                    (s->rec_level_burst || (s->rec_last_total >= 0 && s->rec_last_total < s->T / s->rec_few_div))) {
             s->rec_level_burst = true;
             records = false;
@@ -1088,6 +1096,9 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             const bool two = s->two_stage_enabled && s->M >= 256 && s->M > s->two_stage_off_until_M;
             // the flagged fraction is looked at once per level: on its first pass
             const bool count = two && incr == 2;
+            s->last_kind = 3;
+            s->last_two_stage = two;
+            if (incr == 2) s->last_flagged_frac = -1.0;
             if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));  // (again: behind the sort)
             if (e2vq::launch_pass_sorted(s->NC, two, s->d_fimgF, s->d_perm, s->T, s->nblocks, d_cimg, d_ps, s->d_cbq, s->M, s->d_aos,
                                          s->d_sc, s->d_l1max, (unsigned short*)device_sym, (double*)device_dmin, rows,
@@ -1109,7 +1120,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
                                        (double*)device_dmin, rows, s->d_fblist, e2vq::prefilter_fallback_count(d_ps), s->d_prev_sym,
                                        incr, s->stream);
             if (family) e2vq::launch_family_fixup(rows, s->d_fam, s->fam_M, s->NC, s->stream);
-        } else if (records && s->sweep2_enabled && s->d_fimgF && e2vq::sweep_supported(s->NC, s->M)) {
+        } else if (records && s->sweep2_enabled && s->d_fimgF && s->M >= s->fused_min_M && e2vq::sweep_supported(s->NC, s->M)) {
             // round 5: [sort] -> candidate sweep -> finishing kernel (exact evaluation, outputs, records) -> reduce
             const int incr = family ? 2 : (incremental ? 1 : 0);
             if (incr != 0 && (incr == 2 || s->perm_M != s->M)) {
@@ -1121,6 +1132,8 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             const bool sorted = incr != 0 && s->perm_M == s->M;
             // (two stages need tiles to skip: from eight tiles on; below, the home tile alone is a quarter or half of the codebook)
             const bool two = sorted && s->two_stage_enabled && s->M >= 256 && s->M > s->two_stage_off_until_M;
+            s->last_kind = 2;
+            s->last_two_stage = two;
             if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));  // (again: the sweep kernel alone is what ev0..ev_mid brackets)
             if (e2vq::launch_sweep_candidates(s->NC, two, s->d_fimgF, sorted ? s->d_perm : nullptr, s->T, s->nblocks, d_cimg, d_ps, s->M,
                                               sorted ? s->d_prev_sym : nullptr, sorted ? incr : 0, s->d_cand,
@@ -1213,6 +1226,14 @@ extern "C" int e2vq_last_pass_records(e2vq_session* s, int* recorded, int64_t* r
 {
     if (recorded) *recorded = s->last_recorded ? 1 : 0;
     if (records) *records = s->rec_last_total;
+    return 0;
+}
+
+extern "C" int e2vq_last_pass_sweep(e2vq_session* s, int* kind, int* two_stage, double* flagged_fraction)
+{
+    if (kind) *kind = s->last_prefiltered ? s->last_kind : 0;
+    if (two_stage) *two_stage = s->last_two_stage ? 1 : 0;
+    if (flagged_fraction) *flagged_fraction = s->last_flagged_frac;
     return 0;
 }
 

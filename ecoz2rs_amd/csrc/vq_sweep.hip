@@ -278,7 +278,7 @@ __device__ __forceinline__ void sweep_full_job(const h8 (&A)[PrePack<NC>::NU], c
 // counter at the phase ends so that a phase pays for the loads it waits on.  Never defined in the product build.
 #ifdef E2VQ_SWEEP_STAMP
 __device__ unsigned long long g_sweep_stamps[16];
-#define SW_STAMP_DECL unsigned long long sw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sw_t = __builtin_amdgcn_s_memtime(), sw_n = 0;
+#define SW_STAMP_DECL unsigned long long sw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sw_conv = 0, sw_t = __builtin_amdgcn_s_memtime(), sw_n = 0;
 #define SW_STAMP(i)                                                                          \
     {                                                                                        \
         if (E2VQ_SWEEP_STAMP == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
@@ -447,7 +447,7 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
             // (the lane index afresh from the hardware: computed from the kernel's `lane`, every instruction's slot and piece
             // are invariants of the block loop -- hoisted, kept in 2 RP registers for the whole kernel, and spilled)
             const int lane_q = pre_fresh_lane();
-#pragma unroll
+#pragma unroll 1
             for (int k = 0; k < SL::RP; ++k) {
                 const unsigned q = (unsigned)(k * 64 + lane_q);
                 const unsigned slot = q / (unsigned)SL::RP, pc = q - slot * (unsigned)SL::RP;
@@ -710,9 +710,18 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // lane n < NC: the limb pair of coefficient n; four member frames at a time, their reads in flight together
-                const int2* lrows = (const int2*)wlds;
-                constexpr int RW = SL::ROW_BYTES / 8;
+#ifdef E2VQ_SWEEP_STAMP
+                {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const unsigned long long sw_now = __builtin_amdgcn_s_memtime();
+                    sw_conv += sw_now - sw_t;
+                    sw_t = sw_now;
+                }
+#endif
+                // lane e < 2 NC: limb e of the row (2 n = hi, 2 n + 1 = lo of coefficient n); rows of more than 32 coefficients:
+                // the limbs beyond the 64th ride in a second value of the lanes e < 2 NC - 64
+                const int* lrows = (const int*)wlds;
+                constexpr int RW = SL::ROW_BYTES / 4;
                 while ((mN | mO) != 0) {
                     const int key = mN != 0 ? __builtin_amdgcn_readlane(keyN, (int)__builtin_ctzll(mN))
                                             : __builtin_amdgcn_readlane(oldc, (int)__builtin_ctzll(mO));
@@ -721,26 +730,18 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
                     for (int sgn = 0; sgn < 2; ++sgn) {
                         u64 w = sgn ? sO : sN;
                         while (w != 0) {
-                            int2 v[4];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const bool on = w != 0;  // (wave-uniform)
-                                const int j = on ? (int)__builtin_ctzll(w) : 0;
-                                w = on ? (w & (w - 1)) : w;
-                                v[k] = (on && lane < NC) ? lrows[j * RW + lane] : make_int2(0, 0);
-                            }
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                a0 += sgn ? -(i64)v[k].x : (i64)v[k].x;
-                                a1 += sgn ? -(i64)v[k].y : (i64)v[k].y;
-                            }
+                            const int j = (int)__builtin_ctzll(w);
+                            w &= w - 1;
+                            const int v0 = lane < 2 * NC ? lrows[j * RW + lane] : 0;
+                            const int v1 = (2 * NC > 64 && lane < 2 * NC - 64) ? lrows[j * RW + 64 + lane] : 0;
+                            a0 += sgn ? -(i64)v0 : (i64)v0;
+                            a1 += sgn ? -(i64)v1 : (i64)v1;
                         }
                     }
                     i64* dst = key < fz.M ? fz.rows + (size_t)key * RS : fz.fam + (size_t)(key - fz.M) * RS;
-                    if (lane < NC) {
-                        if (a0 != 0) atomicAdd((u64*)&dst[2 * lane], (u64)a0);
-                        if (a1 != 0) atomicAdd((u64*)&dst[2 * lane + 1], (u64)a1);
-                    } else if (lane == NC) {
+                    if (lane < 2 * NC && a0 != 0) atomicAdd((u64*)&dst[lane], (u64)a0);
+                    if (2 * NC > 64 && lane < 2 * NC - 64 && a1 != 0) atomicAdd((u64*)&dst[64 + lane], (u64)a1);
+                    if (lane == 63) {
                         const i64 cnt = (i64)__builtin_popcountll(sN) - (i64)__builtin_popcountll(sO);
                         if (cnt != 0) atomicAdd((u64*)&dst[2 * NC], (u64)cnt);
                     }
@@ -768,6 +769,7 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
         atomicAdd(&g_sweep_stamps[9], 1ull);
         atomicAdd(&g_sweep_stamps[10], nflag);
         atomicAdd(&g_sweep_stamps[11], njobs);
+        atomicAdd(&g_sweep_stamps[12], sw_conv);
     }
 #endif
     if (counters && lane == 0 && njobs) {

@@ -270,6 +270,13 @@ class VqSession:
         check(lib.e2vq_last_pass_records(self._h, C.byref(r), C.byref(n)))
         return bool(r.value), n.value
 
+    def last_pass_sweep(self):
+        """(kind: 0 plain, 1 round-4 fused kernel, 2 candidate sweep + finish + reduce, 3 fused pass over grouped frames;
+        two-stage?; flagged fraction of the level's first two-stage pass or -1)"""
+        k, t, f = C.c_int(), C.c_int(), C.c_double()
+        check(lib.e2vq_last_pass_sweep(self._h, C.byref(k), C.byref(t), C.byref(f)))
+        return k.value, bool(t.value), f.value
+
     def last_pass_info(self):
         """(prefiltered sweep used?, frames it left to the full FP64 sweep) of the last run_pass."""
         used, n = C.c_int(), C.c_int64()

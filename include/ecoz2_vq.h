@@ -201,6 +201,12 @@ int e2vq_last_pass_info(e2vq_session *s, int *prefiltered, int64_t *fallback_fra
  * itself); *records = how many the last recorded pass of this level wrote (-1: none yet; valid once e2vq_pass_stats has
  * returned for that pass).  Few records switch the rest of a level to the burst of atomics (ECOZ2_VQ_RECORDS_FEW_DIV). */
 int e2vq_last_pass_records(e2vq_session *s, int *recorded, int64_t *records);
+/* how the last e2vq_pass swept (round 5): *kind = 0 plain FP64 sweep, 1 round 4's fused prefiltered kernel, 2 candidate sweep +
+ * finishing kernel + reduce (frames in their natural order), 3 the fused pass over frames grouped by cell; *two_stage = 1
+ * when the sweep ran its coarse stage first; *flagged_fraction = share of the (tile, column block) jobs the level's first
+ * two-stage pass had to finish with all weight levels (-1: not measured at this level; valid once e2vq_pass_stats has
+ * returned for that pass) */
+int e2vq_last_pass_sweep(e2vq_session *s, int *kind, int *two_stage, double *flagged_fraction);
 /* number of training-pass sweep launches so far, by kernel family (k_pass_pre / k_pass_mfma+generic): lets a
  * kernel trace of a whole run be cut to the dispatches of a timed region */
 int e2vq_sweep_launch_counts(e2vq_session *s, int64_t *prefiltered, int64_t *plain);

@@ -21,4 +21,4 @@ if e:
     for l in e['levels']: print('   M %5d passes %d kernel %.3f step %.3f' % (l['M'], l['passes'], l['kernel_ms'], l['step_ms']))
 PY
 done
-ECOZ2VQ_LIB=$PWD/tools/probe/ab/stamp2/libecoz2vq.so timeout -k 10 300 python tools/probe/sweep_stamps.py > gpurun_out/rh_stamp2.txt 2>&1; echo "stamps rc $?"; grep "M  1024\|M   256" gpurun_out/rh_stamp2.txt | cut -c1-420
+true

@@ -36,6 +36,6 @@ with e.VqSession(P) as s:
             per = [buf[k] / n for k in range(7)]
             tot = sum(per)
             print(f"M {M:5d} pass {p + 1}: pass kernels {ms:.3f} ms; cycles per block and wave: " +
-                  ", ".join(f"{nm} {v:8.1f}" for nm, v in zip(names, per)) + f"; total {tot:8.1f}; rows added to per block {buf[7] / n:.2f}; "
+                  ", ".join(f"{nm} {v:8.1f}" for nm, v in zip(names, per)) + f"; limb conversion {buf[12] / n:8.1f}; total {tot + buf[12] / n:8.1f}; rows added to per block {buf[7] / n:.2f}; "
                   f"flagged jobs {buf[10] / max(1, buf[11]):.3f}", flush=True)
         s.set_prev_distortion(st.DD)
