@@ -63,7 +63,7 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                             long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
                             hipStream_t s, const double* rowmajor_frames = nullptr, const int* ea_fused = nullptr,
                             const double* resident_rowmajor = nullptr, long long* family_table = nullptr,
-                            bool assign_only = false, const struct PassRecords* records = nullptr);
+                            const struct PassRecords* records = nullptr);
 // records (accumulate, resident_rowmajor): the accumulating kernel RECORDS the frames that contribute instead of adding them
 // -- (frame, cell within its bin, sign) as 8 bytes into the region of (sweeping workgroup, bin of cells), positions from
 // per-workgroup LDS counters -- and launch_reduce_records folds them into the rows through LDS tables, one workgroup per
@@ -83,13 +83,6 @@ struct PassRecords {
 bool prefilter_records_plan(int NC, int M, bool family, long nblocks, PassRecords* plan, size_t* recs_bytes);
 int launch_reduce_records(int NC, const double* aos, const PassRecords& plan, bool few, const DevScalars* sc, long long* rows,
                           long long* family_table, hipStream_t s);
-// assign_only (accumulate = false, resident_rowmajor and sym given): the accumulating kernel's sweep, outputs and
-// distortion sums (into `rows`) without its cell sums; sym[t] = 0xFFFF marks a frame left to the fallback sweep.
-// launch_accumulate_ranges then adds the cell sums from the symbols, pre-aggregated per (chunk of frames, range of cells)
-// in LDS: cells_new from the sweep, cells_old (incremental) of the previous pass; only read -- swap the arrays afterwards.
-bool accumulate_ranges_supported(int NC);
-int launch_accumulate_ranges(int NC, const double* aos, long T, const unsigned short* cells_new, const unsigned short* cells_old,
-                             bool incremental, int M, const DevScalars* sc, long long* rows, hipStream_t s);
 // round 5 (vq_sweep.hip): the accumulating prefiltered pass as sort (once per level) + candidate sweep + finishing kernel +
 // launch_reduce_records.  sweep_supported: the order has a prefiltered sweep and its rows fit the finishing kernel's LDS.
 bool sweep_supported(int NC, int M);

@@ -173,19 +173,9 @@ struct e2vq_session {
     bool plain_first = true;  // first (full) pass of the smallest prefiltered levels on the plain hybrid kernel
     int incr_M = 0;
     unsigned short* d_prev_sym = nullptr;
-    // round 4: passes up to split_max_M codewords run as an assignment-only sweep + k_accum_ranges (cell sums pre-aggregated
-    // in LDS per chunk of frames and range of cells: vq_prefilter.hip); the sweep writes the new cells here, the accumulate
-    // reads both arrays, then they are swapped
-    unsigned short* d_cells_new = nullptr;
-    // ECOZ2_VQ_SPLIT_ACC_MAX_M (0 = never).  Measured on 2^21 frames (profiles/r04_split_accumulate.txt): the assignment-only
-    // sweep takes 0.37 / 0.55 / 0.93 ms at M = 256 / 512 / 1024 where the accumulating kernel takes 0.60-0.77 / 0.70-0.80 /
-    // 1.06-1.11, but k_accum_ranges costs 0.17-0.42 / 0.21-0.46 / 0.29-0.55 ms on top (a workgroup per chunk and cell
-    // range: its cost follows the number of ranges, not the number of movers): a gain at M = 256 only
-    int split_max_M = 256;
     // round 4: the RECORDED accumulate -- the accumulating sweep writes an 8-byte record per contribution into the region
     // of (sweeping workgroup, bin of cells), k_reduce_records folds the records into the rows through LDS tables
-    // (vq_prefilter.hip).  ECOZ2_VQ_RECORDS=0: the paths above (k_accum_ranges up to split_max_M, the fused burst of
-    // atomics beyond); ECOZ2_VQ_RECORDS_MAX_MB bounds the record buffer (default 8192: it is sized for the worst case, every
+    // (vq_prefilter.hip).  ECOZ2_VQ_RECORDS=0: the fused burst of atomics; ECOZ2_VQ_RECORDS_MAX_MB bounds the record buffer (default 8192: it is sized for the worst case, every
     // frame of a workgroup in one bin, i.e. 16 bytes x frames x bins)
     bool rec_enabled = true;
     int rec_min_M = 64;
@@ -263,7 +253,6 @@ struct e2vq_session {
     long ar_calls = 0, ar_bytes = 0;
 };
 
-static bool split_accumulate(const e2vq_session* s, int M);
 static int pass_mode(const e2vq_session* s);
 static bool use_prefilter(const e2vq_session* s, int mode);
 
@@ -359,7 +348,6 @@ static int session_init(e2vq_session* s)
     if (const char* pf1 = getenv("ECOZ2_VQ_PLAIN_FIRST")) s->plain_first = atoi(pf1) != 0;
     if (const char* fm = getenv("ECOZ2_VQ_FAMILY")) s->fam_enabled = atoi(fm) != 0;
     if (const char* fm = getenv("ECOZ2_VQ_FAMILY_MIN_M")) s->fam_min_M = std::max(64, atoi(fm));
-    if (const char* sm = getenv("ECOZ2_VQ_SPLIT_ACC_MAX_M")) s->split_max_M = std::max(0, atoi(sm));
     if (const char* se = getenv("ECOZ2_VQ_STATS_EVENT")) s->stats_event = atoi(se) != 0;
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS")) s->rec_enabled = atoi(rc) != 0;
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS_MIN_M")) s->rec_min_M = std::max(64, atoi(rc));
@@ -421,7 +409,7 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     void* ptrs[] = {s->d_cbT, s->sv.refl, s->sv.rows, s->sv.rows_local, s->sv.cells, s->d_rows_parent, s->d_fam, s->d_aos, s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
-                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg2[0], s->d_cimg2[1], s->d_ps2[0], s->d_ps2[1], s->d_ps, s->d_fblist, s->d_prev_sym, s->d_cells_new, s->d_rows_local, s->d_recs, s->d_rec_counts, s->d_fimgF, s->d_perm, s->d_cand, s->d_sort,
+                    s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg2[0], s->d_cimg2[1], s->d_ps2[0], s->d_ps2[1], s->d_ps, s->d_fblist, s->d_prev_sym, s->d_rows_local, s->d_recs, s->d_rec_counts, s->d_fimgF, s->d_perm, s->d_cand, s->d_sort,
                     s->d_ea_q, s->d_qfimg, s->d_qfg, s->d_qfblist, s->d_qcimg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -580,11 +568,9 @@ static int set_frames_device_impl(e2vq_session* s, const void* device_frames, in
         if (s->d_fg) HIPCHK(hipFree(s->d_fg));
         if (s->d_fblist) HIPCHK(hipFree(s->d_fblist));
         if (s->d_prev_sym) HIPCHK(hipFree(s->d_prev_sym));
-        if (s->d_cells_new) HIPCHK(hipFree(s->d_cells_new));
         if (s->d_aos) HIPCHK(hipFree(s->d_aos));
         s->d_aos = nullptr;
         s->d_prev_sym = nullptr;
-        s->d_cells_new = nullptr;
         s->d_fimg = nullptr;
         s->d_fg = nullptr;
         s->d_fblist = nullptr;
@@ -594,8 +580,7 @@ static int set_frames_device_impl(e2vq_session* s, const void* device_frames, in
         const bool fits = hipMalloc(&s->d_fimg, e2vq::prefilter_frame_image_bytes(s->NC, s->nblocks)) == hipSuccess &&
                           hipMalloc(&s->d_fg, (size_t)s->nblocks * 64 * sizeof(float)) == hipSuccess &&
                           hipMalloc(&s->d_fblist, (size_t)s->nblocks * 64 * sizeof(int)) == hipSuccess &&
-                          hipMalloc(&s->d_prev_sym, (size_t)s->nblocks * 64 * sizeof(unsigned short) + 256) == hipSuccess &&
-                          hipMalloc(&s->d_cells_new, (size_t)s->nblocks * 64 * sizeof(unsigned short) + 256) == hipSuccess;
+                          hipMalloc(&s->d_prev_sym, (size_t)s->nblocks * 64 * sizeof(unsigned short) + 256) == hipSuccess;
         // the accumulating prefiltered pass stages the FP64 frames of a block in LDS from a row-major copy (another 296 B
         // per frame; without it the pass keeps to the round-2 kernel, which reads the blocked layout)
         if (fits && e2vq::prefilter_lds_stage(s->NC)) {
@@ -649,7 +634,7 @@ static int set_frames_device_impl(e2vq_session* s, const void* device_frames, in
             }
         } else {
             (void)hipGetLastError();  // clear the out-of-memory status
-            for (void** p : {(void**)&s->d_fimg, (void**)&s->d_fg, (void**)&s->d_fblist, (void**)&s->d_prev_sym, (void**)&s->d_cells_new, (void**)&s->d_aos}) {
+            for (void** p : {(void**)&s->d_fimg, (void**)&s->d_fg, (void**)&s->d_fblist, (void**)&s->d_prev_sym, (void**)&s->d_aos}) {
                 if (*p) (void)hipFree(*p);
                 *p = nullptr;
             }
@@ -798,7 +783,7 @@ extern "C" int e2vq_grow(e2vq_session* s)
     const bool seed = s->fam_enabled && s->pre_enabled && s->d_aos && s->d_prev_sym && s->rows_fresh && s->rows_are_local &&
                       s->cells_M == s->M && 2 * s->M >= s->pre_min_M && 2 * s->M >= s->fam_min_M &&
                       e2vq::prefilter_supports(s->NC, 2 * s->M) &&
-                      e2vq::prefilter_lds_stage(s->NC) && s->incr_enabled && !split_accumulate(s, 2 * s->M);
+                      e2vq::prefilter_lds_stage(s->NC) && s->incr_enabled;
     if (seed) {
         if (s->fam_cap < s->M) {
             for (i64** p : {&s->d_rows_parent, &s->d_fam}) {
@@ -888,15 +873,6 @@ static bool records_plan(const e2vq_session* s, int M, bool family, e2vq::PassRe
     return true;
 }
 
-// assignment-only sweep + k_accum_ranges for accumulating prefiltered passes at this codebook size?
-static bool split_accumulate(const e2vq_session* s, int M)
-{
-    if (records_plan(s, M, false, nullptr, nullptr)) return false;
-    return s->pre_enabled && s->incr_enabled && s->d_aos && s->d_cells_new && s->d_prev_sym && M <= s->split_max_M &&
-           M >= s->pre_min_M && e2vq::prefilter_supports(s->NC, M) && e2vq::prefilter_lds_stage(s->NC) &&
-           e2vq::accumulate_ranges_supported(s->NC);
-}
-
 static int ensure_codebook_image(e2vq_session* s)
 {
     if (s->M <= s->cimg_cap) return 0;
@@ -938,23 +914,21 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         rows = s->d_rows_local;
     }
     const bool incremental = keep && s->incr_valid && s->incr_M == s->M;
-    // round 4: the sweep only assigns, k_accum_ranges adds the cell sums (full or incremental) through LDS tables
-    const bool split = keep && split_accumulate(s, s->M);
     // the first pass after a split, seeded with the parents' sums (e2vq_grow stashed them): k_seed_family
-    bool family = s->fam_pending && keep && !incremental && !split && s->d_aos && 2 * s->fam_M == s->M && mode != 0;
+    bool family = s->fam_pending && keep && !incremental && s->d_aos && 2 * s->fam_M == s->M && mode != 0;
     s->fam_pending = false;
     // round 5: the frames are grouped by cell (a seeded first pass, or an incremental one) -> the fused sorted pass: sweep,
     // exact evaluation, outputs and the cell sums reduced in the block, one kernel (vq_sweep.hip); no records
     // (from fused_min_M codewords on: at M = 128 a pass is bound by reading its frames, which round 4's kernel does in
     // their natural order -- 0.35 against 0.40 ms on 2^21 frames; at 256 the two are level, beyond it the sorted pass wins)
-    const bool fused = keep && !split && mode != 0 && (family || incremental) && s->sweep2_enabled && s->fused_enabled && s->d_fimgF &&
+    const bool fused = keep && mode != 0 && (family || incremental) && s->sweep2_enabled && s->fused_enabled && s->d_fimgF &&
                        s->d_aos && s->M >= s->fused_min_M && e2vq::sweep_supported(s->NC, s->M);
     // round 4: contributions recorded by the sweep, folded into the rows by k_reduce_records
     e2vq::PassRecords recplan{};
     bool records = false;
     if (fused) {
         s->last_recorded = false;
-    } else if (keep && !split && mode != 0) {
+    } else if (keep && mode != 0) {
         size_t bytes = 0;
         records = records_plan(s, s->M, family, &recplan, &bytes);
         // few records on the last pass of this level: the rest of the level adds its contributions as a burst
@@ -1002,7 +976,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     // The first pass of a level accumulates in full.  For the smallest prefiltered sizes that is cheaper on the plain
     // FP64 sweep with its workgroup-local LDS table (hybrid accumulate: 0.92 vs 1.5 ms at M = 256, where 2^21 frames
     // hammer 256 rows with global atomics); it records the cells for the incremental passes that follow.
-    const bool plain_first = s->plain_first && keep && !incremental && !family && !split && !records && !fused && mode == 5 && s->M <= 384;
+    const bool plain_first = s->plain_first && keep && !incremental && !family && !records && !fused && mode == 5 && s->M <= 384;
     if (s->last_prefiltered && !plain_first && ensure_codebook_image(s)) return 1;
     {
         // one prologue launch: the rows (all of them, or the distortion columns of an incremental pass), the fallback
@@ -1061,29 +1035,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         void* const d_ps = s->d_ps2[k];
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
         s->n_pre_launches++;
-        if (split) {
-            // cells: into the caller's array when there is one (the fallback sweep then replaces the 0xFFFF marks there), else
-            // into the session's second cell array
-            unsigned short* cells = device_sym ? (unsigned short*)device_sym : s->d_cells_new;
-            if (e2vq::launch_pass_prefiltered(s->NC, false, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, d_cimg, d_ps, s->d_cbq,
-                                              s->M, s->d_sc, s->d_l1max, cells, (double*)device_dmin, rows, s->d_fblist, nullptr,
-                                              false, false, s->stream, nullptr, nullptr, s->d_aos, nullptr, /*assign_only=*/true))
-                return e2vq_set_error("assignment-only prefiltered sweep: unsupported configuration");
-            if (e2vq::launch_accumulate_ranges(s->NC, s->d_aos, s->T, cells, s->d_prev_sym, incremental, s->M, s->d_sc, rows, s->stream))
-                return e2vq_set_error("k_accum_ranges: unsupported prediction order");
-            if (s->timing) {  // (the pass's two kernels together: what the one accumulating kernel is elsewhere)
-                HIPCHK(hipEventRecord(s->ev1, s->stream));
-                s->timed = true;
-                s->timing_pending = true;
-            }
-            e2vq::launch_pass_fallback(s->NC, true, s->d_blk, s->d_cbm, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
-                                       (double*)device_dmin, rows, s->d_fblist, e2vq::prefilter_fallback_count(d_ps), s->d_prev_sym,
-                                       incremental ? 1 : 0, s->stream, false, /*cells_out=*/cells);
-            if (device_sym)
-                HIPCHK(hipMemcpyAsync(s->d_prev_sym, device_sym, (size_t)s->T * sizeof(unsigned short), hipMemcpyDeviceToDevice, s->stream));
-            else
-                std::swap(s->d_prev_sym, s->d_cells_new);
-        } else if (fused) {
+        if (fused) {
             // round 5, frames grouped: [sort] -> ONE kernel (two-stage sweep, exact evaluation, outputs, cell sums in the block)
             const int incr = family ? 2 : 1;
             if (incr == 2 || s->perm_M != s->M) {
@@ -1165,12 +1117,11 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
                                        incr, s->stream);
             if (family) e2vq::launch_family_fixup(rows, s->d_fam, s->fam_M, s->NC, s->stream);
         } else {
-        if (e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, d_cimg, d_ps,
+            if (e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, d_cimg, d_ps,
                                           s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                                           (double*)device_dmin, rows, s->d_fblist, keep ? s->d_prev_sym : nullptr,
                                           incremental, /*hybrid_table=*/mode == 5 && !incremental && !family && !records, s->stream,
-                                          nullptr, nullptr, s->d_aos, family ? s->d_fam : nullptr, false,
-                                          records ? &recplan : nullptr))
+                                          nullptr, nullptr, s->d_aos, family ? s->d_fam : nullptr, records ? &recplan : nullptr))
             return e2vq_set_error("prefiltered sweep: unsupported configuration");
         if (records && s->timing) {
             HIPCHK(hipEventRecord(s->ev_mid, s->stream));
@@ -1189,7 +1140,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
                                    e2vq::prefilter_fallback_count(d_ps), keep ? s->d_prev_sym : nullptr,
                                    family ? 2 : (incremental ? 1 : 0), s->stream);
         if (family) e2vq::launch_family_fixup(rows, s->d_fam, s->fam_M, s->NC, s->stream);
-        }  // !split
+        }
     } else {
         if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
         s->n_plain_launches++;

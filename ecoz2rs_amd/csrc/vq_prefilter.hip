@@ -813,14 +813,13 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
     // cell are moved); 2 = the seeded first pass of a level (vq_device.hip, k_seed_family): a frame's old cell is the even
     // child 2 * prev_sym of the cell it had at the previous size; one that lands in the odd child 2 * prev_sym + 1 adds its
     // limbs to row prev_sym of the side table `fam` and nothing else
-    // ACC = 0 (round 4): the pass only assigns -- `sym` receives every frame's cell, 0xFFFF for a frame left to the
-    // fallback sweep -- and adds the distortion sums; k_accum_ranges does the cell sums from the symbols (incr, prev_sym and
-    // fam are not used).  ACC = 1: the cell sums as a burst of atomics per block.  ACC = 2: the contributions are RECORDED
+    // ACC = 1: the cell sums as a burst of atomics per block.  ACC = 2: the contributions are RECORDED
     // -- 8 bytes each, into the region of (this workgroup, bin of cells) -- and k_reduce_records adds them up (`fam` is
     // not used: a frame that lands in the odd child of its family is recorded for the side table's bin)
     typedef PrePack<NC> PK;
     typedef PreLds<NC> PL;
     constexpr int TPBM = PL::WAVES * 64;
+    static_assert(ACC == 1 || ACC == 2, "burst of atomics or records");
     static_assert(ACC != 1 || PL::BURST_OK, "rows of more than 80 elements are recorded, not added in a burst");
     constexpr int NU = PK::NU;
     constexpr int RS = (2 * NC + 5 + 7) & ~7, NPAD = (NC + 7) & ~7;
@@ -1043,7 +1042,6 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         if (live) {
             if (skip) {
                 fb_list[atomicAdd(&ps->fb_count, 1)] = (int)t;
-                if (!ACCUM) sym[t] = (unsigned short)0xFFFF;  // (k_accum_ranges leaves this frame to the fallback sweep)
             } else {
                 if (sym) sym[t] = (unsigned short)idx;
                 if (dmin) dmin[t] = best;
@@ -1248,128 +1246,6 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         }
     }
 #endif
-}
-
-// ---- k_accum_ranges (round 4): the accumulate of a prefiltered pass as a kernel of its own, pre-aggregated in LDS --------
-// What bounds the accumulate inside the sweep kernel is the memory side: every frame that contributes costs 600 B of int64
-// atomic traffic (1 200 B for a mover of an incremental pass), the chip retires ~1.3 TB/s of it, and a wave's burst sits in
-// its in-order vector-memory queue in front of the next block's operands.  Here the sweep only ASSIGNS (k_pass_pre_lds<.., false>:
-// symbols out, 0xFFFF for a frame it could not certify); this kernel then adds the frames to their cells through a table
-// in LDS and touches global memory once per (chunk of frames, cell) instead of once per (frame, cell):
-//   grid = chunks x ranges.  A workgroup owns the cells [lo, hi) of one range (at most ACC_RANGE_CELLS: the table fills the
-//   CU's LDS) and one contiguous chunk of frames; it reads the chunk's new and old cells (2 + 2 B per frame), and for every
-//   frame that adds to a cell of its range (full pass: new cell in range; incremental: moved INTO the range) or leaves one
-//   (incremental: moved OUT of it) loads the frame's row (296 B, coalesced), converts it to limbs and ds_add's them --
-//   negated for a leaver -- into the table; at the end the non-zero words go to the global rows as one atomic each.
-// Exact 64-bit integers throughout: the rows equal those of any other order of accumulation bit for bit.
-// Atomic traffic of an M = 256 pass over 2^21 frames: 42 MB (256 chunks x 256 cells x 640 B) instead of 450-600 MB.
-// The cells of the previous pass are only READ here (several workgroups look at the same frame): the caller swaps the two
-// cell arrays afterwards; frames with the 0xFFFF mark are the fallback sweep's business (it accumulates them itself).
-constexpr int ACC_RANGE_CELLS = 120;  // x 640 B (NC = 37) = 77 KB: two workgroups per CU
-constexpr int ACC_TPB = 1024;         // 16 waves per workgroup: the row loads of one wave hide under the others' LDS adds
-constexpr int ACC_BATCH = 8;          // rows requested together by a wave (the loads of a batch are all in flight at once)
-
-template <int NC>
-__global__ __launch_bounds__(ACC_TPB, 2) void k_accum_ranges(const double* __restrict__ aos, long T, long chunk_frames,
-                                                          const unsigned short* __restrict__ cells_new,
-                                                          const unsigned short* __restrict__ cells_old, int incremental,
-                                                          int M, int range_cells, const DevScalars* __restrict__ sc,
-                                                          i64* __restrict__ rows)
-{
-    constexpr int RS = (2 * NC + 5 + 7) & ~7;
-    constexpr int NE = 2 * NC + 1;       // limb pairs + count
-    constexpr bool TAIL = NE > 64;
-    constexpr int NT = TAIL ? NE - 64 : 0;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    i64* table = (i64*)smem;
-    const int nranges = (M + range_cells - 1) / range_cells;
-    const int g = (int)(blockIdx.x % (unsigned)nranges);
-    const long chunk = (long)(blockIdx.x / (unsigned)nranges);
-    const int lo = g * range_cells, hi = lo + range_cells < M ? lo + range_cells : M;
-    const int ncell = hi - lo;
-    for (int i = threadIdx.x; i < ncell * RS; i += ACC_TPB) table[i] = 0;
-    __syncthreads();
-    const int sh_r = sc->sh_r;
-    const bool fast_fix = sh_r >= -1000 && sh_r <= 1000;
-    const double scale_r = __longlong_as_double((long long)(1023 + (fast_fix ? sh_r : 0)) << 52);
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int tq = lane >> 4, te = lane & 15;
-    const long t_begin = chunk * chunk_frames, t_end = t_begin + chunk_frames < T ? t_begin + chunk_frames : T;
-    auto limb = [&](double x, int odd) -> int {
-        int h, l;
-        if (fast_fix)
-            fix2_mul(x, scale_r, h, l);
-        else
-            fix2(x, sh_r, h, l);
-        return odd ? l : h;
-    };
-    constexpr long STEP = 64L * (ACC_TPB / 64);
-    // the cells of the wave's next 64 frames are requested while the current ones are worked on
-    auto fetch = [&](long t0, int& cn, int& co) {
-        const long t = t0 + lane;
-        const bool live = t0 < t_end && t < t_end;
-        cn = live ? (int)cells_new[t] : 0xFFFF;
-        co = (live && incremental) ? (int)cells_old[t] : -1;
-    };
-    int cn_next, co_next;
-    fetch(t_begin + 64L * wib, cn_next, co_next);
-    for (long t0 = t_begin + 64L * wib; t0 < t_end; t0 += STEP) {
-        const int cn = cn_next, co = co_next;
-        fetch(t0 + STEP, cn_next, co_next);
-        const bool counts = cn != 0xFFFF && (!incremental || cn != co);  // contributes at all (frames beyond the chunk: 0xFFFF)
-        const bool add = counts && cn >= lo && cn < hi;
-        const bool sub = counts && incremental && co >= lo && co < hi;
-        // contributions of this wave's 64 frames: bit f of `adds` / `subs`, walked ACC_BATCH at a time (adds first)
-        u64 adds = __ballot(add), subs = __ballot(sub);
-        while ((adds | subs) != 0) {
-            int f[ACC_BATCH], cell[ACC_BATCH], sgn[ACC_BATCH];
-            bool on[ACC_BATCH];
-            double x[ACC_BATCH], xt[ACC_BATCH / 4];
-#pragma unroll
-            for (int k = 0; k < ACC_BATCH; ++k) {
-                const bool from_add = adds != 0;
-                u64& mm = from_add ? adds : subs;
-                on[k] = mm != 0;  // wave-uniform
-                f[k] = on[k] ? (int)__builtin_ctzll(mm) : 0;
-                mm = on[k] ? (mm & (mm - 1)) : mm;
-                sgn[k] = from_add ? 1 : -1;
-                cell[k] = __builtin_amdgcn_readlane(from_add ? cn : co, f[k]) - lo;
-                // lane e: element e = 2 n + limb of the frame's row (pairs of lanes read the same double: 296 contiguous bytes)
-                x[k] = (on[k] && lane < 2 * NC) ? aos[(t0 + f[k]) * NC + (lane >> 1)] : 0.0;
-            }
-            if constexpr (TAIL) {  // the row tails of four frames per instruction: 16 lanes each
-#pragma unroll
-                for (int q = 0; q < ACC_BATCH / 4; ++q) {
-                    const int tf = tq == 0 ? f[4 * q] : tq == 1 ? f[4 * q + 1] : tq == 2 ? f[4 * q + 2] : f[4 * q + 3];
-                    const bool ton = (tq == 0 ? on[4 * q] : tq == 1 ? on[4 * q + 1] : tq == 2 ? on[4 * q + 2] : on[4 * q + 3]);
-                    const int et = 64 + te;  // (te < NT - 1: a limb; te == NT - 1: the count)
-                    xt[q] = (ton && te < NT - 1) ? aos[(t0 + tf) * NC + (et >> 1)] : 0.0;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < ACC_BATCH; ++k) {
-                if (!on[k]) continue;  // wave-uniform
-                const int v = lane >= 2 * NC ? 1 : limb(x[k], lane & 1);  // (lane == 2 NC, short rows only: the count)
-                if (TAIL || lane < NE) atomicAdd((u64*)&table[cell[k] * RS + lane], (u64)((i64)sgn[k] * (i64)v));
-            }
-            if constexpr (TAIL) {
-#pragma unroll
-                for (int q = 0; q < ACC_BATCH / 4; ++q) {
-                    if (!on[4 * q]) continue;  // wave-uniform (the batch is filled in order)
-                    const bool ton = (tq == 0 ? on[4 * q] : tq == 1 ? on[4 * q + 1] : tq == 2 ? on[4 * q + 2] : on[4 * q + 3]) && te < NT;
-                    const int tcell = tq == 0 ? cell[4 * q] : tq == 1 ? cell[4 * q + 1] : tq == 2 ? cell[4 * q + 2] : cell[4 * q + 3];
-                    const int tsgn = tq == 0 ? sgn[4 * q] : tq == 1 ? sgn[4 * q + 1] : tq == 2 ? sgn[4 * q + 2] : sgn[4 * q + 3];
-                    const int tv = te >= NT - 1 ? 1 : limb(xt[q], (64 + te) & 1);
-                    if (ton) atomicAdd((u64*)&table[tcell * RS + 64 + te], (u64)((i64)tsgn * (i64)tv));
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < ncell * RS; i += ACC_TPB) {
-        const i64 v = table[i];
-        if (v != 0) atomicAdd((u64*)&rows[(long)lo * RS + i], (u64)v);
-    }
 }
 
 // ---- k_reduce_records (round 4): folds the records of an ACC = 2 pass into the rows ---------------------------------------
@@ -1794,8 +1670,7 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                                      const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym,
                                      double* dmin, long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental,
                                      bool hybrid_table, hipStream_t s, const double* aos, const int* ea_fused,
-                                     const double* aos_resident, long long* family_table, bool assign_only,
-                                     const PassRecords* records)
+                                     const double* aos_resident, long long* family_table, const PassRecords* records)
 {
     constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
     constexpr int TPBM = 512;  // 8 waves = 2 per SIMD, one persistent workgroup per CU
@@ -1812,8 +1687,7 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
         hipLaunchKernelGGL((k_pass_pre<NC, 5, TPBM>), dim3(grid), dim3(TPBM), lds5, s, blk, T, nblocks, (const h8*)fimg, fg,
                            (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
                            dmin, rows, fb_list, stagger, prev_sym, 0, (const double*)nullptr, (const int*)nullptr);
-    } else if ((accumulate || assign_only) && aos_resident && prefilter_lds_stage(NC) &&
-               (records || assign_only || PreLds<NC>::BURST_OK)) {
+    } else if (accumulate && aos_resident && prefilter_lds_stage(NC) && (records || PreLds<NC>::BURST_OK)) {
         // round 3: FP64 frames staged in LDS, lane-per-frame exact evaluation, one burst of atomics per block
         if constexpr (PreLds<NC>::OK) {
             const int MT = M / 32;
@@ -1842,15 +1716,7 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
             const bool rot = MT >= 4 && (MT & 1) == 0 && !simple;
             // (two register sets of codeword granules: up to nine granules per tile -- P = 40 has eleven and would spill)
             constexpr bool ROT_OK = PrePack<NC>::NU <= 9;
-            if (assign_only) {  // (the cell sums follow in launch_accumulate_ranges)
-                if constexpr (ROT_OK) {
-                    if (rot) {
-                        go(k_pass_pre_lds<NC, true, 0>);
-                        return 0;
-                    }
-                }
-                go(k_pass_pre_lds<NC, false, 0>);
-            } else if (records) {  // (the cell sums follow in launch_reduce_records)
+            if (records) {  // (the cell sums follow in launch_reduce_records)
                 if constexpr (ROT_OK) {
                     if (rot) {
                         go(k_pass_pre_lds<NC, true, 2>);
@@ -1906,12 +1772,10 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
                             long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
                             hipStream_t s, const double* rowmajor_frames, const int* ea_fused, const double* resident_rowmajor,
-                            long long* family_table, bool assign_only, const PassRecords* records)
+                            long long* family_table, const PassRecords* records)
 {
-    if (records && (!accumulate || assign_only || hybrid_table || !resident_rowmajor || !prefilter_lds_stage(NC) || !prev_sym)) return 1;
+    if (records && (!accumulate || hybrid_table || !resident_rowmajor || !prefilter_lds_stage(NC) || !prev_sym)) return 1;
     if (family_table && (!accumulate || hybrid_table || incremental || !resident_rowmajor || !prefilter_lds_stage(NC))) return 1;
-    // assign_only: the accumulating kernel's sweep and distortion sums without its cell sums (k_accum_ranges follows)
-    if (assign_only && (accumulate || !sym || !rows || !resident_rowmajor || !prefilter_lds_stage(NC) || ea_fused)) return 1;
     if (!prefilter_supports(NC, M) || (hybrid_table && incremental)) return 1;
     if (ea_fused && (accumulate || !rowmajor_frames || !prefilter_fused_quantize(NC))) return 1;
     switch (NC) {
@@ -1919,39 +1783,7 @@ int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, 
     case N:                                                                                                           \
         return launch_pass_prefiltered_t<N>(accumulate, blk, T, nblocks, fimg, fg, cimg, ps, cbq, M, sc, l1max_bits, sym, \
                                             dmin, rows, fb_list, prev_sym, incremental, hybrid_table, s, rowmajor_frames, \
-                                            ea_fused, resident_rowmajor, family_table, assign_only, records);
-        E2VQ_PRE_NC_LIST(X)
-#undef X
-        default: return 1;
-    }
-}
-
-// the cell sums of a pass whose sweep only assigned (k_pass_pre_lds<.., false>): cells_new[t] = the frame's cell (0xFFFF: left
-// to the fallback sweep), cells_old (incremental != 0) = its cell of the previous pass; adds into `rows` (which the caller
-// zeroed for a full pass)
-bool accumulate_ranges_supported(int NC) { return pre_has_nc(NC) && 2 * NC + 1 <= 80; }
-int launch_accumulate_ranges(int NC, const double* aos, long T, const unsigned short* cells_new, const unsigned short* cells_old,
-                             bool incremental, int M, const DevScalars* sc, long long* rows, hipStream_t s)
-{
-    const int RS = (2 * NC + 5 + 7) & ~7;
-    const int max_cells = (E2VQ_LDS_BYTES - 2048) / (RS * 8) < ACC_RANGE_CELLS ? (E2VQ_LDS_BYTES - 2048) / (RS * 8) : ACC_RANGE_CELLS;
-    const int nranges = (M + max_cells - 1) / max_cells;
-    const int range_cells = (M + nranges - 1) / nranges;
-    const long nchunks = T >= 256L * 1024 ? 256 : (T + 1023) / 1024;  // one chunk per CU, at least 1 024 frames each
-    const long chunk_frames = ((T + nchunks - 1) / nchunks + 63) / 64 * 64;
-    const long used_chunks = (T + chunk_frames - 1) / chunk_frames;
-    const size_t lds = (size_t)range_cells * RS * 8;
-    switch (NC) {
-#define X(N)                                                                                                          \
-    case N:                                                                                                           \
-        if constexpr (2 * N + 1 <= 80) {                                                                              \
-            (void)hipFuncSetAttribute((const void*)k_accum_ranges<N>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                      E2VQ_LDS_BYTES);                                                                \
-            hipLaunchKernelGGL((k_accum_ranges<N>), dim3((unsigned)(used_chunks * nranges)), dim3(ACC_TPB), lds, s, aos, T, \
-                               chunk_frames, cells_new, cells_old, incremental ? 1 : 0, M, range_cells, sc, (i64*)rows); \
-            return 0;                                                                                                 \
-        }                                                                                                             \
-        return 1;
+                                            ea_fused, resident_rowmajor, family_table, records);
         E2VQ_PRE_NC_LIST(X)
 #undef X
         default: return 1;

@@ -208,7 +208,7 @@ def test_learn_ladder_with_prefilter_matches_oracle(oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("M,prefilter", [(16, True), (64, False), (256, False), (256, True), (1024, False)])
-@pytest.mark.parametrize("accumulate", ["records", "ranges", "burst"])
+@pytest.mark.parametrize("accumulate", ["sorted", "sweep", "records", "burst"])
 @pytest.mark.parametrize("collective", [False, True])
 def test_incremental_rows_match_a_full_accumulation_every_pass(oracle, monkeypatch, collective, accumulate, M, prefilter):
     """Five passes at one codebook size with centroid updates in between: from the second pass on only the frames
@@ -217,13 +217,17 @@ def test_incremental_rows_match_a_full_accumulation_every_pass(oracle, monkeypat
     routes the rows through the all-reduce hook (own copy + reduced copy)."""
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER", "1" if prefilter else "0")
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
-    # the three accumulates of a prefiltered pass -- "records" (round 4, the default): the sweep records every contribution,
-    # k_reduce_records folds the records into the rows; "ranges": an assignment-only sweep + k_accum_ranges; "burst":
-    # round 3's one kernel with its atomics, the first pass of M = 256 on the plain hybrid kernel
+    # the accumulates of a prefiltered pass -- "sorted" (round 5, the default from M = 256 on; here from 64): a full first
+    # pass as candidate sweep + finishing kernel + k_reduce_records, then the fused pass over frames grouped by cell;
+    # "sweep": candidate sweep + finishing kernel + k_reduce_records throughout (ECOZ2_VQ_FUSED_SORTED=0); "records": round
+    # 4's fused kernel, whose sweep records every contribution for k_reduce_records; "burst": round 3's one kernel with its
+    # atomics, the first pass of M = 256 on the plain hybrid kernel
     plain_first = accumulate == "burst"
-    monkeypatch.setenv("ECOZ2_VQ_RECORDS", "1" if accumulate == "records" else "0")
+    monkeypatch.setenv("ECOZ2_VQ_RECORDS", "0" if accumulate == "burst" else "1")
     monkeypatch.setenv("ECOZ2_VQ_PLAIN_FIRST", "1" if plain_first else "0")
-    monkeypatch.setenv("ECOZ2_VQ_SPLIT_ACC_MAX_M", "512" if accumulate == "ranges" else "0")
+    monkeypatch.setenv("ECOZ2_VQ_SPLIT_SWEEP", "1" if accumulate in ("sorted", "sweep") else "0")
+    monkeypatch.setenv("ECOZ2_VQ_FUSED_SORTED", "1" if accumulate == "sorted" else "0")
+    monkeypatch.setenv("ECOZ2_VQ_FUSED_MIN_M", "64")
     if collective:
         monkeypatch.setenv("ECOZ2_VQ_FORCE_ALLREDUCE", "1")
     frames = _frames(20257, 9000)
@@ -284,7 +288,7 @@ def test_few_records_switch_the_level_to_the_burst(oracle, monkeypatch, few_div,
     assert 0 <= total <= 2 * len(frames)
 
 
-@pytest.mark.parametrize("split_max_m", [-1, 0, 128, 4096])
+@pytest.mark.parametrize("split_max_m", [-2, -1, 0])
 @pytest.mark.parametrize("collective", [False, True])
 @pytest.mark.parametrize("min_m", [64, 256])
 def test_seeded_first_pass_after_a_split_equals_a_full_accumulation(oracle, monkeypatch, min_m, collective, split_max_m):
@@ -293,14 +297,15 @@ def test_seeded_first_pass_after_a_split_equals_a_full_accumulation(oracle, monk
     pass -- and after the incremental passes that build on it -- must equal the oracle's full accumulation bit for bit.
     Levels 32 -> 64 (parent on the plain sweep, which records the cells) up to 512, through grow / pass / update; with
     `collective` the parent rows come from the rank's own copy.
-    split_max_m (round 4): up to that size the pass is an assignment-only sweep + k_accum_ranges (cell sums through LDS
-    tables, full on the first pass of a level and incremental after; two cell arrays swapped per pass) instead -- 0: seeded
-    passes everywhere; 128: the two kinds of level follow each other; 4096: no seeded pass at all.  -1: the recorded
-    accumulate (the default: seeded first passes whose records include the side table's bins, incremental ones after)."""
+    split_max_m (the name is round 4's; its values now pick the kernels): -2 the fused pass over frames grouped by cell
+    (round 5, here at every prefiltered size), whose in-block reduction adds to the side table and to the rows; -1 round 4's
+    fused kernel with the recorded accumulate (seeded first passes whose records include the side table's bins, incremental
+    ones after); 0 the same kernel with its burst of atomics."""
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", str(min_m))
     monkeypatch.setenv("ECOZ2_VQ_FAMILY_MIN_M", str(min_m))  # (default 512: below, the plain first pass is faster)
     monkeypatch.setenv("ECOZ2_VQ_RECORDS", "1" if split_max_m < 0 else "0")
-    monkeypatch.setenv("ECOZ2_VQ_SPLIT_ACC_MAX_M", str(max(0, split_max_m)))
+    monkeypatch.setenv("ECOZ2_VQ_SPLIT_SWEEP", "1" if split_max_m == -2 else "0")
+    monkeypatch.setenv("ECOZ2_VQ_FUSED_MIN_M", "64")
     monkeypatch.setenv("ECOZ2_VQ_QUIET", "1")
     if collective:
         monkeypatch.setenv("ECOZ2_VQ_FORCE_ALLREDUCE", "1")

@@ -93,9 +93,11 @@ CLEAN = [
     (r"k_reduce_recordsILi37E", "vq_prefilter", 85),          # three workgroups of eight waves per CU
     (r"k_pass_mfmaILi37ELi2ELi512ELi0E", "vq_device", 256),   # plain FP64 sweep
     (r"k_pass_smallILi37E", "vq_device", 256),                # M <= 16
-    (r"k_sweep_candILi37ELb1E", "vq_sweep", 256),             # round 5: two-stage candidate sweep
-    (r"k_sweep_candILi37ELb0E", "vq_sweep", 256),
-    (r"k_finishILi37E", "vq_sweep", 256),
+    (r"k_sweep_candILi37ELb1ELb1E", "vq_sweep", 256),         # round 5: the fused pass over grouped frames, two-stage sweep
+    (r"k_sweep_candILi37ELb0ELb1E", "vq_sweep", 256),         # ... one-stage sweep
+    (r"k_sweep_candILi37ELb1ELb0E", "vq_sweep", 256),         # candidate sweep alone (finishing kernel + reduce behind it)
+    (r"k_sweep_candILi37ELb0ELb0E", "vq_sweep", 256),
+    (r"k_finishILi37E", "vq_sweep", 168),                     # twelve waves per workgroup: three per SIMD
 ]
 
 
@@ -124,11 +126,23 @@ def test_rotating_tile_loop(asm, pattern):
                    if not any(l.strip() in b for b in loads)), "a compiler-visible load inside the tile loop"
 
 
-def test_two_stage_sweep_shape(asm):
-    k = Kernel(asm["vq_sweep"], r"k_sweep_candILi37ELb1E")
-    # the coarse stage's loop: one tile = 2 column blocks x 8 k-steps, no 15-step job inside it
-    coarse = [lp for lp in k.loops() if lp[2] == 16]
+@pytest.mark.parametrize("pattern", [r"k_sweep_candILi37ELb1ELb1E", r"k_sweep_candILi37ELb1ELb0E"])
+def test_two_stage_sweep_shape(asm, pattern):
+    k = Kernel(asm["vq_sweep"], pattern)
+    # the coarse stage's loop: two register sets = two tiles of 2 column blocks x 8 k-steps, no 15-step job inside it,
+    # and the MFMAs of a job interleaved with the previous job's epilogue (never eight in a row)
+    coarse = [lp for lp in k.loops() if lp[2] == 32]
     assert coarse, [lp for lp in k.loops() if lp[2]]
+    first, last, _, _ = min(coarse, key=lambda lp: lp[1] - lp[0])
+    run, longest = 0, 0
+    for l in k.body[first:last]:
+        t = l.strip()
+        if t.startswith("v_mfma"):
+            run += 1
+            longest = max(longest, run)
+        elif t.startswith("v_"):
+            run = 0
+    assert longest <= 4, "the coarse jobs' MFMAs are no longer interleaved with the key epilogue"
     assert k.count("scratch_") == 0
 
 

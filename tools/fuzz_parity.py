@@ -131,11 +131,14 @@ def fuzz_prefilter(n, rng, oracle):
         rc, st = oracle.data_stats(frames)
         sh_r, sh_q = oracle.shifts(st.maxabs)
         ok, what = True, ""
-        # the accumulate of the prefiltered passes: recorded contributions + k_reduce_records (the default), the
-        # assignment-only sweep + k_accum_ranges, or the one kernel with its burst of atomics
+        # the kernels of the prefiltered passes, drawn per case: 0 the defaults with the round-5 kernels from M = 64 on (a full
+        # first pass as candidate sweep + finishing kernel + k_reduce_records, then the fused pass over grouped frames), 1 the
+        # same without the fused pass, 2 round 4's fused kernel with recorded contributions, 3 the same with its burst of atomics
         acc = int(rng.integers(0, 4))
-        os.environ["ECOZ2_VQ_RECORDS"] = "0" if acc >= 2 else "1"
-        os.environ["ECOZ2_VQ_SPLIT_ACC_MAX_M"] = "4096" if acc == 2 else "0"
+        os.environ["ECOZ2_VQ_RECORDS"] = "0" if acc == 3 else "1"
+        os.environ["ECOZ2_VQ_SPLIT_SWEEP"] = "1" if acc <= 1 else "0"
+        os.environ["ECOZ2_VQ_FUSED_SORTED"] = "1" if acc == 0 else "0"
+        os.environ["ECOZ2_VQ_FUSED_MIN_M"] = "64"
         with e.VqSession(P) as s:
             s.set_frames(frames); s.prepare(); s.set_codebook(refl)
             for it in range(3):
