@@ -126,7 +126,7 @@ def test_rotating_tile_loop(asm, pattern):
                    if not any(l.strip() in b for b in loads)), "a compiler-visible load inside the tile loop"
 
 
-@pytest.mark.parametrize("pattern", [r"k_sweep_candILi37ELb1ELb1E", r"k_sweep_candILi37ELb1ELb0E"])
+@pytest.mark.parametrize("pattern", [r"k_sweep_candILi37ELb1ELb1E"])
 def test_two_stage_sweep_shape(asm, pattern):
     k = Kernel(asm["vq_sweep"], pattern)
     # the coarse stage's loop: two register sets = two tiles of 2 column blocks x 8 k-steps, no 15-step job inside it,
