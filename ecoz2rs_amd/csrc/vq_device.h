@@ -60,7 +60,7 @@ int* prefilter_codebook_scale(void* ps);
 int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, long nblocks, const void* fimg,
                             const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
-                            long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
+                            long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental,
                             hipStream_t s, const double* rowmajor_frames = nullptr, const int* ea_fused = nullptr,
                             const double* resident_rowmajor = nullptr, long long* family_table = nullptr,
                             const struct PassRecords* records = nullptr);

@@ -151,7 +151,7 @@ __global__ void k_finish_scalars(const u64* __restrict__ maxabs_bits, DevScalars
 // ------------------------------------------------------------------------------------------
 //   MODE  0: assignment only (quantize)   1: LDS accumulator table (small M)   2: global atomics (large M)
 //         5: hybrid LDS/global (mid M)    3: diagnostics (MODE 2 without the atomics)
-constexpr int TPB = 256;
+[[maybe_unused]] constexpr int TPB = 256;
 
 // ------------------------------------------------------------------------------------------
 // MFMA path (P = 36): operand layouts
@@ -725,71 +725,11 @@ __global__ __launch_bounds__(256) void k_global_sums_mfma(const double* __restri
     }
 }
 
-// generic (any P) fallback: frame coefficients re-read from global/L1 per codeword.
-// Correct for every P <= E2VQ_MAX_P; only the instantiated NC values get the register kernel.
-template <int MODE>
-__global__ __launch_bounds__(TPB) void k_pass_generic(const double* __restrict__ blk, long T, long nblocks, int NC,
-                                                      const double* __restrict__ cbq, int M,
-                                                      const DevScalars* __restrict__ sc,
-                                                      const u64* __restrict__ l1max_bits,
-                                                      unsigned short* __restrict__ sym, double* __restrict__ dmin,
-                                                      i64* __restrict__ rows)
-{
-    const int NPAD = (NC + 7) & ~7;
-    const int RS = (2 * NC + 5 + 7) & ~7;
-    const int lane = threadIdx.x & 63;
-    const long wave = (long)blockIdx.x * (TPB >> 6) + (threadIdx.x >> 6);
-    const long nwaves = (long)gridDim.x * (TPB >> 6);
-    int sh_r = 0, sh_d = 0, sh_d2 = 0;
-    if (MODE != 0) {
-        sh_r = sc->sh_r;
-        const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
-        sh_d = 30 - Ed;
-        sh_d2 = 30 - 2 * Ed;
-    }
-    for (long b = wave; b < nblocks; b += nwaves) {
-        const double* fb = blk + b * (long)(NC * 64);
-        double best = __builtin_inf();
-        int bi = 0;
-        for (int m = 0; m < M; ++m) {
-            const double* c = cbq + (long)m * NPAD;
-            double d = __builtin_fma(fb[lane], c[0], 0.0);
-            for (int n = 1; n < NC; ++n) d = __builtin_fma(fb[n * 64 + lane], c[n], d);
-            const bool lt = d < best;
-            best = lt ? d : best;
-            bi = lt ? m : bi;
-        }
-        const long t = b * 64 + lane;
-        if (t < T) {
-            if (sym) sym[t] = (unsigned short)bi;
-            if (dmin) dmin[t] = best;
-            if (MODE != 0) {
-                i64* row = rows + (long)bi * RS;
-                for (int n = 0; n < NC; ++n) {
-                    int hi, lo;
-                    fix2(fb[n * 64 + lane], sh_r, hi, lo);
-                    atomicAdd((u64*)&row[2 * n], (u64)(i64)hi);
-                    atomicAdd((u64*)&row[2 * n + 1], (u64)(i64)lo);
-                }
-                const double e = best - 1.0;
-                int hi, lo;
-                atomicAdd((u64*)&row[2 * NC], 1ull);
-                fix2(e, sh_d, hi, lo);
-                atomicAdd((u64*)&row[2 * NC + 1], (u64)(i64)hi);
-                atomicAdd((u64*)&row[2 * NC + 2], (u64)(i64)lo);
-                fix2(e * e, sh_d2, hi, lo);
-                atomicAdd((u64*)&row[2 * NC + 3], (u64)(i64)hi);
-                atomicAdd((u64*)&row[2 * NC + 4], (u64)(i64)lo);
-            }
-        }
-    }
-}
-
 // Prediction orders beyond the MFMA instantiations (P > 40; the reference allows up to 200), round 3: the frames of a
 // block are staged ONCE in the wave's LDS ([n][64]: lane = frame, conflict-free 8-byte rows) and the codewords come
 // eight at a time from a transposed copy cbT[n][m] (8 consecutive doubles = one scalar load per coefficient), so a
-// coefficient costs one LDS read for eight FMAs -- k_pass_generic re-read every frame coefficient from global memory
-// per codeword (1 load per FMA: ~2 TFLOP/s).  Same chain: acc = +0.0, fma(r[n], c[n], acc) for ascending n; ascending
+// coefficient costs one LDS read for eight FMAs (round 2's generic kernel re-read every frame coefficient from global memory
+// per codeword: ~2 TFLOP/s; it left the tree in round 5).  Same chain: acc = +0.0, fma(r[n], c[n], acc) for ascending n; ascending
 // codeword index with strict < (padding codewords repeat codeword 0 and can never win).  One wave per workgroup; LDS =
 // 520 (P + 1) bytes, so P = 200 still fits (one workgroup per CU).
 constexpr int GEN_G = 8;    // codewords per group
@@ -1418,13 +1358,6 @@ void launch_global_sums(const double* blk, long nblocks, int NC, int FB, const D
                        stats);
 }
 
-// A/B switch: ECOZ2_VQ_SMALL_REGS=0 sends M <= 16 back to the LDS-table kernel
-static bool small_codebook_register_sums()
-{
-    static const bool on = !(getenv("ECOZ2_VQ_SMALL_REGS") && atoi(getenv("ECOZ2_VQ_SMALL_REGS")) == 0);
-    return on;
-}
-
 template <int NC>
 static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, const double* cbm, int M,
                             const DevScalars* sc, const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows,
@@ -1444,7 +1377,7 @@ static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, c
         const int grid = grid_for(nblocks, 4, 512);
         hipLaunchKernelGGL((k_pass_mfma<NC, 0, 256, 1>), dim3(grid), dim3(256), lds, s, blk, T, nblocks, cbm, MT, M, sc,
                            l1max_bits, sym, dmin, rows, 0);
-    } else if (mode == 1 && M <= 16 && RegAcc<NC>::OK && small_codebook_register_sums()) {
+    } else if (mode == 1 && M <= 16 && RegAcc<NC>::OK) {
         const size_t lds = (size_t)M * RS * 8 + (size_t)((((NC + 3) / 4 + 1) / 2) * 128 + 16) * 8 + (size_t)8 * RegAcc<NC>::WAVE_INTS * 4;
         (void)hipFuncSetAttribute((const void*)k_pass_small<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, E2VQ_LDS_BYTES);
         const int grid = grid_for(nblocks, 8, 256);
@@ -1464,7 +1397,7 @@ static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, c
         (void)hipFuncSetAttribute((const void*)k_pass_mfma<NC, 5, 512>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   E2VQ_LDS_BYTES);
         const int grid = grid_for(nblocks, 8, 256);
-        static const int stagger = getenv("ECOZ2_VQ_STAGGER") ? atoi(getenv("ECOZ2_VQ_STAGGER")) : 1;
+        const int stagger = 1;
         hipLaunchKernelGGL((k_pass_mfma<NC, 5, 512>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, MT, M, sc,
                            l1max_bits, sym, dmin, rows, stagger);
     } else if (mode == 3) {  // diagnostics: MODE 2 without the atomics
@@ -1475,7 +1408,7 @@ static int launch_pass_mfma(int mode, const double* blk, long T, long nblocks, c
     } else {
         const size_t lds = (size_t)8 * 16 * IMG * 4;
         const int grid = grid_for(nblocks, 8, 256);  // one 8-wave workgroup per CU: partner waves are w, w+4
-        static const int stagger = getenv("ECOZ2_VQ_STAGGER") ? atoi(getenv("ECOZ2_VQ_STAGGER")) : 1;  // A/B: ~1 % faster on
+        const int stagger = 1;  // A/B: ~1 % faster on
         hipLaunchKernelGGL((k_pass_mfma<NC, 2, 512>), dim3(grid), dim3(512), lds, s, blk, T, nblocks, cbm, MT, M, sc,
                            l1max_bits, sym, dmin, rows, stagger);
     }
@@ -1540,15 +1473,7 @@ int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const
         }
         return 0;
     }
-    // generic: 64 frames per block, global atomics for the accumulation
-    const int grid = grid_for(nblocks, TPB / 64, 2048);
-    if (mode == 0)
-        hipLaunchKernelGGL((k_pass_generic<0>), dim3(grid), dim3(TPB), 0, s, blk, T, nblocks, NC, cbq, M, sc,
-                           l1max_bits, sym, dmin, rows);
-    else
-        hipLaunchKernelGGL((k_pass_generic<2>), dim3(grid), dim3(TPB), 0, s, blk, T, nblocks, NC, cbq, M, sc,
-                           l1max_bits, sym, dmin, rows);
-    return 0;
+    return 1;  // (no scratch for the transposed codebook: the caller always provides one)
 }
 
 // full FP64 sweep of the frames a prefiltered pass could not certify (vq_prefilter.hip): fb_list[0 .. *fb_count)

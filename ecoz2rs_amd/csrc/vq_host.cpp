@@ -98,7 +98,6 @@ struct e2vq_session {
     bool spec_valid = false;
     bool spec_zeroed = false;  // the pass prologue zeroed d_l1max_spec and the shadow image's scalars
     hipEvent_t ev_stats = nullptr;
-    bool stats_event = false;  // ECOZ2_VQ_STATS_EVENT=1: an event behind the statistics kernel instead of stream queries (A/B)
     struct HostStats { i64 l[64 * 8]; u64 l1bits; volatile u64 seq; i64 failed; volatile u64 seq2; volatile u64 err; volatile i64 rec_total; volatile u64 sw_flagged, sw_jobs; }* h_stats = nullptr;  // pinned, host-mapped
     long verified_passes = 0;
     bool verify_publish = false;  // ECOZ2_VQ_VERIFY_PUBLISH: recompute every published statistic on the host from the rows
@@ -348,7 +347,6 @@ static int session_init(e2vq_session* s)
     if (const char* pf1 = getenv("ECOZ2_VQ_PLAIN_FIRST")) s->plain_first = atoi(pf1) != 0;
     if (const char* fm = getenv("ECOZ2_VQ_FAMILY")) s->fam_enabled = atoi(fm) != 0;
     if (const char* fm = getenv("ECOZ2_VQ_FAMILY_MIN_M")) s->fam_min_M = std::max(64, atoi(fm));
-    if (const char* se = getenv("ECOZ2_VQ_STATS_EVENT")) s->stats_event = atoi(se) != 0;
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS")) s->rec_enabled = atoi(rc) != 0;
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS_MIN_M")) s->rec_min_M = std::max(64, atoi(rc));
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS_MAX_MB")) s->rec_max_bytes = (size_t)std::max(0, atoi(rc)) << 20;
@@ -854,10 +852,18 @@ static int fold_pending_timing(e2vq_session* s)
 }
 
 // the prefiltered sweep serves the accumulate-by-global-atomics and assignment-only passes of large codebooks
+static bool records_plan(const e2vq_session* s, int M, bool family, e2vq::PassRecords* plan, size_t* bytes);
 static bool use_prefilter(const e2vq_session* s, int mode)
 {
-    return s->pre_enabled && s->d_fimg && (mode == 1 || mode == 2 || mode == 5 || mode == 0) && s->M >= s->pre_min_M &&
-           e2vq::prefilter_supports(s->NC, s->M);
+    if (!(s->pre_enabled && s->d_fimg && (mode == 1 || mode == 2 || mode == 5 || mode == 0) && s->M >= s->pre_min_M &&
+          e2vq::prefilter_supports(s->NC, s->M)))
+        return false;
+    if (mode == 0) return true;
+    // an accumulating prefiltered pass needs the row-major resident copy with LDS room for a block of it, and an accumulate
+    // that takes its rows: records, or -- rows of at most 80 elements -- the burst of atomics.  Anything else runs the
+    // plain FP64 sweep (round 2's accumulating kernel, which served those cases, left in round 5).
+    return s->d_aos && e2vq::prefilter_lds_stage(s->NC) &&
+           (e2vq::prefilter_burst_supported(s->NC) || records_plan(s, s->M, false, nullptr, nullptr));
 }
 
 // the recorded accumulate for accumulating prefiltered passes at this codebook size?  (plan: filled in but for the pointers)
@@ -1120,7 +1126,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             if (e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, d_cimg, d_ps,
                                           s->d_cbq, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                                           (double*)device_dmin, rows, s->d_fblist, keep ? s->d_prev_sym : nullptr,
-                                          incremental, /*hybrid_table=*/mode == 5 && !incremental && !family && !records, s->stream,
+                                          incremental, s->stream,
                                           nullptr, nullptr, s->d_aos, family ? s->d_fam : nullptr, records ? &recplan : nullptr))
             return e2vq_set_error("prefiltered sweep: unsupported configuration");
         if (records && s->timing) {
@@ -1284,7 +1290,7 @@ static int spin_for_sequence(e2vq_session* s, volatile u64* word, const char* wh
             // (the safety net: the stream has drained and the number never came.  A stream query, not an event recorded
             // behind the kernel: the event's marker packet sat between the update and the next kernel of the stream and
             // cost ~5 us of idle GPU per pass)
-            const hipError_t q = s->stats_event ? hipEventQuery(s->ev_stats) : hipStreamQuery(s->stream);
+            const hipError_t q = hipStreamQuery(s->stream);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) return e2vq_set_error("%s failed: %s", what, hipGetErrorString(q));
             (void)hipGetLastError();  // (hipErrorNotReady is sticky for hipGetLastError: nobody downstream should see it)
@@ -1425,7 +1431,6 @@ static int pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_fai
                                  /*zero_first=*/false, image ? s->d_ea : nullptr,
                                  image ? e2vq::prefilter_codebook_scale(s->d_ps2[k]) : nullptr, &pub);
         s->failed_pending = true;
-        if (s->stats_event) HIPCHK(hipEventRecord(s->ev_stats, s->stream));
         if (image) {
             e2vq::launch_prefilter_codebook(s->d_cbq_spec, s->M, s->NC, s->d_ea, s->d_ps2[k], s->d_cimg2[k], s->stream,
                                             /*scale_ready=*/true);
@@ -1437,7 +1442,6 @@ static int pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_fai
         e2vq::launch_rows_stats(s->d_rows, s->M, s->NC, s->d_sc, s->d_S, s->d_within, s->d_lstats, s->stream);
         e2vq::launch_publish_stats(s->d_lstats, s->d_l1max, s->d_within, s->M, dstats->l, &dstats->l1bits, (double*)dw,
                                    (u64*)&dstats->seq, ++s->stats_seq, s->stream);
-        if (s->stats_event) HIPCHK(hipEventRecord(s->ev_stats, s->stream));
         e2vq::launch_centroids(s->d_rows, s->d_S, s->M, s->NC, s->d_refl, s->d_refl_spec, s->d_lstats, s->stream);
         s->lstats_dirty = true;
         e2vq::launch_codebook_prepare(s->d_refl_spec, s->M, s->NC, s->d_cbq_spec, s->d_l1max_spec, s->d_cbm_spec,
@@ -1796,12 +1800,12 @@ extern "C" int e2vq_quantize_device(e2vq_session* s, const void* device_frames, 
         if (fused) {
             e2vq::launch_pass_prefiltered(s->NC, false, nullptr, T, nb, nullptr, nullptr, s->d_qcimg, s->d_ps, s->d_cbq,
                                           s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym, (double*)device_dmin,
-                                          nullptr, s->d_qfblist, nullptr, false, false, s->stream, aos, s->d_ea_q);
+                                          nullptr, s->d_qfblist, nullptr, false, s->stream, aos, s->d_ea_q);
         } else {
             e2vq::launch_prefilter_quantize_prep(aos, T, nb, s->NC, s->d_ea_q, nullptr, s->d_qfimg, s->d_qfg, s->stream);
             e2vq::launch_pass_prefiltered(s->NC, false, nullptr, T, nb, s->d_qfimg, s->d_qfg, s->d_qcimg, s->d_ps, s->d_cbq,
                                           s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym, (double*)device_dmin,
-                                          nullptr, s->d_qfblist, nullptr, false, false, s->stream, aos);
+                                          nullptr, s->d_qfblist, nullptr, false, s->stream, aos);
         }
         e2vq::launch_pass_fallback(s->NC, false, aos, s->d_cbm, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                                    (double*)device_dmin, nullptr, s->d_qfblist, e2vq::prefilter_fallback_count(s->d_ps),

@@ -476,47 +476,29 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 {
     // MODE 0: assignment only (limb image from fimg; FP64 frames from blk, or from the row-major payload aos);
     // MODE 6: assignment only, fused quantize -- limb image AND FP64 frames from the row-major payload aos, through the
-    //         wave's LDS stage (pre_build_block); MODE 2 / 5: accumulate (global atomics / + workgroup LDS table)
+    //         wave's LDS stage (pre_build_block).  (Round 2's accumulating modes 2 / 5 of this kernel left in round 5:
+    //         training passes run k_pass_pre_lds or the kernels of vq_sweep.hip.)
     typedef PrePack<NC> PK;
-    constexpr bool QF = MODE == 6, ACC = MODE != 0 && MODE != 6;
-    // the distortion elements of the frames (e, e^2 as limb pairs) are summed per wave in registers and added to the
-    // distortion columns of one row at the end: only the column totals are ever used (level statistics), and per-frame
-    // atomics on those four words were 2^23 per pass, the only ones left for a frame that keeps its cell
-    constexpr bool DSEP = ACC;
-    i64 dacc[4] = {0, 0, 0, 0};
+    static_assert(MODE == 0 || MODE == 6, "assignment-only modes");
+    constexpr bool QF = MODE == 6;
     E2VQ_STAMP_DECL
     constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2;
-    constexpr int NE = 2 * NC + 5, IMG = NE + IMG_STRIDE_PAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int q = lane >> 4, j = lane & 15;
     const long wave = (long)blockIdx.x * (TPBM >> 6) + wib;
     const long nwaves = (long)gridDim.x * (TPBM >> 6);
-    // MODE 5 (full accumulation at 128 < M <= 672): the first HYB_CELLS cells go to an LDS table of the workgroup,
-    // flushed once at the end; the others, and every cell in MODE 2, take global atomics
-    constexpr int RS = (2 * NC + 5 + 7) & ~7;
-    constexpr int HYB_CELLS = mfma_hyb_cells(NC);
-    const int lds_cells = MODE == 5 ? HYB_CELLS : 0;
-    i64* lacc = (i64*)smem;
-    int* img = (int*)(smem + (size_t)lds_cells * RS * 8) + wib * (16 * IMG);
     double* stage = (double*)smem + wib * (64 * NC);                       // QF: the wave's 64 row-major FP64 frames
     int* eas = (int*)((double*)smem + (TPBM >> 6) * (64 * NC));            // QF: per-coefficient scale exponents
     if constexpr (QF) {
         for (int n = threadIdx.x; n < NC; n += TPBM) eas[n] = ea[n];
         __syncthreads();
     }
-    if constexpr (MODE == 5) {
-        for (int i = threadIdx.x; i < lds_cells * RS; i += TPBM) lacc[i] = 0;
-        __syncthreads();
-    }
-
-    int sh_r = 0, sh_d = 0, sh_d2 = 0;
-    if constexpr (ACC) {
-        sh_r = sc->sh_r;
-        const int Ed = dist_exponent(sc->maxabs, __longlong_as_double((i64)*l1max_bits));
-        sh_d = 30 - Ed;
-        sh_d2 = 30 - 2 * Ed;
-    }
+    (void)sc;
+    (void)l1max_bits;
+    (void)rows;
+    (void)prev_sym;
+    (void)incr;
     int maskv = idxmask;
     asm volatile("" : "+v"(maskv));
     float ninf = -__builtin_inff();
@@ -633,16 +615,6 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             continue;
         }
 
-        // cells of the previous pass (incremental accumulation): loaded here, with the frames, not after the evaluation
-        int oldidx[4] = {0, 0, 0, 0};
-        if (ACC && incr) {
-#pragma unroll
-            for (int ft = 0; ft < 4; ++ft) {
-                const long t = b * 64 + 16 * ft + j;
-                oldidx[ft] = t < T ? prev_sym[t] : 0;
-            }
-        }
-
         E2VQ_STAMP_DRAIN(2)  // certification, cells of the previous pass
         // ---- FP64 frames (MFMA operand layout of k_pass_mfma), exact evaluation of the two candidates -----------
         double Bf[4][2 * NP];
@@ -695,9 +667,6 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             E2VQ_STAMP(6)  // the runners-up
         }
 
-        // (frames left to the fallback change nothing here: their old cell is taken as their new one, 0)
-#pragma unroll
-        for (int ft = 0; ft < 4; ++ft) oldidx[ft] = skip[ft] ? 0 : oldidx[ft];
 
         // ---- outputs: lane 16q + j owns frame b*64 + lane; uncertified frames go to the fallback list ---------
         {
@@ -715,51 +684,10 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             }
         }
         E2VQ_STAMP(7)  // outputs
-        if constexpr (ACC) {
-            if constexpr (DSEP) {
-                if (q == 0) {
-#pragma unroll
-                    for (int ft = 0; ft < 4; ++ft)
-                        if (!skip[ft] && b * 64 + 16 * ft + j < T) {
-                            const double e = best[ft] - 1.0;
-                            int hi, lo;
-                            fix2(e, sh_d, hi, lo);
-                            dacc[0] += hi;
-                            dacc[1] += lo;
-                            fix2(e * e, sh_d2, hi, lo);
-                            dacc[2] += hi;
-                            dacc[3] += lo;
-                        }
-                }
-            }
-            // (MODE 2 has no LDS table, lds_cells = 0; a null table pointer crashes the ROCm 7.2 optimizer: the LDS base)
-            accumulate_block<NC, MODE, true, 4, MODE == 2, DSEP>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2,
-                                                                 b, T, lane, skip, incr != 0, oldidx);
-            // (after the accumulate, which consumed the old cells: the owner lane records the new one)
-            const int is = q == 0 ? idx[0] : q == 1 ? idx[1] : q == 2 ? idx[2] : idx[3];
-            const bool sk = q == 0 ? skip[0] : q == 1 ? skip[1] : q == 2 ? skip[2] : skip[3];
-            if (prev_sym && b * 64 + lane < T && !sk) prev_sym[b * 64 + lane] = (unsigned short)is;
-        }
         E2VQ_STAMP(8)  // accumulate (issue side: the atomics drain later)
 #ifdef E2VQ_PRE_STAMP
         st_n += 1;
 #endif
-    }
-    if constexpr (DSEP) {  // the wave's distortion sums -> the distortion columns of one row (any row: totals only)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            i64 v = dacc[k];
-            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            if (lane == 0 && v != 0)
-                atomicAdd((u64*)&rows[(long)(wave % (32 * MT)) * RS + 2 * NC + 1 + k], (u64)v);
-        }
-    }
-    if constexpr (MODE == 5) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < lds_cells * RS; i += TPBM) {
-            const i64 v = lacc[i];
-            if (v != 0) atomicAdd((u64*)&rows[i], (u64)v);
-        }
     }
 #ifdef E2VQ_PRE_STAMP
     {
@@ -1626,7 +1554,6 @@ __host__ __device__ constexpr bool fused_quantize_fits(int NC) { return fused_qu
 bool prefilter_fused_quantize(int NC) { return pre_has_nc(NC) && fused_quantize_fits(NC) && !getenv("ECOZ2_VQ_QUANTIZE_UNFUSED"); }
 
 // the accumulating pass with LDS-staged frames (k_pass_pre_lds) needs (64 frames + 512 B) of LDS per wave: eight waves for P <= 38, seven at P = 40;
-// ECOZ2_VQ_PRE_LDS=0 keeps the round-2 kernel (A/B)
 template <int NC> static constexpr bool lds_stage_ok_t() { return PreLds<NC>::OK; }
 static int pre_lds_waves(int NC)
 {
@@ -1649,8 +1576,6 @@ bool prefilter_burst_supported(int NC)
 }
 bool prefilter_lds_stage(int NC)
 {
-    static const bool off = getenv("ECOZ2_VQ_PRE_LDS") && atoi(getenv("ECOZ2_VQ_PRE_LDS")) == 0;
-    if (off) return false;
     switch (NC) {
 #define X(N) case N: return lds_stage_ok_t<N>();
         E2VQ_PRE_NC_LIST(X)
@@ -1659,7 +1584,6 @@ bool prefilter_lds_stage(int NC)
     }
 }
 
-// hybrid_table (full accumulation only): cells < mfma_hybrid_cells(NC) accumulate in the workgroup's LDS table.
 // accumulate = false: assignment only.  prev_sym (optional): the cell of every frame is recorded there; with
 // `incremental` the rows must be those of the previous pass over the same frames (distortion elements zeroed) and
 // prev_sym its cells.  Runs after launch_prefilter_codebook of the same pass; afterwards
@@ -1669,7 +1593,7 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                                      const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                                      const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym,
                                      double* dmin, long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental,
-                                     bool hybrid_table, hipStream_t s, const double* aos, const int* ea_fused,
+                                     hipStream_t s, const double* aos, const int* ea_fused,
                                      const double* aos_resident, long long* family_table, const PassRecords* records)
 {
     constexpr int IMG = 2 * NC + 5 + IMG_STRIDE_PAD;
@@ -1679,15 +1603,11 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
     while ((1 << bits) < M) ++bits;
     const int idxmask = ~((1 << bits) - 1);
     const int grid = pre_grid(nblocks, TPBM / 64, 256);
-    static const int stagger = getenv("ECOZ2_VQ_PRE_STAGGER") ? atoi(getenv("ECOZ2_VQ_PRE_STAGGER")) : 1;
-    if (accumulate && hybrid_table) {  // full accumulation with the workgroup's LDS table for the first cells
-        const size_t lds5 = (size_t)mfma_hyb_cells(NC) * (((2 * NC + 5 + 7) & ~7) * 8) + lds;
-        (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 5, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  E2VQ_LDS_BYTES);
-        hipLaunchKernelGGL((k_pass_pre<NC, 5, TPBM>), dim3(grid), dim3(TPBM), lds5, s, blk, T, nblocks, (const h8*)fimg, fg,
-                           (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
-                           dmin, rows, fb_list, stagger, prev_sym, 0, (const double*)nullptr, (const int*)nullptr);
-    } else if (accumulate && aos_resident && prefilter_lds_stage(NC) && (records || PreLds<NC>::BURST_OK)) {
+    const int stagger = 1;  // (partner waves of a SIMD half a block period apart)
+    if (accumulate) {
+        // (an accumulating pass needs the row-major resident copy, LDS room for a block of it, and -- for rows of more than
+        // 80 elements -- the recorded accumulate: the caller sends anything else to the plain FP64 sweep)
+        if (!(aos_resident && prefilter_lds_stage(NC) && (records || PreLds<NC>::BURST_OK))) return 1;
         // round 3: FP64 frames staged in LDS, lane-per-frame exact evaluation, one burst of atomics per block
         if constexpr (PreLds<NC>::OK) {
             const int MT = M / 32;
@@ -1712,8 +1632,7 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                                    idxmask, sc, (const u64*)l1max_bits, sym, dmin, rows, fb_list, stagger, prev_sym,
                                    family_table ? 2 : (incremental ? 1 : 0), (i64*)family_table, rec);
             };
-            static const bool simple = getenv("ECOZ2_VQ_PRE_SIMPLE_LOOP") && atoi(getenv("ECOZ2_VQ_PRE_SIMPLE_LOOP")) != 0;  // (tests)
-            const bool rot = MT >= 4 && (MT & 1) == 0 && !simple;
+            const bool rot = MT >= 4 && (MT & 1) == 0;
             // (two register sets of codeword granules: up to nine granules per tile -- P = 40 has eleven and would spill)
             constexpr bool ROT_OK = PrePack<NC>::NU <= 9;
             if (records) {  // (the cell sums follow in launch_reduce_records)
@@ -1733,17 +1652,9 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
                 }
                 go(k_pass_pre_lds<NC, false, 1>);
             } else {
-                return 1;  // (launch_pass_prefiltered sends rows of more than 80 elements without records to k_pass_pre)
+                return 1;
             }
         }
-    } else if (accumulate) {
-        (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 2, TPBM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  E2VQ_LDS_BYTES);
-        const size_t lds2 = lds;
-        hipLaunchKernelGGL((k_pass_pre<NC, 2, TPBM>), dim3(grid), dim3(TPBM), lds2, s, blk, T, nblocks, (const h8*)fimg, fg,
-                           (const h8*)cimg, (PreScalars*)ps, cbq, M / 32, idxmask, sc, (const u64*)l1max_bits, sym,
-                           dmin, rows, fb_list, stagger, prev_sym, incremental ? 1 : 0, (const double*)nullptr,
-                           (const int*)nullptr);
     } else if (ea_fused) {  // fused quantize: limb images built in the kernel from the row-major payload
         if constexpr (fused_quantize_fits(NC)) {
             constexpr int QT = fused_quantize_waves(NC) * 64;
@@ -1770,19 +1681,18 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
 int launch_pass_prefiltered(int NC, bool accumulate, const double* blk, long T, long nblocks, const void* fimg,
                             const float* fg, const void* cimg, void* ps, const double* cbq, int M,
                             const DevScalars* sc, const unsigned long long* l1max_bits, unsigned short* sym, double* dmin,
-                            long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, bool hybrid_table,
-                            hipStream_t s, const double* rowmajor_frames, const int* ea_fused, const double* resident_rowmajor,
+                            long long* rows, int* fb_list, unsigned short* prev_sym, bool incremental, hipStream_t s, const double* rowmajor_frames, const int* ea_fused, const double* resident_rowmajor,
                             long long* family_table, const PassRecords* records)
 {
-    if (records && (!accumulate || hybrid_table || !resident_rowmajor || !prefilter_lds_stage(NC) || !prev_sym)) return 1;
-    if (family_table && (!accumulate || hybrid_table || incremental || !resident_rowmajor || !prefilter_lds_stage(NC))) return 1;
-    if (!prefilter_supports(NC, M) || (hybrid_table && incremental)) return 1;
+    if (records && (!accumulate || !resident_rowmajor || !prefilter_lds_stage(NC) || !prev_sym)) return 1;
+    if (family_table && (!accumulate || incremental || !resident_rowmajor || !prefilter_lds_stage(NC))) return 1;
+    if (!prefilter_supports(NC, M)) return 1;
     if (ea_fused && (accumulate || !rowmajor_frames || !prefilter_fused_quantize(NC))) return 1;
     switch (NC) {
 #define X(N)                                                                                                          \
     case N:                                                                                                           \
         return launch_pass_prefiltered_t<N>(accumulate, blk, T, nblocks, fimg, fg, cimg, ps, cbq, M, sc, l1max_bits, sym, \
-                                            dmin, rows, fb_list, prev_sym, incremental, hybrid_table, s, rowmajor_frames, \
+                                            dmin, rows, fb_list, prev_sym, incremental, s, rowmajor_frames, \
                                             ea_fused, resident_rowmajor, family_table, records);
         E2VQ_PRE_NC_LIST(X)
 #undef X
@@ -1832,9 +1742,8 @@ int launch_reduce_records(int NC, const double* aos, const PassRecords& plan, bo
     if (plan.nbins > plan.nbins_rows && !family_table) return 1;
     const int RS = (2 * NC + 5 + 7) & ~7;
     // (three workgroups per CU by registers and LDS; the kernel shares them out over the bins by their record counts)
-    static const int wg_env = getenv("ECOZ2_VQ_REC_WG") ? atoi(getenv("ECOZ2_VQ_REC_WG")) : 768;
     (void)few;
-    const int nwg = wg_env < plan.nbins ? plan.nbins : wg_env;
+    const int nwg = 768 < plan.nbins ? plan.nbins : 768;
     if (plan.grid > 256 || plan.bin_cells > 128 || plan.nbins > 64) return 1;  // (the prefix array; the histogram; lane = bin)
     const size_t lds = (size_t)plan.bin_cells * RS * 8;
     PreRec rec{};
