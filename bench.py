@@ -623,7 +623,7 @@ def run(args, comm):
     sess.enable_timing(True)  # HIP events around the sweep kernel of every pass, summed inside the library
     sess.enable_collective_timing(True)  # ... and around every call of the exchange
     fence()
-    launches_before = sess.sweep_launch_counts()
+    launches_before = sess.launch_counts_by_kernel()  # (k_pass_pre_lds, k_sweep_cand, plain)
     ar_before = comm.counters()
     t0 = time.perf_counter()
     steps_left = args.steps
@@ -645,8 +645,10 @@ def run(args, comm):
     ar_ms, ar_n, ar_b = sess.collective_timing()
     sess.enable_collective_timing(False)
     prefiltered, fallback_frames = sess.last_pass_info()
-    launches_after = sess.sweep_launch_counts()
-    timed_pre, timed_plain = launches_after[0] - launches_before[0], launches_after[1] - launches_before[1]
+    launches_after = sess.launch_counts_by_kernel()
+    timed_lds, timed_sweep, timed_plain = (launches_after[k] - launches_before[k] for k in range(3))
+    timed_pre = timed_lds + timed_sweep
+    sweep_kind, two_stage, flagged_frac = sess.last_pass_sweep()
     dt = comm.max_over_ranks(dt)
     collective = comm.describe(ar_timed)
     if collective is not None:
@@ -704,14 +706,19 @@ def run(args, comm):
             hbm_ms = BYTES_PER_FRAME_PASS * S / (HBM_PEAK_GBS * 1e9) * 1e3
             fp64_ms = 2.0 * m * (P + 1) * S / (FP64_PEAK_TFLOPS * 1e12) * 1e3
             f16_ms = F16_MFMA_FLOP_PER_FRAME_CODEWORD * m * S / (F16_PEAK_TFLOPS * 1e12) * 1e3
-            if prefiltered and m >= 128:  # (the prefiltered pass serves M >= 128 with the recorded accumulate)
+            lkind, ltwo, lfrac = sess.last_pass_sweep()
+            if prefiltered and m >= 128 and lkind in (2, 3) and ltwo and lfrac >= 0:
+                # two-stage sweep: 8 coarse k-steps for every (tile, column block), all 15 again for the flagged ones
+                bound, bound_ms = "f16 mfma (executed limb products: two-stage sweep)", f16_ms * (8 + 15 * lfrac) / 15
+            elif prefiltered and m >= 128:  # (the prefiltered pass serves M >= 128)
                 bound, bound_ms = "f16 mfma (executed limb products)", f16_ms
             elif hbm_ms >= fp64_ms:
                 bound, bound_ms = "hbm (306 B per frame-pass)", hbm_ms
             else:
                 bound, bound_ms = "fp64 mfma (2 M (P+1) flop per frame-pass)", fp64_ms
             level_detail.append({"M": m, "passes": lvm.passes, "kernel_ms": kms / max(1, kn), "step_ms": wall / lvm.passes * 1e3,
-                                 "bound": bound, "bound_ms": bound_ms, "frac_of_bound": bound_ms / (kms / max(1, kn))})
+                                 "bound": bound, "bound_ms": bound_ms, "frac_of_bound": bound_ms / (kms / max(1, kn)),
+                                 "sweep_kind": lkind, "flagged_fraction": lfrac if ltwo else None})
             if collective is not None:
                 level_detail[-1]["allreduce_us_per_call"] = 1e3 * lar_ms / max(1, lar_n)
                 level_detail[-1]["allreduce_bytes"] = m * e.lib.e2vq_row_stride(P) * 8
@@ -780,10 +787,10 @@ def run(args, comm):
         k_ms = kernel_ms_total / kernel_passes
         frames_per_launch = S
         # PMC traffic cannot be collected inside this process: it comes from separate rocprofv3 --pmc passes over this
-        # same command (tools/summarize_profiles.py -> profiles/r04_traffic*.json).  The file records the hash of the
+        # same command (tools/summarize_profiles.py -> profiles/r05_traffic*.json).  The file records the hash of the
         # kernel sources it was measured on; a figure measured on other sources is reported as stale (null).
         traffic, traffic_detail = None, None
-        tname = "r04_traffic" + ("" if M == 1024 else f"_M{M}") + ("" if prefiltered else "_noprefilter") + ".json"
+        tname = ("r05_traffic" if prefiltered else "r05np_traffic") + ("" if M == 1024 else f"_M{M}") + ("" if prefiltered else "_noprefilter") + ".json"
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and S == FRAMES_PER_GPU:
             try:
@@ -803,15 +810,29 @@ def run(args, comm):
             # dominant kernel: the prefiltered sweep.  The work it EXECUTES is 15 f16 MFMA k-steps per (frame, codeword)
             # pair (exact integer limb products) -- priced against the dense f16 MFMA peak of the guide; the FP64 chain
             # runs only for the two certified candidates of a frame.
-            exec_tf = F16_MFMA_FLOP_PER_FRAME_CODEWORD * M * frames_per_launch / (k_ms * 1e-3) / 1e12
+            # k-steps of v_mfma_f32_32x32x16_f16 executed per (frame, codeword) pair: 15 for a one-stage sweep; two stages: 8 for
+            # every pair + all 15 again for the flagged (tile, column block) jobs (their share is measured by the kernel)
+            ksteps = (8 + 15 * flagged_frac) if (two_stage and flagged_frac >= 0) else 15.0
+            exec_tf = 2 * 16 * ksteps * M * frames_per_launch / (k_ms * 1e-3) / 1e12
+            if sweep_kind == 3:
+                kname, kdesc = "k_sweep_cand", (
+                    "k_sweep_cand<37, two-stage, fused> over frames grouped by cell (one counting sort per level): exact f16-limb "
+                    "prefilter on v_mfma_f32_32x32x16_f16 in two stages (8 coarse k-steps for every codeword tile, all 15 + top-3 "
+                    "keys for the tiles a rigorous bound cannot rule out), FP64 rows gathered into LDS by LDS-DMA, the certified "
+                    "top two evaluated as lane-per-frame v_fma_f64 chains, symbols / distortion sums out, the contributions to "
+                    "the cell sums reduced in the block and added with one atomic per row element (exact int64); then, for "
+                    "uncertified frames, k_pass_mfma<37,2,256,2>")
+            elif sweep_kind == 2:
+                kname, kdesc = "k_sweep_cand", (
+                    "k_sweep_cand<37> (candidate sweep, frames in their natural order) + k_finish (exact evaluation, outputs, "
+                    "records) + k_reduce_records")
+            else:
+                kname, kdesc = "k_pass_pre", (
+                    "k_pass_pre_lds<37> (round 4's fused kernel: f16-limb prefilter + top-3 keys, FP64 frames of the block staged "
+                    "in LDS, lane-per-frame v_fma_f64 chains, contributions recorded for k_reduce_records or added as a burst)")
             roofline = {
                 "bound": "mfma",
-                "kernel": "k_pass_pre_lds<37> (exact f16-limb prefilter on v_mfma_f32_32x32x16_f16 + top-3 keys; FP64 frames "
-                          "of the block staged in LDS, the certified top two evaluated as lane-per-frame v_fma_f64 chains; "
-                          "contributions to the cell sums -- seeded on the first pass of the level, incremental after -- "
-                          "recorded as 8-byte records, or added as a burst of atomics with ECOZ2_VQ_RECORDS=0); then "
-                          "k_reduce_records (records sorted by cell in LDS, rows summed in registers, exact int64) and, for "
-                          "uncertified frames, k_pass_mfma<37,2,256,2>",
+                "kernel": kdesc,
                 "achieved": exec_tf,
                 "peak": F16_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
@@ -821,10 +842,19 @@ def run(args, comm):
                 "kernel_ms": k_ms,
                 "accumulate_kernel_ms": (pass_kernels_ms_total - kernel_ms_total) / kernel_passes,
                 "launches": kernel_passes,
-                "trace_dispatches": {"kernel": "k_pass_pre", "first": launches_before[0], "count": timed_pre,
-                                     "plain_first": launches_before[1], "plain_count": timed_plain},
-                "work_per_launch": f"{F16_MFMA_FLOP_PER_FRAME_CODEWORD} f16 MFMA flop x {M} codewords x {S} frames "
-                                   "(limb products actually issued)",
+                "trace_dispatches": {"kernel": kname, "first": launches_before[1] if kname == "k_sweep_cand" else launches_before[0],
+                                     "count": timed_sweep if kname == "k_sweep_cand" else timed_lds,
+                                     "plain_first": launches_before[2], "plain_count": timed_plain},
+                "work_per_launch": f"{2 * 16 * ksteps:.1f} f16 MFMA flop x {M} codewords x {S} frames "
+                                   f"(limb products actually issued: {ksteps:.2f} k-steps per pair"
+                                   + (f", flagged fraction {flagged_frac:.3f}" if two_stage and flagged_frac >= 0 else "") + ")",
+                "ksteps_per_pair": ksteps,
+                "two_stage": bool(two_stage), "flagged_fraction": flagged_frac if two_stage else None,
+                "one_stage_equivalent": {
+                    "what": "the limb products a one-stage sweep issues (15 k-steps per pair: round 4's count) / this kernel's "
+                            "time: what the same pass would need on round 4's kernel to be as fast -- a speed-up figure",
+                    "tflops": F16_MFMA_FLOP_PER_FRAME_CODEWORD * M * frames_per_launch / (k_ms * 1e-3) / 1e12,
+                    "frac_of_peak": F16_MFMA_FLOP_PER_FRAME_CODEWORD * M * frames_per_launch / (k_ms * 1e-3) / 1e12 / F16_PEAK_TFLOPS},
                 "executed_dtype": "f16 limbs (exact integers) -> f32 accumulators; candidates in f64",
                 "fallback_frames_last_pass": fallback_frames,
                 "note": "dense f16 MFMA peak of the guide (2.5 PF); on random operands the pipe sustains 1.1-1.4 PF "
@@ -851,7 +881,7 @@ def run(args, comm):
                 "traffic_detail": traffic_detail,
                 "kernel_ms": k_ms,
                 "launches": kernel_passes,
-                "trace_dispatches": {"kernel": "k_pass_mfma", "first": launches_before[1], "count": timed_plain},
+                "trace_dispatches": {"kernel": "k_pass_mfma", "first": launches_before[2], "count": timed_plain},
             }
         out = {
             "metric": f"vq_learn_frames_per_sec_M{M}_P36",
@@ -883,7 +913,7 @@ def run(args, comm):
                 "ladder_seconds_untimed": round(t_ladder, 3),
                 "final_avg_distortion": st.avg_distortion,
                 "parity": parity,
-                "timed_sweep_launches": {"prefiltered": timed_pre, "plain": timed_plain},
+                "timed_sweep_launches": {"k_sweep_cand": timed_sweep, "k_pass_pre_lds": timed_lds, "plain": timed_plain},
                 "steady_state": None if not extras else {
                     "what": "back-to-back iterations on the converged codebook (incremental accumulate nearly idle): "
                             "round 1's headline regime, informational",

@@ -95,6 +95,7 @@ _sig("e2vq_last_pass_sweep", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(
 _sig("e2vq_set_prev_distortion", C.c_int, C.c_void_p, C.c_double)
 _sig("e2vq_get_prev_distortion", C.c_int, C.c_void_p, C.POINTER(C.c_double))
 _sig("e2vq_sweep_launch_counts", C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+_sig("e2vq_launch_counts_by_kernel", C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64))
 _sig("e2vq_row_stride", C.c_int, C.c_int)
 _sig("e2vq_get_rows", C.c_int, C.c_void_p, C.c_void_p)
 _sig("e2vq_learn", C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, LEARN_CALLBACK,

@@ -236,6 +236,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             // the flagged fraction is looked at once per level: on its first pass
             const bool count = two && incr == 2;
             s->last_kind = 3;
+            s->n_sweep_launches++;
             s->last_two_stage = two;
             if (incr == 2) s->last_flagged_frac = -1.0;
             if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));  // (again: behind the sort)
@@ -272,6 +273,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             // (two stages need tiles to skip: from eight tiles on; below, the home tile alone is a quarter or half of the codebook)
             const bool two = sorted && s->two_stage_enabled && s->M >= 256 && s->M > s->two_stage_off_until_M;
             s->last_kind = 2;
+            s->n_sweep_launches++;
             s->last_two_stage = two;
             if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));  // (again: the sweep kernel alone is what ev0..ev_mid brackets)
             if (e2vq::launch_sweep_candidates(s->NC, two, s->d_fimgF, sorted ? s->d_perm : nullptr, s->T, s->nblocks, d_cimg, d_ps, s->M,
@@ -396,6 +398,14 @@ extern "C" int e2vq_last_pass_info(e2vq_session* s, int* prefiltered, int64_t* f
 extern "C" int e2vq_sweep_launch_counts(e2vq_session* s, int64_t* prefiltered, int64_t* plain)
 {
     if (prefiltered) *prefiltered = s->n_pre_launches;
+    if (plain) *plain = s->n_plain_launches;
+    return 0;
+}
+
+extern "C" int e2vq_launch_counts_by_kernel(e2vq_session* s, int64_t* pass_pre_lds, int64_t* sweep_cand, int64_t* plain)
+{
+    if (pass_pre_lds) *pass_pre_lds = s->n_pre_launches - s->n_sweep_launches;
+    if (sweep_cand) *sweep_cand = s->n_sweep_launches;
     if (plain) *plain = s->n_plain_launches;
     return 0;
 }

@@ -126,7 +126,7 @@ struct e2vq_session {
     void* d_ps = nullptr;  // quantize
     int* d_fblist = nullptr;
     bool last_prefiltered = false;
-    i64 n_pre_launches = 0, n_plain_launches = 0;  // sweep launches of this session's training passes, by kernel family
+    i64 n_pre_launches = 0, n_plain_launches = 0, n_sweep_launches = 0;  // (n_sweep_launches: those of n_pre_launches that ran k_sweep_cand)  // sweep launches of this session's training passes, by kernel family
     // quantize through the prefiltered sweep: scratch images of the frames handed in and of the codebook
     int* d_ea_q = nullptr;
     void* d_qfimg = nullptr;

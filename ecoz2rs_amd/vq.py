@@ -305,6 +305,12 @@ class VqSession:
         check(lib.e2vq_sweep_launch_counts(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def launch_counts_by_kernel(self):
+        """(k_pass_pre_lds, k_sweep_cand, plain) sweep launches of training passes so far"""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.e2vq_launch_counts_by_kernel(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def get_rows(self):
         rs = lib.e2vq_row_stride(self.P)
         out = np.empty((self.codebook_size(), rs), dtype=np.int64)

@@ -210,6 +210,9 @@ int e2vq_last_pass_sweep(e2vq_session *s, int *kind, int *two_stage, double *fla
 /* number of training-pass sweep launches so far, by kernel family (k_pass_pre / k_pass_mfma+generic): lets a
  * kernel trace of a whole run be cut to the dispatches of a timed region */
 int e2vq_sweep_launch_counts(e2vq_session *s, int64_t *prefiltered, int64_t *plain);
+/* the same by kernel: *pass_pre_lds = launches of round 4's fused kernel (k_pass_pre_lds), *sweep_cand = launches of round 5's
+ * k_sweep_cand (the fused pass over grouped frames, or the candidate sweep in front of k_finish), *plain = FP64 sweeps */
+int e2vq_launch_counts_by_kernel(e2vq_session *s, int64_t *pass_pre_lds, int64_t *sweep_cand, int64_t *plain);
 int e2vq_update(e2vq_session *s);
 /* ECOZ2_VQ_VERIFY_PUBLISH=1 (read at session creation): after every pass the statistics the update kernel published
  * through host-mapped memory (level sums, within-cell terms, L1 maximum, failed recursions) are recomputed on the host

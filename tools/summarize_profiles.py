@@ -43,6 +43,8 @@ def bench_line(name):
 def is_dominant(kname, family):
     # the training sweep itself: k_pass_pre<...> or k_pass_mfma<37, m, 512> (the FP64 fallback sweep is <.., 256, 2>)
     # (rocprofv3 leaves k_pass_pre mangled -- its _Float16 vector parameters defeat the demangler: _ZN4e2vq10k_pass_preILi37E..)
+    if family == "k_sweep_cand":  # round 5 (mangled like k_pass_pre)
+        return "k_sweep_cand" in kname
     if family == "k_pass_pre":
         return "k_pass_pre" in kname
     head = kname.split("(")[0]
@@ -63,7 +65,8 @@ def reduce_rows(path, hint):
     accumulate is recorded (the default) -- same indices; none otherwise."""
     allr = list(csv.DictReader(open(path)))
     red = [r for r in allr if "k_reduce_records" in r["Kernel_Name"]]
-    # (quantize sweeps are of the k_pass_pre family too, but follow the timed region)
+    # (quantize sweeps are of the k_pass_pre family too, but follow the timed region; the fused pass over grouped frames --
+    # k_sweep_cand -- has no reduce kernel behind it)
     return red[hint["first"]:hint["first"] + hint["count"]] if hint["kernel"] == "k_pass_pre" else []
 
 
@@ -109,8 +112,8 @@ def main():
         "kernel": rows[0]["Kernel_Name"].split("(")[0][:80],
         "dispatches": len(d), "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d),
         "avg_ms_by_pass_of_level": [sum(x) / len(x) for x in by_pos if x],
-        "note": f"timed region = {len(d) // L} repetitions of the real M={M} level ({L} passes: pass 0 accumulates in full, "
-                "the others incrementally); bench.py's HIP-event average over the same launches is bench_kernel_ms",
+        "note": f"timed region = {len(d) // L} repetitions of the real M={M} level ({L} passes: the first seeded with the parents' sums, "
+                "the others incremental); bench.py's HIP-event average over the same launches is bench_kernel_ms",
         "bench_kernel_ms": b["roofline"]["kernel_ms"], "bench_ms_per_step": b["ms_per_step"], "bench_value": b["value"],
         "vgpr": rows[0].get("VGPR_Count"), "accum_vgpr": rows[0].get("Accum_VGPR_Count"),
         "lds_bytes": rows[0].get("LDS_Block_Size"), "grid": rows[0].get("Grid_Size"), "workgroup": rows[0].get("Workgroup_Size"),
@@ -141,7 +144,7 @@ def main():
         hf, hw = bench_line("fetch")["roofline"]["trace_dispatches"], bench_line("write")["roofline"]["trace_dispatches"]
         f, fsel = counters(newest(f"{SRC}/{TAG}_fetch/*/*_counter_collection.csv"), hf)
         w, wsel = counters(newest(f"{SRC}/{TAG}_write/*/*_counter_collection.csv"), hw)
-        prefiltered = hint["kernel"] == "k_pass_pre"
+        prefiltered = hint["kernel"] in ("k_pass_pre", "k_sweep_cand")
         tj = {
             "kernel": out["kernel"] + f" at M={M}, 2^21 frames per launch (bench.py --steps 6: two repetitions of the {L}-pass level)",
             "FETCH_SIZE_KB_raw": f["FETCH_SIZE"], "WRITE_SIZE_KB_raw": w["WRITE_SIZE"],
@@ -190,6 +193,11 @@ def main():
             f16 = (T // 32) * (M // 32) * 15
             sq["expected_f16_mfma_instructions"] = f16
             sq["fp64_mfma_instructions"] = c["SQ_INSTS_MFMA"] - f16
+        if hint["kernel"] == "k_sweep_cand":
+            ks = b["roofline"].get("ksteps_per_pair", 15.0)
+            sq["expected_f16_mfma_instructions"] = (T // 32) * (M // 32) * ks
+            sq["ksteps_per_pair_from_the_bench_line"] = ks
+            sq["note_mfma"] = "SQ_INSTS_MFMA against (frames / 32) x (codewords / 32) x k-steps per pair: the flagged share varies a little from pass to pass"
         json.dump(sq, open(f"{DST}/{TAG}_sq_counters{sfx}.json", "w"), indent=1)
         print({k: sq[k] for k in ("kernel_ms_under_pmc", "clock_GHz_under_pmc", "mfma_pipe_busy_fraction",
                                   "other_valu_instructions_per_mfma")})
