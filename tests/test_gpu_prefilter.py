@@ -452,9 +452,10 @@ def test_prefilter_for_other_prediction_orders(oracle, monkeypatch, Pn):
 @pytest.mark.parametrize("records", ["1", "0"])
 def test_order_40_runs_seven_waves_per_workgroup(oracle, monkeypatch, records):
     """P = 40: 21 KB of FP64 frames per wave -- seven waves per workgroup instead of eight in the LDS-staged pass and in
-    fused quantize (round 4) -- and rows of 83 elements, which only the recorded accumulate can add: with
-    ECOZ2_VQ_RECORDS=0 the pass falls back to round 2's kernel and no first pass is seeded.  Default thresholds (prefilter and
-    seeding from M = 128), ladder to 1024 on a ragged frame count."""
+    fused quantize (round 4) -- and rows of 83 elements, which the burst of atomics cannot add: with ECOZ2_VQ_RECORDS=0 the
+    training passes run the plain FP64 sweep (round 2's accumulating kernel, which used to serve that case, left in round 5).
+    Default thresholds (prefilter and seeding from M = 128, the round-5 kernels from 256), ladder to 1024 on a ragged frame
+    count."""
     monkeypatch.setenv("ECOZ2_VQ_RECORDS", records)
     Pn = 40
     frames = e.synth.synth_frames(20340, 9, Pn, 0, 64 * 7 * 9 + 37)
@@ -469,7 +470,8 @@ def test_order_40_runs_seven_waves_per_workgroup(oracle, monkeypatch, records):
         refl = s.get_codebook()
         used = s.last_pass_info()[0]
         sym, dmin = s.quantize(frames)
-    assert used and [(l.M, l.passes) for l in levels] == [(l["M"], l["passes"]) for l in levels_o] and cbs == cbs_o
+    assert used == (records == "1")
+    assert [(l.M, l.passes) for l in levels] == [(l["M"], l["passes"]) for l in levels_o] and cbs == cbs_o
     assert np.array_equal(refl.view(np.uint64), levels_o[-1]["reflections"].view(np.uint64))
     sym_o, dmin_o = oracle.quantize(oracle.reflections_to_cq(refl), frames)
     assert np.array_equal(sym, sym_o) and np.array_equal(dmin.view(np.uint64), dmin_o.view(np.uint64))
