@@ -149,7 +149,9 @@ def fuzz_prefilter(n, rng, oracle):
                 refl, _ = oracle.update(rows_o, P, sh_r, refl)
                 s.run_pass(); used, nfb = s.last_pass_info(); rows = s.get_rows(); ls = s.pass_stats(); s.update()
                 fallback += nfb; frames_total += T
-                good = (used and oracle_lib.rows_match(rows, rows_o, P) and ls.DD == ls_o.DD and ls.sigma == ls_o.sigma
+                # (P = 40 without records: rows of 83 elements, which the burst of atomics cannot add -- the plain sweep serves)
+                expect_used = not (P == 40 and acc == 3)
+                good = (used == expect_used and oracle_lib.rows_match(rows, rows_o, P) and ls.DD == ls_o.DD and ls.sigma == ls_o.sigma
                         and ls.inertia == ls_o.inertia
                         and np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64)))
                 if not good:
