@@ -278,7 +278,14 @@ __device__ __forceinline__ void sweep_full_job(const h8 (&A)[PrePack<NC>::NU], c
 // counter at the phase ends so that a phase pays for the loads it waits on.  Never defined in the product build.
 #ifdef E2VQ_SWEEP_STAMP
 __device__ unsigned long long g_sweep_stamps[16];
-#define SW_STAMP_DECL unsigned long long sw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sw_conv = 0, sw_t = __builtin_amdgcn_s_memtime(), sw_n = 0;
+// experiments on the stamped build only (tools/probe/sweep_stamps.py; results are WRONG under them, timing is the point):
+// 1 = stage 1 does not reload its codeword tiles, 2 = stage 2 runs the home tile only, 4 = no rows request,
+// 8 = the cell sums' atomics are skipped, 16 = no codeword-row gathers in the evaluation, 32 = rows request of even frames
+// only (16-byte aligned pieces), 64 = rows request without the frame-number shuffle
+__device__ int g_sweep_exp;
+#define SW_EXP(bit) ((sw_exp & (bit)) != 0)
+#define SW_STAMP_DECL unsigned long long sw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sw_conv = 0, sw_t = __builtin_amdgcn_s_memtime(), sw_n = 0; \
+    const int sw_exp = __builtin_amdgcn_readfirstlane(g_sweep_exp);
 #define SW_STAMP(i)                                                                          \
     {                                                                                        \
         if (E2VQ_SWEEP_STAMP == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
@@ -289,6 +296,7 @@ __device__ unsigned long long g_sweep_stamps[16];
 #else
 #define SW_STAMP_DECL
 #define SW_STAMP(i)
+#define SW_EXP(bit) false
 #endif
 
 struct SweepCounters {
@@ -448,10 +456,11 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
             // are invariants of the block loop -- hoisted, kept in 2 RP registers for the whole kernel, and spilled)
             const int lane_q = pre_fresh_lane();
 #pragma unroll 1
-            for (int k = 0; k < SL::RP; ++k) {
+            for (int k = 0; k < (SW_EXP(4) ? 0 : SL::RP); ++k) {
                 const unsigned q = (unsigned)(k * 64 + lane_q);
                 const unsigned slot = q / (unsigned)SL::RP, pc = q - slot * (unsigned)SL::RP;
-                const unsigned fr_ = (unsigned)__shfl((int)fs, (int)slot, 64);
+                unsigned fr_ = SW_EXP(64) ? fs : (unsigned)__shfl((int)fs, (int)slot, 64);
+                if (SW_EXP(32)) fr_ &= ~1u;
                 // (a padding piece fetches the row's first piece again: any valid address)
                 const char* g = (const char*)fz.aos + ((size_t)fr_ * (size_t)(NC * 8) + (size_t)((pc < (unsigned)SL::RP0 ? pc : 0u) * 16u));
                 __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(wlds + k * 1024), 16, 0, 0);
@@ -507,7 +516,7 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
 #pragma unroll
                 for (int k = 0; k < ND; ++k) {
                     const int i = i0 + k;
-                    sweep_load_tile<NC>(A[(k + ND - 1) % ND], cimg, tile_at(i + ND - 1), lane, true);
+                    if (!SW_EXP(1)) sweep_load_tile<NC>(A[(k + ND - 1) % ND], cimg, tile_at(i + ND - 1), lane, true);
                     if (i < MT) {  // (wave-uniform)
                         const int tile = tile_at(i);
                         const float m1 = sweep_coarse_job_pinned<NC>(acc0, A[k], B[0], acc1);  // (digests tile_prev, column block 1)
@@ -532,6 +541,10 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
                 digest1(m);
             }
             njobs += 2ull * MT;
+            if (SW_EXP(2)) {
+                ntl = 1;
+                tlist[0] = (unsigned short)((unsigned)home | 3u << 8);
+            }
             SW_STAMP(1)  // stage 1
             home_n = home_of(f0n);  // (the next block's list entries have long arrived)
             // ---- stage 2: the flagged tiles with all their k-steps and the key epilogue ---------------------------------------
@@ -603,11 +616,11 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
                 const double2* r1 = (const double2*)(fz.cbq + (size_t)c1 * NPAD);
                 const double2* r2 = (const double2*)(fz.cbq + (size_t)c2 * NPAD);
 #pragma unroll
-                for (int n2 = 0; n2 < NH; ++n2) x[n2] = r1[n2];  // (rows are padded to a multiple of 8 doubles)
+                for (int n2 = 0; n2 < NH; ++n2) x[n2] = SW_EXP(16) ? make_double2(1.0, 1.0) : r1[n2];  // (rows are padded to a multiple of 8 doubles)
                 // (the runner-up's row only where it can matter: a gather costs the texture path a request per lane)
 #pragma unroll
                 for (int n2 = 0; n2 < NH; ++n2) y[n2] = make_double2(0.0, 0.0);
-                if (amb) {
+                if (amb && !SW_EXP(16)) {
 #pragma unroll
                     for (int n2 = 0; n2 < NH; ++n2) y[n2] = r2[n2];
                 }
@@ -739,9 +752,10 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
                         }
                     }
                     i64* dst = key < fz.M ? fz.rows + (size_t)key * RS : fz.fam + (size_t)(key - fz.M) * RS;
+                    if (SW_EXP(8)) a0 = 0, a1 = 0;
                     if (lane < 2 * NC && a0 != 0) atomicAdd((u64*)&dst[lane], (u64)a0);
                     if (2 * NC > 64 && lane < 2 * NC - 64 && a1 != 0) atomicAdd((u64*)&dst[64 + lane], (u64)a1);
-                    if (lane == 63) {
+                    if (lane == 63 && !SW_EXP(8)) {
                         const i64 cnt = (i64)__builtin_popcountll(sN) - (i64)__builtin_popcountll(sO);
                         if (cnt != 0) atomicAdd((u64*)&dst[2 * NC], (u64)cnt);
                     }
@@ -996,6 +1010,11 @@ __global__ __launch_bounds__(FinLds<NC>::WAVES * 64) void k_finish(const double*
 // ---- launch wrappers ----------------------------------------------------------------------------------------------------------
 #ifdef E2VQ_SWEEP_STAMP
 }  // namespace e2vq
+extern "C" int e2vq_debug_sweep_exp(int mode)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(e2vq::g_sweep_exp), &mode, sizeof(int)) != hipSuccess;
+}
+
 extern "C" int e2vq_debug_sweep_stamps(unsigned long long* out16, int reset)
 {
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(e2vq::g_sweep_stamps), 16 * 8) != hipSuccess) return 1;
