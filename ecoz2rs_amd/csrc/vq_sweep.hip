@@ -55,6 +55,21 @@ struct SweepImg {
             if (PK::step_pair(s) == p) return true;
         return false;
     }
+    // registers of the coarse stage with FOUR column blocks resident (two blocks of 64 slots per turn of the fused kernel):
+    // their coarse pairs, two sets of coarse granules, the accumulators of two jobs -- beside ~55 of everything else
+    __host__ __device__ static constexpr int count_coarse_pairs()
+    {
+        int n = 0;
+        for (int p = 0; p < PK::PAIRS; ++p) n += coarse_pair(p) ? 1 : 0;
+        return n;
+    }
+    __host__ __device__ static constexpr int count_coarse_unique()
+    {
+        int n = 0;
+        for (int u = 0; u < PK::NU; ++u) n += coarse_unique(u) ? 1 : 0;
+        return n;
+    }
+    static constexpr bool TWO_BLOCKS_FIT = 16 * count_coarse_pairs() + 8 * count_coarse_unique() + 64 <= 200;
 };
 
 // ---- frame-major limb image: the same limbs as k_pre_frames (same scales, same pre_split), one frame's granules together --
@@ -387,20 +402,28 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
     }
     const float ymax1 = __int_as_float(ps->ymax_bits);
     const float relk = __int_as_float((127 + __builtin_popcount(~idxmask) - 21) << 23);  // 2 rho, rho = 2^-(22-idxbits)
-    int maskv = idxmask;
-    asm volatile("" : "+v"(maskv));
-    float ninf = -__builtin_inff();
-    asm volatile("" : "+v"(ninf));
     const float pinf = __builtin_inff();
     const int col = lane & 31, h = lane >> 5;
     unsigned long long nflag = 0, njobs = 0;
     SW_STAMP_DECL
 
-    // the block's slots -> frames; lane (h, col) holds lane half h of the granules of slots col and 32 + col.  Loop-carried:
-    // the frames, the home tile and the B operands of a block are requested while the block before it is still at work
-    // (three dependent global latencies -- list, home cell, granules -- would otherwise open every block)
+    // A turn of the loop = NB blocks of 64 slots = NCB column blocks of 32.  The fused two-stage kernel takes TWO blocks per
+    // turn: what bounds its stage 1 is not the matrix pipe but what the codeword tiles' operand loads cost the CU's
+    // vector-memory path (profiles/r05_sweep_experiments.txt: 6 KB per tile and wave; without the reloads the stage runs at
+    // the pipe's rate) -- with four column blocks a loaded tile serves four jobs instead of two.  The coarse stage needs the
+    // pairs holding frame limbs 0 and 1 only (5 of 7 at P = 36: 20 registers per column block); the others are fetched
+    // behind it, block by block, for stage 2.
+    constexpr int NB = (TWO && FUSE && SweepImg<NC>::TWO_BLOCKS_FIT) ? 2 : 1;
+    constexpr int NCB = 2 * NB;
+    const long nturns = (nblocks + NB - 1) / NB;
+
+    // slots -> frames; lane (h, col) holds lane half h of the granules of slots col and 32 + col of each block.  Loop-carried:
+    // the frames, the home tile and the B operands of a turn are requested while the turn before it is still at work
+    // (three dependent global latencies -- list, home cell, granules -- would otherwise open every turn)
     auto slot_frames = [&](long blk, unsigned& fa, unsigned& fb) {
-        long s0 = blk * 64 + col, s1 = s0 + 32;
+        int cq = col;  // (afresh at every call: see load_pairs)
+        asm volatile("" : "+v"(cq));
+        long s0 = blk * 64 + cq, s1 = s0 + 32;
         s0 = s0 < T ? s0 : T - 1;
         s1 = s1 < T ? s1 : T - 1;
         fa = perm ? perm[s0] : (unsigned)s0;
@@ -415,45 +438,54 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
         }
         return hm;
     };
-    h8 B[2][PK::PAIRS];
-    float g0 = 0.f, g1 = 0.f;
-    auto load_B = [&](unsigned fa, unsigned fb) {
-        const unsigned char* p0 = fimg + (size_t)fa * FS;
-        const unsigned char* p1 = fimg + (size_t)fb * FS;
-#pragma unroll
-        for (int p = 0; p < PK::PAIRS; ++p) {
-            B[0][p] = *(const h8*)(p0 + p * 32 + h * 16);
-            B[1][p] = *(const h8*)(p1 + p * 32 + h * 16);
-        }
-        g0 = *(const float*)(p0 + PK::PAIRS * 32);
-        g1 = *(const float*)(p1 + PK::PAIRS * 32);
-    };
-    unsigned f0n = 0, f1n = 0;
+    h8 B[NCB][PK::PAIRS];
+    float g[NCB];
+    unsigned fn[NCB];
     int home_n = 0;
-    if (wave < nblocks) {
-        slot_frames(wave, f0n, f1n);
-        home_n = home_of(f0n);
-        load_B(f0n, f1n);
+    // WHICH: 1 = the coarse stage's pairs, 2 = the others, 4 = g
+    auto load_pairs = [&](h8 (&Bc)[PK::PAIRS], float& gg, unsigned fr, int which) {
+        // (the lane half's offset made afresh at every call: as a loop invariant the per-lane base pointer is one more pair of
+        // registers alive across stage 1, whose budget has none left)
+        int hq = h * 16;
+        asm volatile("" : "+v"(hq));
+        const unsigned char* p0 = fimg + (size_t)fr * FS + hq;
+#pragma unroll
+        for (int p = 0; p < PK::PAIRS; ++p)
+            if (which & (SweepImg<NC>::coarse_pair(p) ? 1 : 2)) Bc[p] = *(const h8*)(p0 + p * 32);
+        if (which & 4) gg = *(const float*)(p0 - hq + PK::PAIRS * 32);
+    };
+    auto next_frames = [&](long turn) {
+#pragma unroll
+        for (int hh = 0; hh < NB; ++hh) slot_frames(turn * NB + hh, fn[2 * hh], fn[2 * hh + 1]);
+    };
+    auto request_B = [&]() {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) load_pairs(B[cb], g[cb], fn[cb], NB == 2 ? 5 : 7);
+    };
+    if (wave < nturns) {
+        next_frames(wave);
+        home_n = home_of(fn[0]);
+        request_B();
     }
-    for (long b = wave; b < nblocks; b += nwaves) {
-        const unsigned f0 = f0n, f1 = f1n;
+    for (long turn = wave; turn < nturns; turn += nwaves) {
+        unsigned f[NCB];
+        float gc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) f[cb] = fn[cb], gc[cb] = g[cb];
         const int home = home_n;
-        const float gc0 = g0, gc1 = g1;
-        const long bn = b + nwaves < nblocks ? b + nwaves : b;  // (the wave's last block asks for itself again: no load is conditional)
-        SW_STAMP(0)  // the block's B operands (requested behind the previous block's stage 2) are there
-        slot_frames(bn, f0n, f1n);
-        const unsigned fs = h ? f1 : f0;  // the frame of slot b * 64 + lane
+        const long tn = turn + nwaves < nturns ? turn + nwaves : turn;  // (the wave's last turn asks for itself again: no load is conditional)
+        SW_STAMP(0)  // the turn's B operands (requested behind the previous turn's evaluation) are there
+        if constexpr (!TWO) next_frames(tn);  // (two-stage: behind stage 1, whose registers are the kernel's peak)
         unsigned short oldraw = 0;  // (turned into the old cell further down: a use up here would wait for the requests below)
-        if constexpr (FUSE) {
-            // the block's FP64 rows -> the wave's LDS region, frame by frame (the previous block's reads of it are complete);
-            // they are needed behind stage 2 -- in this wave's in-order queue they only delay the first tile's operands
+        // FUSE: a block's FP64 rows -> the wave's LDS region, frame by frame (the previous block's reads of it are complete).
+        // (RP instructions of 64 pieces of 16 bytes -- an LDS-DMA instruction costs its issue whatever its width: fetched dword
+        // by dword the request took 18 k cycles per block --: lane -> piece q = 64 k + lane of the block's padded row-major image
+        // = piece q % RP of slot q / RP, whose frame number comes from that slot's lane.  The lane index afresh from the
+        // hardware: computed from the kernel's `lane`, every instruction's slot and piece are invariants of the loop -- hoisted,
+        // kept in 2 RP registers for the whole kernel, and spilled)
+        auto request_rows = [&](unsigned fs) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (fz.incr) oldraw = fz.cells[fs];
-            // (RP instructions of 64 pieces of 16 bytes -- an LDS-DMA instruction costs its ~100 cycles of issue whatever its
-            // width: fetched dword by dword the request took 18 k cycles per block --: lane -> piece q = 64 k + lane of the
-            // block's padded row-major image = piece q % RP of slot q / RP, whose frame number comes from that slot's lane)
-            // (the lane index afresh from the hardware: computed from the kernel's `lane`, every instruction's slot and piece
-            // are invariants of the block loop -- hoisted, kept in 2 RP registers for the whole kernel, and spilled)
             const int lane_q = pre_fresh_lane();
 #pragma unroll 1
             for (int k = 0; k < (SW_EXP(4) ? 0 : SL::RP); ++k) {
@@ -462,8 +494,8 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
                 unsigned fr_ = SW_EXP(64) ? fs : (unsigned)__shfl((int)fs, (int)slot, 64);
                 if (SW_EXP(32)) fr_ &= ~1u;
                 // (a padding piece fetches the row's first piece again: any valid address)
-                const char* g = (const char*)fz.aos + ((size_t)fr_ * (size_t)(NC * 8) + (size_t)((pc < (unsigned)SL::RP0 ? pc : 0u) * 16u));
-                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(wlds + k * 1024), 16, 0, 0);
+                const char* gp = (const char*)fz.aos + ((size_t)fr_ * (size_t)(NC * 8) + (size_t)((pc < (unsigned)SL::RP0 ? pc : 0u) * 16u));
+                __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(wlds + k * 1024), 16, 0, 0);
             }
 #ifdef E2VQ_SWEEP_STAMP
             {   // (issue side of the requests only: no drain)
@@ -472,21 +504,18 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
                 sw_t = sw_now;
             }
 #endif
-        }
-        float k1[2], k2[2], k3[2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) k1[cb] = k2[cb] = k3[cb] = __int_as_float(0x7f7fffff);
+        };
+        // the first block's rows are needed behind stage 2 -- in this wave's in-order queue they only delay the first tile
+        // (whose wait, behind a loop of requests, is for everything outstanding: the last row's latency once per turn)
+        if constexpr (FUSE) request_rows(h ? f[1] : f[0]);
+        float k1[NCB], k2[NCB], k3[NCB];
+        int ntl = 0;
 
         if constexpr (TWO) {
-            // ---- stage 1: every tile, weight levels 0 and 1; tiles in cyclic order from the block's home tile ---------------
-            // 2 x 1.27 x E2 of the lane's two frames (coarse-key units; header)
-            const float D0 = 2.54f * (257.f * (gc0 + ymax1) + (129.f * NC + 2.f));
-            const float D1 = 2.54f * (257.f * (gc1 + ymax1) + (129.f * NC + 2.f));
-            float U0 = pinf, U1 = pinf, thr0 = pinf, thr1 = pinf;
-            int ntl = 0;
+            // ---- stage 1: every tile, weight levels 0 and 1; tiles in cyclic order from the turn's home tile -----------------
+            // 2 x 1.27 x E2 of the lane's frames (coarse-key units; header)
             // Two register sets of coarse granules, one tile requested ahead (measured: one, two or three tiles of distance
-            // make no difference -- the stage runs at what the matrix pipe delivers at this clock -- and the registers are
-            // needed by what lives across the whole block in the fused kernel)
+            // make no difference)
             auto tile_at = [&](int i) {
                 i = i < MT ? i : MT - 1;
                 return home + i < MT ? home + i : home + i - MT;
@@ -495,21 +524,32 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
             h8 A[ND][NU];
 #pragma unroll
             for (int k = 0; k < ND - 1; ++k) sweep_load_tile<NC>(A[k], cimg, tile_at(k), lane, true);
-            // accumulators of the two column blocks; each job digests the other's previous values: the "previous" values
-            // of the very first job are huge (no flag), and one more epilogue follows the loop
+            // (per column block only U lives across the jobs: the threshold is made from it and the frame's g when a job is
+            // digested -- four operations against eight registers)
+            float U[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) U[cb] = pinf;
+            // accumulators of two jobs: each job digests the values of the one before it (the next column block of the same
+            // tile, or the last one of the tile before); the "previous" values of the very first job are huge (no flag), and
+            // one more epilogue follows the loop
             f16v acc0[2], acc1[2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f, acc1[1][r] = 3.0e38f;
-            unsigned bits_prev = 0u;  // column block 0's flag of the tile whose column block 1 is still being digested
+            unsigned bits_acc = 0u;  // flags of the column blocks digested so far of the tile whose last one is still to come
             int tile_prev = 0;
-            auto digest1 = [&](float m1) {  // column block 1 of tile_prev: flag, U, threshold; the tile's list entry
-                const bool fl1 = !(m1 > thr1);
-                U1 = __builtin_fminf(U1, m1);
-                thr1 = U1 > 0.f ? __builtin_fmaf(U1, 1.000001f, D1) : pinf;
-                const unsigned bits = bits_prev | (__ballot(fl1) != 0 ? 2u : 0u);
-                if (bits) {  // (wave-uniform; every lane stores the same word)
-                    tlist[ntl] = (unsigned short)((unsigned)tile_prev | bits << 8);
-                    ++ntl;
+            // column block CB of `tile`: flag, U, threshold; with the tile's last column block its list entry
+            auto digest = [&](float m, float& Uc, float gcb, int cb, int tile) {
+                const float Dc = 2.54f * (257.f * (gcb + ymax1) + (129.f * NC + 2.f));
+                const float thrc = Uc > 0.f && Uc < pinf ? __builtin_fmaf(Uc, 1.000001f, Dc) : pinf;
+                const bool fl = !(m > thrc);  // (negated comparison: a NaN key flags its tile)
+                Uc = __builtin_fminf(Uc, m);
+                bits_acc |= __ballot(fl) != 0 ? 1u << cb : 0u;
+                if (cb == NCB - 1) {
+                    if (bits_acc) {  // (wave-uniform; every lane stores the same word)
+                        tlist[ntl] = (unsigned short)((unsigned)tile | bits_acc << 8);
+                        ++ntl;
+                    }
+                    bits_acc = 0u;
                 }
             };
             for (int i0 = 0; i0 < MT; i0 += ND) {
@@ -519,14 +559,16 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
                     if (!SW_EXP(1)) sweep_load_tile<NC>(A[(k + ND - 1) % ND], cimg, tile_at(i + ND - 1), lane, true);
                     if (i < MT) {  // (wave-uniform)
                         const int tile = tile_at(i);
-                        const float m1 = sweep_coarse_job_pinned<NC>(acc0, A[k], B[0], acc1);  // (digests tile_prev, column block 1)
-                        if (i > 0) digest1(m1);
-                        const float m0 = sweep_coarse_job_pinned<NC>(acc1, A[k], B[1], acc0);  // (digests this tile, column block 0)
-                        // (negated comparisons: a NaN key flags its tile)
-                        const bool fl0 = !(m0 > thr0);
-                        U0 = __builtin_fminf(U0, m0);
-                        thr0 = U0 > 0.f ? __builtin_fmaf(U0, 1.000001f, D0) : pinf;
-                        bits_prev = __ballot(fl0) != 0 ? 1u : 0u;
+#pragma unroll
+                        for (int cb = 0; cb < NCB; ++cb) {
+                            const float m = (cb & 1) ? sweep_coarse_job_pinned<NC>(acc1, A[k], B[cb], acc0)
+                                                     : sweep_coarse_job_pinned<NC>(acc0, A[k], B[cb], acc1);
+                            if (cb == 0) {
+                                if (i > 0) digest(m, U[NCB - 1], gc[NCB - 1], NCB - 1, tile_prev);
+                            } else {
+                                digest(m, U[cb - 1], gc[cb - 1], cb - 1, tile);
+                            }
+                        }
                         tile_prev = tile;
                     }
                 }
@@ -538,33 +580,24 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
                 float m = __builtin_fminf(v[0], v[1]);
 #pragma unroll
                 for (int r = 2; r < 16; r += 2) m = __builtin_fminf(m, __builtin_fminf(v[r], v[r + 1]));
-                digest1(m);
+                digest(m, U[NCB - 1], gc[NCB - 1], NCB - 1, tile_prev);
             }
-            njobs += 2ull * MT;
+            njobs += (unsigned long long)NCB * MT;
             if (SW_EXP(2)) {
                 ntl = 1;
-                tlist[0] = (unsigned short)((unsigned)home | 3u << 8);
+                tlist[0] = (unsigned short)((unsigned)home | ((1u << NCB) - 1u) << 8);
             }
             SW_STAMP(1)  // stage 1
-            home_n = home_of(f0n);  // (the next block's list entries have long arrived)
-            // ---- stage 2: the flagged tiles with all their k-steps and the key epilogue ---------------------------------------
-            if (ntl > 0) {
-                h8 Acur[NU], Anext[NU];
-                unsigned e = tlist[0];
-                sweep_load_tile<NC>(Acur, cimg, (int)(e & 0xffu), lane, false);
-                for (int j = 0; j < ntl; ++j) {
-                    const unsigned en = tlist[j + 1 < ntl ? j + 1 : j];
-                    sweep_load_tile<NC>(Anext, cimg, (int)(en & 0xffu), lane, false);
-                    const int tile = (int)(e & 0xffu);
-                    if (e & 0x100u) sweep_full_job<NC>(Acur, B[0], tile, k1[0], k2[0], k3[0], maskv, ninf);
-                    if (e & 0x200u) sweep_full_job<NC>(Acur, B[1], tile, k1[1], k2[1], k3[1], maskv, ninf);
-                    nflag += ((e >> 8) & 1u) + ((e >> 9) & 1u);
+            next_frames(tn);
+        }
 #pragma unroll
-                    for (int u = 0; u < NU; ++u) Acur[u] = Anext[u];
-                    e = en;
-                }
-            }
-        } else {
+        for (int cb = 0; cb < NCB; ++cb) k1[cb] = k2[cb] = k3[cb] = __int_as_float(0x7f7fffff);
+        // (operands of the key epilogue that have to be registers; made behind stage 1, whose budget has none to spare)
+        int maskv = idxmask;
+        asm volatile("" : "+v"(maskv));
+        float ninf = -__builtin_inff();
+        asm volatile("" : "+v"(ninf));
+        if constexpr (!TWO) {
             // ---- one stage: every tile with all its k-steps (frames that are not grouped, or data that flags most tiles) ------
             h8 Acur[NU], Anext[NU];
             sweep_load_tile<NC>(Acur, cimg, 0, lane, false);
@@ -579,18 +612,65 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
             nflag += 2ull * MT;
             home_n = 0;
         }
+#pragma unroll
+        for (int hh = 0; hh < NB; ++hh) {
+        const long b = turn * NB + hh;
+        // (the second block's rows: its turn of the wave's LDS region begins when the first block's sums are done; stage 2 of
+        // the block runs behind the request -- a wave's vector-memory operations return in order, so the block's first tile
+        // arrives with its rows, and its k-steps cover what is left of the evaluation's wait)
+        if (FUSE && hh) request_rows(h ? f[NCB - 1] : f[NCB - 2]);
+        if constexpr (TWO) {
+            // ---- stage 2: the block's flagged tiles with all their k-steps and the key epilogue -------------------------------
+            if constexpr (NB == 2) {
+                // (the second block's coarse pairs again: 40 registers that the first block's stage 2 and tail need more)
+                load_pairs(B[2 * hh], g[2 * hh], f[2 * hh], hh == 0 ? 2 : 3);
+                load_pairs(B[2 * hh + 1], g[2 * hh + 1], f[2 * hh + 1], hh == 0 ? 2 : 3);
+            }
+            const unsigned sh = 8u + 2u * hh;
+            auto next_e = [&](int j) {
+                while (j < ntl && ((tlist[j] >> sh) & 3u) == 0u) ++j;
+                return j;
+            };
+            int j = next_e(0);
+            if (j < ntl) {
+                h8 Acur[NU], Anext[NU];
+                unsigned e = tlist[j];
+                sweep_load_tile<NC>(Acur, cimg, (int)(e & 0xffu), lane, false);
+                while (j < ntl) {
+                    const int jn = next_e(j + 1);
+                    const unsigned en = tlist[jn < ntl ? jn : j];
+                    sweep_load_tile<NC>(Anext, cimg, (int)(en & 0xffu), lane, false);
+                    const int tile = (int)(e & 0xffu);
+                    const unsigned eb = e >> sh;
+                    if (eb & 1u) sweep_full_job<NC>(Acur, B[2 * hh], tile, k1[2 * hh], k2[2 * hh], k3[2 * hh], maskv, ninf);
+                    if (eb & 2u) sweep_full_job<NC>(Acur, B[2 * hh + 1], tile, k1[2 * hh + 1], k2[2 * hh + 1], k3[2 * hh + 1], maskv, ninf);
+                    nflag += (eb & 1u) + ((eb >> 1) & 1u);
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) Acur[u] = Anext[u];
+                    e = en;
+                    j = jn;
+                }
+            }
+            if (hh == 0) home_n = home_of(fn[0]);  // (the next turn's list entries, requested behind stage 1, have arrived)
+        }
         SW_STAMP(2)  // stage 2 (or the one-stage loop)
-        // the next block's B operands: their registers are free from here on (FUSE: requested further down)
-        if constexpr (!FUSE) load_B(f0n, f1n);
+        // the next turn's B operands: their registers are free from here on (FUSE: requested further down)
+        if constexpr (!FUSE) request_B();
 
+        const unsigned f0 = NB == 2 && hh ? f[NCB - 2] : f[0], f1 = NB == 2 && hh ? f[NCB - 1] : f[1];
+        const float gc0 = NB == 2 && hh ? gc[NCB - 2] : gc[0], gc1 = NB == 2 && hh ? gc[NCB - 1] : gc[1];
+        const float ka1 = NB == 2 && hh ? k1[NCB - 2] : k1[0], ka2 = NB == 2 && hh ? k2[NCB - 2] : k2[0],
+                    ka3 = NB == 2 && hh ? k3[NCB - 2] : k3[0];
+        const float kb1 = NB == 2 && hh ? k1[NCB - 1] : k1[1], kb2 = NB == 2 && hh ? k2[NCB - 1] : k2[1],
+                    kb3 = NB == 2 && hh ? k3[NCB - 1] : k3[1];
         // ---- lane = slot b * 64 + lane: merge the two lane halves of its frame's keys, certify the top two ------------------
         const int hb = h << 2;
         float a1, a2, a3, q1, q2, q3;
         {
-            const float o1 = __int_as_float(__float_as_int(k1[0]) | hb), o2 = __int_as_float(__float_as_int(k2[0]) | hb),
-                        o3 = __int_as_float(__float_as_int(k3[0]) | hb);
-            const float r1 = __int_as_float(__float_as_int(k1[1]) | hb), r2 = __int_as_float(__float_as_int(k2[1]) | hb),
-                        r3 = __int_as_float(__float_as_int(k3[1]) | hb);
+            const float o1 = __int_as_float(__float_as_int(ka1) | hb), o2 = __int_as_float(__float_as_int(ka2) | hb),
+                        o3 = __int_as_float(__float_as_int(ka3) | hb);
+            const float r1 = __int_as_float(__float_as_int(kb1) | hb), r2 = __int_as_float(__float_as_int(kb2) | hb),
+                        r3 = __int_as_float(__float_as_int(kb3) | hb);
             a1 = h ? r1 : o1, a2 = h ? r2 : o2, a3 = h ? r3 : o3;  // own frame's keys (slot 32 h + col)
             q1 = h ? o1 : r1, q2 = h ? o2 : r2, q3 = h ? o3 : r3;  // the partner's frame's keys
         }
@@ -598,15 +678,15 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
         const float t3 = med3f(a2, a3, b1), t2 = med3f(a1, a2, b1), t1 = med3f(a1, b1, ninf);
         const float u3 = med3f(t2, t3, b2), u2 = med3f(t1, t2, b2);
         const float w3 = med3f(u2, u3, b3);
-        const float g = h ? gc1 : gc0;
-        const unsigned f = h ? f1 : f0;
-        const float tau = 1.27f * (512.f * (g + ymax1 + (NC + 4.0f)) + relk * t1);
+        const float gfr = h ? gc1 : gc0;
+        const unsigned fr = h ? f1 : f0;
+        const float tau = 1.27f * (512.f * (gfr + ymax1 + (NC + 4.0f)) + relk * t1);
         const bool cert = t1 >= 1.0e-30f && t1 < 1.0e37f && w3 > t1 + tau;
         const bool amb = !(u2 > t1 + tau);
         const unsigned c1 = (unsigned)(__float_as_int(t1) & ~idxmask), c2 = (unsigned)(__float_as_int(u2) & ~idxmask);
         const bool live = b * 64 + lane < T;
         if constexpr (!FUSE) {
-            if (live) cand[f] = c1 | c2 << 13 | (amb ? CAND_AMB : 0u) | (cert ? CAND_CERT : 0u);
+            if (live) cand[fr] = c1 | c2 << 13 | (amb ? CAND_AMB : 0u) | (cert ? CAND_CERT : 0u);
         } else {
             // ---- exact evaluation: the canonical chain acc = fma(r[n], cq[n], acc), n ascending from +0.0; r from the frame's
             // LDS row (inline asm, eight at a time, the fmas pinned behind them: see k_finish), cq gathered from L2 ----------
@@ -649,8 +729,8 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
             const bool take_b = amb && (d2 < d1 || (d2 == d1 && c2 < c1));
             const double best = take_b ? d2 : d1;
             int idx = take_b ? (int)c2 : (int)c1;
-            // the next block's B operands: the codeword rows' registers are free now
-            load_B(f0n, f1n);
+            // the next turn's B operands: the codeword rows' registers are free now
+            if (hh == NB - 1) request_B();
             const bool skip = !cert;
             idx = skip ? 0 : idx;
 #ifdef E2VQ_SWEEP_STAMP
@@ -663,11 +743,11 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
             // ---- outputs; uncertified frames go to the fallback list ----
             if (live) {
                 if (skip) {
-                    fz.fb_list[atomicAdd(&ps->fb_count, 1)] = (int)f;
+                    fz.fb_list[atomicAdd(&ps->fb_count, 1)] = (int)fr;
                 } else {
-                    if (fz.sym) fz.sym[f] = (unsigned short)idx;
-                    if (fz.dmin) fz.dmin[f] = best;
-                    fz.cells[f] = (unsigned short)idx;
+                    if (fz.sym) fz.sym[fr] = (unsigned short)idx;
+                    if (fz.dmin) fz.dmin[fr] = best;
+                    fz.cells[fr] = (unsigned short)idx;
                     const double e = best - 1.0;
                     int h0, l0, h1, l1;
                     if (fast_d) {  // (kernel-uniform; same limbs as fix2: vq_fixed.h)
@@ -775,6 +855,7 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
             sw_n += 1;
         }
 #endif
+    }  // (blocks of the turn)
     }
 #ifdef E2VQ_SWEEP_STAMP
     if (lane == 0) {

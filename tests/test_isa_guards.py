@@ -129,9 +129,10 @@ def test_rotating_tile_loop(asm, pattern):
 @pytest.mark.parametrize("pattern", [r"k_sweep_candILi37ELb1ELb1E"])
 def test_two_stage_sweep_shape(asm, pattern):
     k = Kernel(asm["vq_sweep"], pattern)
-    # the coarse stage's loop: two register sets = two tiles of 2 column blocks x 8 k-steps, no 15-step job inside it,
-    # and the MFMAs of a job interleaved with the previous job's epilogue (never eight in a row)
-    coarse = [lp for lp in k.loops() if lp[2] == 32]
+    # the coarse stage's loop: two register sets = two tiles of 4 column blocks (two blocks of 64 slots per turn: a loaded
+    # tile serves four jobs) x 8 k-steps, no 15-step job inside it, and the MFMAs of a job interleaved with the previous
+    # job's epilogue (never eight in a row)
+    coarse = [lp for lp in k.loops() if lp[2] == 64]
     assert coarse, [lp for lp in k.loops() if lp[2]]
     first, last, _, _ = min(coarse, key=lambda lp: lp[1] - lp[0])
     run, longest = 0, 0
