@@ -28,8 +28,7 @@ struct PrdSet {
 
 // Pinned staging buffers cost page pinning both ways: ~0.2 ms per MB to make, ~0.13 ms per MB to release
 // (tools/probe/alloc_cost.hip: 2 x 78 MB = 27-35 ms + 19-22 ms -- a fifth of a warm ecoz2_vq_learn over 10 M frames, a third
-// of an ecoz2_vq_quantize).  The process keeps them for its next call instead: up to ECOZ2_VQ_PINNED_KEEP_MB (default 512; 0 =
-// allocate and free every time) stay in this pool, portable across devices; whatever is pooled when the process ends is left to
+// of an ecoz2_vq_quantize).  The process keeps them for its next call instead: up to 512 MB stay in this pool, portable across devices; whatever is pooled when the process ends is left to
 // the operating system (the HIP runtime may already be gone when static destructors run).
 namespace {
 struct PinnedPool {
@@ -42,8 +41,7 @@ struct PinnedPool {
     size_t kept = 0;
     static size_t cap()
     {
-        static const size_t c = (size_t)(getenv("ECOZ2_VQ_PINNED_KEEP_MB") ? std::max(0, atoi(getenv("ECOZ2_VQ_PINNED_KEEP_MB"))) : 512) << 20;
-        return c;
+        return (size_t)512 << 20;
     }
     // a buffer of at least `bytes` (an idle one no larger than twice that, else a new one); null on failure
     void* acquire(size_t bytes, size_t* got)

@@ -126,22 +126,31 @@ static int session_init(e2vq_session* s)
     const char* pf = getenv("ECOZ2_VQ_PREFILTER");
     s->pre_enabled = e2vq::prefilter_supports(s->NC, 64) && !(pf && atoi(pf) == 0);
     if (const char* mm = getenv("ECOZ2_VQ_PREFILTER_MIN_M")) s->pre_min_M = s->pre_min_M_quant = std::max(64, atoi(mm));
-    if (const char* inc = getenv("ECOZ2_VQ_INCREMENTAL")) s->incr_enabled = atoi(inc) != 0;
-    if (const char* pf1 = getenv("ECOZ2_VQ_PLAIN_FIRST")) s->plain_first = atoi(pf1) != 0;
-    if (const char* fm = getenv("ECOZ2_VQ_FAMILY_MIN_M")) s->fam_min_M = std::max(64, atoi(fm));
-    if (const char* rc = getenv("ECOZ2_VQ_RECORDS")) s->rec_enabled = atoi(rc) != 0;
-    if (const char* rc = getenv("ECOZ2_VQ_RECORDS_MAX_MB")) s->rec_max_bytes = (size_t)std::max(0, atoi(rc)) << 20;
     if (const char* rc = getenv("ECOZ2_VQ_RECORDS_FEW_DIV")) s->rec_few_div = std::max(0, atoi(rc));
-    if (const char* sw = getenv("ECOZ2_VQ_SPLIT_SWEEP")) s->sweep2_enabled = atoi(sw) != 0;
-    if (const char* sw = getenv("ECOZ2_VQ_TWO_STAGE")) s->two_stage_enabled = atoi(sw) != 0;
-    if (const char* sw = getenv("ECOZ2_VQ_FUSED_SORTED")) s->fused_enabled = atoi(sw) != 0;
-    if (const char* sw = getenv("ECOZ2_VQ_FUSED_MIN_M")) s->fused_min_M = std::max(64, atoi(sw));
-    // With the recorded accumulate the prefiltered pass also wins at M = 128 (0.36 vs 0.43 ms per pass on 2^21 frames; not
-    // at 64: 0.30 vs 0.28), and a seeded first pass halves the records of every prefiltered level's first pass
-    if (s->rec_enabled && e2vq::prefilter_lds_stage(s->NC)) {
-        if (!getenv("ECOZ2_VQ_PREFILTER_MIN_M")) s->pre_min_M = 128;
-        if (!getenv("ECOZ2_VQ_FAMILY_MIN_M")) s->fam_min_M = 128;
+    // ECOZ2_VQ_ACCUMULATE: which kernels a prefiltered training pass runs -- one switch for the tests and the probes, which
+    // have to reach every one of them; "auto" is the product
+    {
+        const char* am = getenv("ECOZ2_VQ_ACCUMULATE");
+        const std::string acc = am ? am : "auto";
+        if (acc == "sorted") {           // the fused sorted pass wherever the prefilter runs (default: from M = 256)
+            s->sweep_min_M = 64;
+        } else if (acc == "sweep") {     // candidate sweep + finishing kernel + k_reduce_records, grouped or not
+            s->fused_enabled = false;
+            s->sweep_min_M = 64;
+        } else if (acc == "records") {   // round 4: k_pass_pre_lds recording its contributions + k_reduce_records
+            s->sweep2_enabled = false;
+        } else if (acc == "burst") {     // round 3: k_pass_pre_lds with its burst of atomics
+            s->sweep2_enabled = false;
+            s->rec_enabled = false;
+        } else if (acc == "full") {      // every pass accumulates every frame (no seeded first pass, no incremental ones)
+            s->incr_enabled = false;
+        } else if (acc != "auto") {
+            return e2vq_set_error("ECOZ2_VQ_ACCUMULATE=%s: auto, sorted, sweep, records, burst or full", acc.c_str());
+        }
     }
+    // With the recorded accumulate the prefiltered pass also wins at M = 128 (0.36 vs 0.43 ms per pass on 2^21 frames; not
+    // at 64: 0.30 vs 0.28)
+    if (s->rec_enabled && e2vq::prefilter_lds_stage(s->NC) && !getenv("ECOZ2_VQ_PREFILTER_MIN_M")) s->pre_min_M = 128;
     if (s->pre_enabled) {
         HIPCHK(hipMalloc(&s->d_colmax, (size_t)s->NC * 8));
         HIPCHK(hipMalloc(&s->d_ea, (size_t)s->NC * sizeof(int)));
@@ -560,7 +569,7 @@ extern "C" int e2vq_grow(e2vq_session* s)
     // The rows and cells of the last pass over the codebook about to be split seed the first pass of the next size
     // (k_seed_family): they must be this rank's own sums, for the codebook as it stands, with every frame's cell recorded.
     const bool seed = s->fam_enabled && s->pre_enabled && s->d_aos && s->d_prev_sym && s->rows_fresh && s->rows_are_local &&
-                      s->cells_M == s->M && 2 * s->M >= s->pre_min_M && 2 * s->M >= s->fam_min_M &&
+                      s->cells_M == s->M && 2 * s->M >= s->pre_min_M &&
                       e2vq::prefilter_supports(s->NC, 2 * s->M) &&
                       e2vq::prefilter_lds_stage(s->NC) && s->incr_enabled;
     if (seed) {

@@ -294,12 +294,7 @@ int e2vq_io::prd_read_range_mt(const char* path, int P, int64_t first, int64_t c
 
 int e2vq_io::io_threads()
 {
-    static const int n = [] {
-        const char* e = getenv("ECOZ2_VQ_IO_THREADS");
-        const int v = e ? atoi(e) : 4;
-        return v < 1 ? 1 : (v > 64 ? 64 : v);
-    }();
-    return n;
+    return 4;
 }
 
 extern "C" int e2vq_prd_write(const char* path, const char* class_name, int P, const double* frames, int64_t T)

@@ -106,10 +106,10 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     s->fam_pending = false;
     // round 5: the frames are grouped by cell (a seeded first pass, or an incremental one) -> the fused sorted pass: sweep,
     // exact evaluation, outputs and the cell sums reduced in the block, one kernel (vq_sweep.hip); no records
-    // (from fused_min_M codewords on: at M = 128 a pass is bound by reading its frames, which round 4's kernel does in
+    // (from sweep_min_M codewords on: at M = 128 a pass is bound by reading its frames, which round 4's kernel does in
     // their natural order -- 0.35 against 0.40 ms on 2^21 frames; at 256 the two are level, beyond it the sorted pass wins)
     const bool fused = keep && mode != 0 && (family || incremental) && s->sweep2_enabled && s->fused_enabled && s->d_fimgF &&
-                       s->d_aos && s->M >= s->fused_min_M && e2vq::sweep_supported(s->NC, s->M);
+                       s->d_aos && s->M >= s->sweep_min_M && e2vq::sweep_supported(s->NC, s->M);
     // round 4: contributions recorded by the sweep, folded into the rows by k_reduce_records
     e2vq::PassRecords recplan{};
     bool records = false;
@@ -122,7 +122,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         if (!incremental) {
             s->rec_level_burst = false;
             s->rec_last_total = -1;
-        } else if (records && !(s->sweep2_enabled && s->d_fimgF && s->M >= s->fused_min_M) && s->rec_few_div > 0 && e2vq::prefilter_burst_supported(s->NC) &&
+        } else if (records && !(s->sweep2_enabled && s->d_fimgF && s->M >= s->sweep_min_M) && s->rec_few_div > 0 && e2vq::prefilter_burst_supported(s->NC) &&
                    (s->rec_level_burst || (s->rec_last_total >= 0 && s->rec_last_total < s->T / s->rec_few_div))) {
             s->rec_level_burst = true;
             records = false;
@@ -160,18 +160,14 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     }
     // (P = 40: rows of 83 elements are seeded only where the contributions are recorded -- the burst cannot add them)
     if (family && !records && !fused && !e2vq::prefilter_burst_supported(s->NC)) family = false;
-    // The first pass of a level accumulates in full.  For the smallest prefiltered sizes that is cheaper on the plain
-    // FP64 sweep with its workgroup-local LDS table (hybrid accumulate: 0.92 vs 1.5 ms at M = 256, where 2^21 frames
-    // hammer 256 rows with global atomics); it records the cells for the incremental passes that follow.
-    const bool plain_first = s->plain_first && keep && !incremental && !family && !records && !fused && mode == 5 && s->M <= 384;
-    if (s->last_prefiltered && !plain_first && ensure_codebook_image(s)) return 1;
+    if (s->last_prefiltered && ensure_codebook_image(s)) return 1;
     {
         // one prologue launch: the rows (all of them, or the distortion columns of an incremental pass), the fallback
         // count of a codebook image that is already there, and what the speculative update after this pass
         // accumulates into with atomicMax (the shadow codebook's L1 max and the scalars of its limb image)
         e2vq::ZeroList z{};
         int nz = 0;
-        if (s->last_prefiltered && !plain_first && s->img_valid[s->img_cur]) {
+        if (s->last_prefiltered && s->img_valid[s->img_cur]) {
             z.p[nz] = (void*)e2vq::prefilter_fallback_count(s->d_ps2[s->img_cur]);
             z.words[nz++] = 1;
         }
@@ -190,25 +186,10 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     }
     // a plain pass records every frame's cell when the next size could be seeded from it (the level below the first
     // prefiltered one)
-    const bool record_cells = !s->last_prefiltered && !plain_first && mode != 0 && s->fam_enabled && s->pre_enabled &&
-                              s->d_prev_sym && s->d_aos && !device_sym && 2 * s->M >= s->pre_min_M && 2 * s->M >= s->fam_min_M &&
+    const bool record_cells = !s->last_prefiltered && mode != 0 && s->fam_enabled && s->pre_enabled &&
+                              s->d_prev_sym && s->d_aos && !device_sym && 2 * s->M >= s->pre_min_M &&
                               e2vq::prefilter_supports(s->NC, 2 * s->M);
-    if (plain_first) {
-        unsigned short* sym_out = device_sym ? (unsigned short*)device_sym : s->d_prev_sym;
-        if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));
-        s->n_plain_launches++;
-        e2vq::launch_pass(s->NC, mode, s->d_blk, s->T, s->nblocks, s->d_cbq, s->d_cbm ? s->d_cbm : s->d_cbT, s->M, s->d_sc, s->d_l1max, sym_out,
-                          (double*)device_dmin, rows, s->stream);
-        if (s->timing) {
-            HIPCHK(hipEventRecord(s->ev1, s->stream));
-            s->timed = true;
-            s->timing_pending = true;
-        }
-        if (sym_out != s->d_prev_sym)
-            HIPCHK(hipMemcpyAsync(s->d_prev_sym, sym_out, (size_t)s->T * sizeof(unsigned short), hipMemcpyDeviceToDevice,
-                                  s->stream));
-        s->last_prefiltered = false;
-    } else if (s->last_prefiltered) {
+    if (s->last_prefiltered) {
         // f16 limb image of the current codebook, prefiltered sweep (exact evaluation of the certified top two),
         // then the full FP64 sweep of whatever it could not certify
         const int k = s->img_cur;
@@ -232,7 +213,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
                 s->perm_M = s->M;
             }
             // (two stages need tiles to skip: from eight tiles on; below, the home tile alone is a quarter or half of the codebook)
-            const bool two = s->two_stage_enabled && s->M >= 256 && s->M > s->two_stage_off_until_M;
+            const bool two = s->M >= 256 && s->M > s->two_stage_off_until_M;
             // the flagged fraction is looked at once per level: on its first pass
             const bool count = two && incr == 2;
             s->last_kind = 3;
@@ -260,7 +241,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
                                        (double*)device_dmin, rows, s->d_fblist, e2vq::prefilter_fallback_count(d_ps), s->d_prev_sym,
                                        incr, s->stream);
             if (family) e2vq::launch_family_fixup(rows, s->d_fam, s->fam_M, s->NC, s->stream);
-        } else if (records && s->sweep2_enabled && s->d_fimgF && s->M >= s->fused_min_M && e2vq::sweep_supported(s->NC, s->M)) {
+        } else if (records && s->sweep2_enabled && s->d_fimgF && s->M >= s->sweep_min_M && e2vq::sweep_supported(s->NC, s->M)) {
             // round 5: [sort] -> candidate sweep -> finishing kernel (exact evaluation, outputs, records) -> reduce
             const int incr = family ? 2 : (incremental ? 1 : 0);
             if (incr != 0 && (incr == 2 || s->perm_M != s->M)) {
@@ -271,7 +252,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             }
             const bool sorted = incr != 0 && s->perm_M == s->M;
             // (two stages need tiles to skip: from eight tiles on; below, the home tile alone is a quarter or half of the codebook)
-            const bool two = sorted && s->two_stage_enabled && s->M >= 256 && s->M > s->two_stage_off_until_M;
+            const bool two = sorted && s->M >= 256 && s->M > s->two_stage_off_until_M;
             s->last_kind = 2;
             s->n_sweep_launches++;
             s->last_two_stage = two;

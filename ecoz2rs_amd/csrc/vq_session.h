@@ -143,7 +143,6 @@ struct e2vq_session {
     // incremental accumulation (prefiltered passes): the rank's own rows and every frame's cell persist between
     // passes of one codebook size; a pass then moves only the frames whose cell changed (vq_accum.h)
     bool incr_enabled = true, incr_valid = false;
-    bool plain_first = true;  // first (full) pass of the smallest prefiltered levels on the plain hybrid kernel
     int incr_M = 0;
     unsigned short* d_prev_sym = nullptr;
     // round 4: the RECORDED accumulate -- the accumulating sweep writes an 8-byte record per contribution into the region
@@ -171,9 +170,8 @@ struct e2vq_session {
     // and data whose near codewords share tiles: the finishing kernel publishes the flagged fraction of every two-stage
     // sweep, and above two_stage_max_frac the rest of the level (and the next one) runs the one-stage sweep.
     bool sweep2_enabled = true;
-    bool fused_enabled = true;       // ECOZ2_VQ_FUSED_SORTED=0: grouped passes as sweep + finishing kernel + reduce too (A/B)
-    int fused_min_M = 256;           // ECOZ2_VQ_FUSED_MIN_M
-    bool two_stage_enabled = true;   // ECOZ2_VQ_TWO_STAGE=0: one-stage sweep always
+    bool fused_enabled = true;       // ECOZ2_VQ_ACCUMULATE=sweep: grouped passes as sweep + finishing kernel + reduce too (A/B)
+    int sweep_min_M = 256;           // smallest codebook of the round-5 kernels (ECOZ2_VQ_ACCUMULATE=sorted / sweep: 64)
     double two_stage_max_frac = 0.45;
     int two_stage_off_until_M = 0;   // one-stage sweeps while M <= this
     bool sw_pending = false;         // a two-stage sweep's counters have not been read yet
@@ -191,7 +189,6 @@ struct e2vq_session {
     // size, stashed by e2vq_grow, and the side table of the in-family arrivals
     bool fam_enabled = true, fam_pending = false;
     int fam_M = 0, fam_cap = 0;
-    int fam_min_M = 512;  // smallest size whose first pass is seeded: at M = 256 the atomics of 2^21 frames crowd onto 384
                           // rows and the plain first pass with its workgroup LDS table is faster (0.96 vs 1.08 ms)
     int cells_M = 0;             // codebook size d_prev_sym's cells belong to (0: not valid)
     bool rows_local_is_current = false;  // d_rows_local (not d_rows) holds this rank's rows of the last pass

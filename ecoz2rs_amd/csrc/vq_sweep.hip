@@ -413,7 +413,10 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
     // the pipe's rate) -- with four column blocks a loaded tile serves four jobs instead of two.  The coarse stage needs the
     // pairs holding frame limbs 0 and 1 only (5 of 7 at P = 36: 20 registers per column block); the others are fetched
     // behind it, block by block, for stage 2.
-    constexpr int NB = (TWO && FUSE && SweepImg<NC>::TWO_BLOCKS_FIT) ? 2 : 1;
+#ifndef E2VQ_SWEEP_ONE_BLOCK  // (A/B switch of the probes: tools/probe/ab/build_variant.sh)
+#define E2VQ_SWEEP_ONE_BLOCK 0
+#endif
+    constexpr int NB = (TWO && FUSE && SweepImg<NC>::TWO_BLOCKS_FIT && !E2VQ_SWEEP_ONE_BLOCK) ? 2 : 1;
     constexpr int NCB = 2 * NB;
     const long nturns = (nblocks + NB - 1) / NB;
 
@@ -487,11 +490,18 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (fz.incr) oldraw = fz.cells[fs];
             const int lane_q = pre_fresh_lane();
+            // (the next instruction's frame numbers are shuffled while this one is issued: 0.70 -> 0.68 ms at M = 1024)
+            unsigned fr_next = (unsigned)__shfl((int)fs, (int)((unsigned)lane_q / (unsigned)SL::RP), 64);
 #pragma unroll 1
             for (int k = 0; k < (SW_EXP(4) ? 0 : SL::RP); ++k) {
                 const unsigned q = (unsigned)(k * 64 + lane_q);
                 const unsigned slot = q / (unsigned)SL::RP, pc = q - slot * (unsigned)SL::RP;
-                unsigned fr_ = SW_EXP(64) ? fs : (unsigned)__shfl((int)fs, (int)slot, 64);
+                unsigned fr_ = fr_next;
+                {
+                    const unsigned qn = (unsigned)((k + 1 < SL::RP ? k + 1 : k) * 64 + lane_q);
+                    fr_next = (unsigned)__shfl((int)fs, (int)(qn / (unsigned)SL::RP), 64);
+                }
+                if (SW_EXP(64)) fr_ = fs;
                 if (SW_EXP(32)) fr_ &= ~1u;
                 // (a padding piece fetches the row's first piece again: any valid address)
                 const char* gp = (const char*)fz.aos + ((size_t)fr_ * (size_t)(NC * 8) + (size_t)((pc < (unsigned)SL::RP0 ? pc : 0u) * 16u));
@@ -530,20 +540,21 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) U[cb] = pinf;
             // accumulators of two jobs: each job digests the values of the one before it (the next column block of the same
-            // tile, or the last one of the tile before); the "previous" values of the very first job are huge (no flag), and
-            // one more epilogue follows the loop
+            // tile, or the last one of the tile before); the "previous" values of the very first job are +inf -- its digest runs
+            // like any other (a branch around it would take the job's epilogue out from between its MFMAs), changes nothing
+            // and is barred from flagging --, and one more epilogue follows the loop
             f16v acc0[2], acc1[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f, acc1[1][r] = 3.0e38f;
+            for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f, acc1[1][r] = pinf;
             unsigned bits_acc = 0u;  // flags of the column blocks digested so far of the tile whose last one is still to come
             int tile_prev = 0;
             // column block CB of `tile`: flag, U, threshold; with the tile's last column block its list entry
-            auto digest = [&](float m, float& Uc, float gcb, int cb, int tile) {
+            auto digest = [&](float m, float& Uc, float gcb, int cb, int tile, bool valid) {
                 const float Dc = 2.54f * (257.f * (gcb + ymax1) + (129.f * NC + 2.f));
                 const float thrc = Uc > 0.f && Uc < pinf ? __builtin_fmaf(Uc, 1.000001f, Dc) : pinf;
                 const bool fl = !(m > thrc);  // (negated comparison: a NaN key flags its tile)
                 Uc = __builtin_fminf(Uc, m);
-                bits_acc |= __ballot(fl) != 0 ? 1u << cb : 0u;
+                bits_acc |= (valid && __ballot(fl) != 0) ? 1u << cb : 0u;
                 if (cb == NCB - 1) {
                     if (bits_acc) {  // (wave-uniform; every lane stores the same word)
                         tlist[ntl] = (unsigned short)((unsigned)tile | bits_acc << 8);
@@ -563,11 +574,10 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
                         for (int cb = 0; cb < NCB; ++cb) {
                             const float m = (cb & 1) ? sweep_coarse_job_pinned<NC>(acc1, A[k], B[cb], acc0)
                                                      : sweep_coarse_job_pinned<NC>(acc0, A[k], B[cb], acc1);
-                            if (cb == 0) {
-                                if (i > 0) digest(m, U[NCB - 1], gc[NCB - 1], NCB - 1, tile_prev);
-                            } else {
-                                digest(m, U[cb - 1], gc[cb - 1], cb - 1, tile);
-                            }
+                            if (cb == 0)
+                                digest(m, U[NCB - 1], gc[NCB - 1], NCB - 1, tile_prev, i > 0);
+                            else
+                                digest(m, U[cb - 1], gc[cb - 1], cb - 1, tile, true);
                         }
                         tile_prev = tile;
                     }
@@ -580,7 +590,7 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
                 float m = __builtin_fminf(v[0], v[1]);
 #pragma unroll
                 for (int r = 2; r < 16; r += 2) m = __builtin_fminf(m, __builtin_fminf(v[r], v[r + 1]));
-                digest(m, U[NCB - 1], gc[NCB - 1], NCB - 1, tile_prev);
+                digest(m, U[NCB - 1], gc[NCB - 1], NCB - 1, tile_prev, true);
             }
             njobs += (unsigned long long)NCB * MT;
             if (SW_EXP(2)) {

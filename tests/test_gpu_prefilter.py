@@ -69,7 +69,6 @@ class _DeviceBuffer:
 def _gpu_pass(frames, refl, monkeypatch, prefilter=True):
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER", "1" if prefilter else "0")
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
-    monkeypatch.setenv("ECOZ2_VQ_PLAIN_FIRST", "0")  # (by default the first pass of a level at M <= 384 is a plain one)
     T = frames.shape[0]
     sym, dmin = _DeviceBuffer(2 * T), _DeviceBuffer(8 * T)
     with e.VqSession(P) as s:
@@ -219,15 +218,9 @@ def test_incremental_rows_match_a_full_accumulation_every_pass(oracle, monkeypat
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
     # the accumulates of a prefiltered pass -- "sorted" (round 5, the default from M = 256 on; here from 64): a full first
     # pass as candidate sweep + finishing kernel + k_reduce_records, then the fused pass over frames grouped by cell;
-    # "sweep": candidate sweep + finishing kernel + k_reduce_records throughout (ECOZ2_VQ_FUSED_SORTED=0); "records": round
-    # 4's fused kernel, whose sweep records every contribution for k_reduce_records; "burst": round 3's one kernel with its
-    # atomics, the first pass of M = 256 on the plain hybrid kernel
-    plain_first = accumulate == "burst"
-    monkeypatch.setenv("ECOZ2_VQ_RECORDS", "0" if accumulate == "burst" else "1")
-    monkeypatch.setenv("ECOZ2_VQ_PLAIN_FIRST", "1" if plain_first else "0")
-    monkeypatch.setenv("ECOZ2_VQ_SPLIT_SWEEP", "1" if accumulate in ("sorted", "sweep") else "0")
-    monkeypatch.setenv("ECOZ2_VQ_FUSED_SORTED", "1" if accumulate == "sorted" else "0")
-    monkeypatch.setenv("ECOZ2_VQ_FUSED_MIN_M", "64")
+    # "sweep": candidate sweep + finishing kernel + k_reduce_records throughout; "records": round 4's fused kernel, whose
+    # sweep records every contribution for k_reduce_records; "burst": round 3's one kernel with its atomics
+    monkeypatch.setenv("ECOZ2_VQ_ACCUMULATE", accumulate)
     if collective:
         monkeypatch.setenv("ECOZ2_VQ_FORCE_ALLREDUCE", "1")
     frames = _frames(20257, 9000)
@@ -261,7 +254,7 @@ def test_few_records_switch_the_level_to_the_burst(oracle, monkeypatch, few_div,
     disabled (0): the two accumulates follow each other within a level and the rows equal the oracle's every pass."""
     monkeypatch.setenv("ECOZ2_VQ_RECORDS_FEW_DIV", few_div)
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
-    monkeypatch.setenv("ECOZ2_VQ_SPLIT_SWEEP", "0")  # (round 4's fused kernel: the split pass of round 5 records throughout)
+    monkeypatch.setenv("ECOZ2_VQ_ACCUMULATE", "records")  # (round 4's fused kernel: the sweeps of round 5 never switch)
     M = 256
     frames = _frames(20311, 9000)
     refl = np.concatenate([_codebook(oracle, frames, M // 2, seed=11)] * 2, axis=0)
@@ -302,10 +295,7 @@ def test_seeded_first_pass_after_a_split_equals_a_full_accumulation(oracle, monk
     fused kernel with the recorded accumulate (seeded first passes whose records include the side table's bins, incremental
     ones after); 0 the same kernel with its burst of atomics."""
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", str(min_m))
-    monkeypatch.setenv("ECOZ2_VQ_FAMILY_MIN_M", str(min_m))  # (default 512: below, the plain first pass is faster)
-    monkeypatch.setenv("ECOZ2_VQ_RECORDS", "1" if split_max_m < 0 else "0")
-    monkeypatch.setenv("ECOZ2_VQ_SPLIT_SWEEP", "1" if split_max_m == -2 else "0")
-    monkeypatch.setenv("ECOZ2_VQ_FUSED_MIN_M", "64")
+    monkeypatch.setenv("ECOZ2_VQ_ACCUMULATE", {-2: "sorted", -1: "records", 0: "burst"}[split_max_m])
     monkeypatch.setenv("ECOZ2_VQ_QUIET", "1")
     if collective:
         monkeypatch.setenv("ECOZ2_VQ_FORCE_ALLREDUCE", "1")
@@ -365,11 +355,11 @@ def test_save_and_restore_state_repeat_a_level(oracle, monkeypatch):
 
 
 def test_incremental_switch_gives_the_same_ladder(oracle, monkeypatch):
-    """ECOZ2_VQ_INCREMENTAL=0 (full accumulation every pass) and the default produce identical ladders."""
+    """ECOZ2_VQ_ACCUMULATE=full (full accumulation every pass) and the default produce identical ladders."""
     frames = _frames(20262, 12000, classes=5)
     out = []
-    for inc in ("1", "0"):
-        monkeypatch.setenv("ECOZ2_VQ_INCREMENTAL", inc)
+    for acc in ("auto", "full"):
+        monkeypatch.setenv("ECOZ2_VQ_ACCUMULATE", acc)
         cbs = []
         with e.VqSession(P) as s:
             s.set_frames(frames)
@@ -410,7 +400,6 @@ def test_prefilter_for_other_prediction_orders(oracle, monkeypatch, Pn):
     adversarial frames -- all bit-identical to the oracle"""
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER", "1")
     monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
-    monkeypatch.setenv("ECOZ2_VQ_PLAIN_FIRST", "0")  # (by default the first pass of a level at M <= 384 is a plain one)
     frames = e.synth.synth_frames(20270 + Pn, 6, Pn, 0, 12000)
     rc, levels_o, cbs_o = oracle.learn(frames, 0.05, 512)
     assert rc == 0
@@ -452,11 +441,11 @@ def test_prefilter_for_other_prediction_orders(oracle, monkeypatch, Pn):
 @pytest.mark.parametrize("records", ["1", "0"])
 def test_order_40_runs_seven_waves_per_workgroup(oracle, monkeypatch, records):
     """P = 40: 21 KB of FP64 frames per wave -- seven waves per workgroup instead of eight in the LDS-staged pass and in
-    fused quantize (round 4) -- and rows of 83 elements, which the burst of atomics cannot add: with ECOZ2_VQ_RECORDS=0 the
+    fused quantize (round 4) -- and rows of 83 elements, which the burst of atomics cannot add: with ECOZ2_VQ_ACCUMULATE=burst the
     training passes run the plain FP64 sweep (round 2's accumulating kernel, which used to serve that case, left in round 5).
     Default thresholds (prefilter and seeding from M = 128, the round-5 kernels from 256), ladder to 1024 on a ragged frame
     count."""
-    monkeypatch.setenv("ECOZ2_VQ_RECORDS", records)
+    monkeypatch.setenv("ECOZ2_VQ_ACCUMULATE", "auto" if records == "1" else "burst")
     Pn = 40
     frames = e.synth.synth_frames(20340, 9, Pn, 0, 64 * 7 * 9 + 37)
     rc, levels_o, cbs_o = oracle.learn(frames, 0.05, 1024)

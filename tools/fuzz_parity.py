@@ -102,7 +102,6 @@ def main():
 def fuzz_prefilter(n, rng, oracle):
     os.environ["ECOZ2_VQ_PREFILTER"] = "1"
     os.environ["ECOZ2_VQ_PREFILTER_MIN_M"] = "64"
-    os.environ["ECOZ2_VQ_PLAIN_FIRST"] = "0"
     bad, fallback, frames_total, t0 = 0, 0, 0, time.time()
     for case in range(n):
         P = int(rng.choice([36, 36, 36, 12, 16, 20, 24, 28, 32, 40]))
@@ -135,10 +134,7 @@ def fuzz_prefilter(n, rng, oracle):
         # first pass as candidate sweep + finishing kernel + k_reduce_records, then the fused pass over grouped frames), 1 the
         # same without the fused pass, 2 round 4's fused kernel with recorded contributions, 3 the same with its burst of atomics
         acc = int(rng.integers(0, 4))
-        os.environ["ECOZ2_VQ_RECORDS"] = "0" if acc == 3 else "1"
-        os.environ["ECOZ2_VQ_SPLIT_SWEEP"] = "1" if acc <= 1 else "0"
-        os.environ["ECOZ2_VQ_FUSED_SORTED"] = "1" if acc == 0 else "0"
-        os.environ["ECOZ2_VQ_FUSED_MIN_M"] = "64"
+        os.environ["ECOZ2_VQ_ACCUMULATE"] = ("sorted", "sweep", "records", "burst")[acc]
         with e.VqSession(P) as s:
             s.set_frames(frames); s.prepare(); s.set_codebook(refl)
             for it in range(3):
