@@ -27,5 +27,5 @@ int seq_create(const char* path, const char* class_name, int M, int64_t T);
 int seq_write_range(const char* path, int64_t t0, const uint16_t* sym, int64_t n);
 // Levinson-Durbin on the host (src/lpc/lpca_r_rs.rs:8-43): status 0 / 1 (r0 == 0) / 2 (prediction error <= 0)
 int lpca_r_host(int P, const double* r, double* rc, double* a);
-int io_threads();  // ECOZ2_VQ_IO_THREADS (default 4): reader threads per rank / worker
+int io_threads();  // reader threads per rank / worker
 }  // namespace e2vq_io

@@ -147,8 +147,8 @@ struct e2vq_session {
     unsigned short* d_prev_sym = nullptr;
     // round 4: the RECORDED accumulate -- the accumulating sweep writes an 8-byte record per contribution into the region
     // of (sweeping workgroup, bin of cells), k_reduce_records folds the records into the rows through LDS tables
-    // (vq_prefilter.hip).  ECOZ2_VQ_RECORDS=0: the fused burst of atomics; ECOZ2_VQ_RECORDS_MAX_MB bounds the record buffer (default 8192: it is sized for the worst case, every
-    // frame of a workgroup in one bin, i.e. 16 bytes x frames x bins)
+    // (vq_prefilter.hip).  ECOZ2_VQ_ACCUMULATE=burst: the fused burst of atomics; rec_max_bytes bounds the record buffer (it is sized for
+    // the worst case, every frame of a workgroup in one bin, i.e. 16 bytes x frames x bins)
     bool rec_enabled = true;
     int rec_min_M = 64;
     size_t rec_max_bytes = (size_t)8192 << 20;
@@ -166,7 +166,7 @@ struct e2vq_session {
     size_t recs_cap = 0;
     int* d_rec_counts = nullptr;
     // round 5 (vq_sweep.hip): recorded passes run as sort (once per level) + candidate sweep + finishing kernel + reduce.
-    // ECOZ2_VQ_SPLIT_SWEEP=0 keeps round 4's fused kernel (A/B).  The sweep's two-stage keys need the frames grouped by cell
+    // ECOZ2_VQ_ACCUMULATE=records keeps round 4's fused kernel (A/B).  The sweep's two-stage keys need the frames grouped by cell
     // and data whose near codewords share tiles: the finishing kernel publishes the flagged fraction of every two-stage
     // sweep, and above two_stage_max_frac the rest of the level (and the next one) runs the one-stage sweep.
     bool sweep2_enabled = true;

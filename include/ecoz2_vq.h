@@ -82,33 +82,16 @@ int ecoz2_vq_classify(const char *const *cb_filenames, int num_codebooks,
  * vector (Levinson recursion of src/lpc/lpca_r_rs.rs:8-43 on its autocorrelation) instead of the r<n>. */
 int ecoz2_prd_show_file(const char *prd_filename, int show_reflections, int from, int to);
 
-/* Knobs the reference has no argument for (environment):
+/* Knobs the reference has no argument for: environment variables, none of which changes a result.  The one table of them
+ * (19) is INTEGRATION.md section 2; the ones a caller of these entry points is likely to set:
  *   ECOZ2_VQ_MAX_CODEBOOK_SIZE  last codebook size trained (default 2048, notes.md:147)
+ *   ECOZ2_VQ_OUT_ROOT           prefix for the data/... outputs (default ".")
  *   ECOZ2_VQ_DEVICE             HIP device ordinal (default 0)
  *   ECOZ2_VQ_GPUS               vq learn: shard the frames over this many in-process ranks / GPUs (default 1);
  *                               vq quantize: deal the files to this many workers (no collective; same .seq files)
- *   ECOZ2_VQ_PREFILTER          0 = every pass on the FP64 sweep (default 1: prefiltered sweep for P = 12, 16, ..., 40
- *                               and 256 <= M <= 4096, M a multiple of 32)
- *   ECOZ2_VQ_PREFILTER_MIN_M    smallest codebook the prefiltered sweep serves (default 256, at least 64)
- *   ECOZ2_VQ_INCREMENTAL        0 = accumulate in full every pass; ECOZ2_VQ_PLAIN_FIRST 0 = no plain first pass
- *   ECOZ2_VQ_QUANTIZE_UNFUSED   1 = quantize with a separate preparation pass (limb image through HBM) instead of the
- *                               fused kernel that builds the limb images of its frames itself (default for P <= 38)
- *   ECOZ2_VQ_IO_THREADS         reader threads per rank / worker for the .prd payloads (default 4)
  *   ECOZ2_VQ_COLLECTIVE         rccl | p2p: the in-process exchange of ECOZ2_VQ_GPUS > 1 (default: RCCL -- librccl.so is
  *                               loaded with dlopen -- when every rank has a device of its own, else the peer-to-peer kernel)
- *   ECOZ2_VQ_QUANTIZE_CHUNK     frames per quantize unit (default 2^17): short files are batched into one sweep, longer
- *                               files are split over the workers
- *   ECOZ2_VQ_VERIFY_PUBLISH     1 = check every published pass statistic against a host recomputation (diagnostics)
- *   ECOZ2_VQ_FAMILY             0 = the first pass of every level accumulates in full (default 1: from M = 512
- *                               -- ECOZ2_VQ_FAMILY_MIN_M -- it is seeded with the parents' sums; same rows bit for bit)
- *   ECOZ2_VQ_PRE_LDS            0 = accumulating prefiltered passes on the round-2 kernel (A/B; same results)
- *   ECOZ2_VQ_PINNED_KEEP_MB     pinned staging buffers kept for the next call of the process (default 512 MB; 0 = none:
- *                               making and releasing them costs ~50 ms of every learn / quantize call)
- *   ECOZ2_VQ_SMALL_REGS         0 = passes at M <= 16 on the LDS-table kernel instead of k_pass_small (A/B; same results)
- *   ECOZ2_VQ_SMALL_FLUSH_MASK   k_pass_small flushes its register sums every (mask + 1) blocks of a wave (default 65535;
- *                               0 in the tests: after every block)
- *   ECOZ2_VQ_TIMING             wall time of the stages of ecoz2_vq_learn on stderr (diagnostics)
- *   ECOZ2_VQ_OUT_ROOT           prefix for data/... outputs (default ".")               */
+ *   ECOZ2_VQ_QUIET              no progress lines on stderr                                   */
 
 /* ========================================================================================
  * Part 2 -- session API (resident training set, one session per GPU / per rank)

@@ -238,7 +238,7 @@ def test_incremental_rows_match_a_full_accumulation_every_pass(oracle, monkeypat
             cq = oracle.reflections_to_cq(refl)
             _sym, _dmin, rows_o = oracle.run_pass(cq, frames, sh_r, oracle.dist_exponent(cq, st.maxabs))
             s.run_pass()
-            expect_pre = prefilter and M >= 64 and not (plain_first and it == 0 and M == 256)
+            expect_pre = prefilter and M >= 64
             assert s.last_pass_info()[0] == expect_pre
             assert oracle_lib.rows_match(s.get_rows(), rows_o, P), f"pass {it}"
             refl, _failed = oracle.update(rows_o, P, sh_r, refl)

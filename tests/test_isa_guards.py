@@ -87,7 +87,7 @@ class Kernel:
 
 # (mangled-name pattern, file, VGPR budget: 512 / waves per SIMD the launch bounds assume)
 CLEAN = [
-    (r"k_pass_pre_ldsILi37ELb1ELi2E", "vq_prefilter", 256),   # round 4's fused pass (ECOZ2_VQ_SPLIT_SWEEP=0), records
+    (r"k_pass_pre_ldsILi37ELb1ELi2E", "vq_prefilter", 256),   # round 4's fused pass (M = 128; ECOZ2_VQ_ACCUMULATE=records)
     (r"k_pass_pre_ldsILi37ELb1ELi1E", "vq_prefilter", 256),   # ... with the burst of atomics
     (r"k_pass_preILi37ELi6ELi512E", "vq_prefilter", 256),     # fused quantize
     (r"k_reduce_recordsILi37E", "vq_prefilter", 85),          # three workgroups of eight waves per CU

@@ -1,6 +1,6 @@
 """Recorded accumulate vs the burst of atomics as a level converges, back to back inside the library: one level run to a small
 epsilon (many passes) through e2vq_learn, kernel ms (sweep + reduce) and wall ms per pass for
-ECOZ2_VQ_RECORDS=1 without the switch (FEW_DIV=0), with it (FEW_DIV=8 / 16 / 32), and ECOZ2_VQ_RECORDS=0."""
+ECOZ2_VQ_ACCUMULATE=records without the switch (FEW_DIV=0), with it (FEW_DIV=8 / 16 / 32), and ECOZ2_VQ_ACCUMULATE=burst."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
@@ -11,11 +11,10 @@ frames = e.synth.synth_frames(20244, 20, P, 0, S)
 EPS = float(sys.argv[1]) if len(sys.argv) > 1 else 0.002
 for M in (1024, 512, 256):
     DIVS = [int(x) for x in os.environ.get("CROSSOVER_DIVS", "0,8,16,32").split(",")]
-    modes = [(f"records, switch below 1/{d}" if d else "records, no switch", {"ECOZ2_VQ_RECORDS": "1", "ECOZ2_VQ_RECORDS_FEW_DIV": str(d)}) for d in DIVS]
-    modes.append(("burst", {"ECOZ2_VQ_RECORDS": "0", "ECOZ2_VQ_PREFILTER_MIN_M": "128", "ECOZ2_VQ_FAMILY_MIN_M": "128"}))
+    modes = [(f"records, switch below 1/{d}" if d else "records, no switch", {"ECOZ2_VQ_ACCUMULATE": "records", "ECOZ2_VQ_RECORDS_FEW_DIV": str(d)}) for d in DIVS]
+    modes.append(("burst", {"ECOZ2_VQ_ACCUMULATE": "burst", "ECOZ2_VQ_PREFILTER_MIN_M": "128"}))
     for mode, env in modes:
-        for k in ("ECOZ2_VQ_PREFILTER_MIN_M", "ECOZ2_VQ_FAMILY_MIN_M"):
-            os.environ.pop(k, None)
+        os.environ.pop("ECOZ2_VQ_PREFILTER_MIN_M", None)
         os.environ.update(env)
         with e.VqSession(P) as s:
             s.set_frames(frames); s.prepare(); s.init_codebook(); s.learn(0.05, M // 2)
