@@ -816,7 +816,8 @@ def run(args, comm):
             exec_tf = 2 * 16 * ksteps * M * frames_per_launch / (k_ms * 1e-3) / 1e12
             if sweep_kind == 3:
                 kname, kdesc = "k_sweep_cand", (
-                    "k_sweep_cand<37, two-stage, fused> over frames grouped by cell (one counting sort per level): exact f16-limb "
+                    "k_sweep_cand<37, two-stage, fused> over frames grouped by cell (one counting sort per level), two blocks of "
+                    "64 slots per turn of a wave (a loaded codeword tile serves four coarse jobs): exact f16-limb "
                     "prefilter on v_mfma_f32_32x32x16_f16 in two stages (8 coarse k-steps for every codeword tile, all 15 + top-3 "
                     "keys for the tiles a rigorous bound cannot rule out), FP64 rows gathered into LDS by LDS-DMA, the certified "
                     "top two evaluated as lane-per-frame v_fma_f64 chains, symbols / distortion sums out, the contributions to "

@@ -101,7 +101,7 @@ int launch_sweep_candidates(int NC, bool two_stage, const void* fimg, const unsi
 // the FUSED pass over grouped frames (perm != nullptr, incr 1 or 2): sweep + exact evaluation + outputs + the cell sums
 // reduced in the block, one kernel; `cells`: every frame's cell, read as the old one and written with the new one.
 // counters: sweep_counters_of(sort scratch) or nullptr (left for the host to fetch: launch_sweep_counters_out)
-int launch_pass_sorted(int NC, bool two_stage, const void* fimg, const unsigned* perm, long T, long nblocks, const void* cimg, void* ps,
+int launch_pass_sorted(int NC, bool two_stage, bool one_block, const void* fimg, const unsigned* perm, long T, long nblocks, const void* cimg, void* ps,
                        const double* cbq, int M, const double* aos, const DevScalars* sc, const unsigned long long* l1max_bits,
                        unsigned short* sym, double* dmin, long long* rows, long long* fam, int* fb_list, unsigned short* cells, int incr,
                        void* counters, hipStream_t s);

@@ -132,8 +132,9 @@ static int session_init(e2vq_session* s)
     {
         const char* am = getenv("ECOZ2_VQ_ACCUMULATE");
         const std::string acc = am ? am : "auto";
-        if (acc == "sorted") {           // the fused sorted pass wherever the prefilter runs (default: from M = 256)
-            s->sweep_min_M = 64;
+        if (acc == "sorted") {           // the fused sorted pass wherever the prefilter runs (default: from M = 256), two
+            s->sweep_min_M = 64;         // blocks per turn whatever the shard's size (default: from 4 096 blocks on)
+            s->two_blocks_always = true;
         } else if (acc == "sweep") {     // candidate sweep + finishing kernel + k_reduce_records, grouped or not
             s->fused_enabled = false;
             s->sweep_min_M = 64;

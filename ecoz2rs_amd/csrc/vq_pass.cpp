@@ -221,7 +221,10 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             s->last_two_stage = two;
             if (incr == 2) s->last_flagged_frac = -1.0;
             if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));  // (again: behind the sort)
-            if (e2vq::launch_pass_sorted(s->NC, two, s->d_fimgF, s->d_perm, s->T, s->nblocks, d_cimg, d_ps, s->d_cbq, s->M, s->d_aos,
+            // (a turn of the kernel's loop takes two blocks of 64 slots where the shard has at least two per wave of the grid --
+            // 256 workgroups of 8 waves --, one where it has not; ECOZ2_VQ_ACCUMULATE=sorted: two, whatever the size)
+            const bool one_block = !s->two_blocks_always && s->nblocks < 2 * 256 * 8;
+            if (e2vq::launch_pass_sorted(s->NC, two, one_block, s->d_fimgF, s->d_perm, s->T, s->nblocks, d_cimg, d_ps, s->d_cbq, s->M, s->d_aos,
                                          s->d_sc, s->d_l1max, (unsigned short*)device_sym, (double*)device_dmin, rows,
                                          family ? s->d_fam : nullptr, s->d_fblist, s->d_prev_sym, incr,
                                          count ? e2vq::sweep_counters_of(s->d_sort) : nullptr, s->stream))

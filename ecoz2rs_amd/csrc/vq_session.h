@@ -170,6 +170,7 @@ struct e2vq_session {
     // and data whose near codewords share tiles: the finishing kernel publishes the flagged fraction of every two-stage
     // sweep, and above two_stage_max_frac the rest of the level (and the next one) runs the one-stage sweep.
     bool sweep2_enabled = true;
+    bool two_blocks_always = false;  // ECOZ2_VQ_ACCUMULATE=sorted (the tests' small shards reach the two-block turn)
     bool fused_enabled = true;       // ECOZ2_VQ_ACCUMULATE=sweep: grouped passes as sweep + finishing kernel + reduce too (A/B)
     int sweep_min_M = 256;           // smallest codebook of the round-5 kernels (ECOZ2_VQ_ACCUMULATE=sorted / sweep: 64)
     double two_stage_max_frac = 0.45;

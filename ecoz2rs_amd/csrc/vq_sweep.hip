@@ -362,7 +362,7 @@ struct SweepLds {
     static constexpr bool FUSE_OK = WAVES_FUSE >= 6 && NC < 64;
 };
 
-template <int NC, bool TWO, bool FUSE>
+template <int NC, bool TWO, bool FUSE, bool ONE_BLOCK = false>
 __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void k_sweep_cand(
     const unsigned char* __restrict__ fimg, const unsigned* __restrict__ perm, long T, long nblocks, const h8* __restrict__ cimg,
     PreScalars* __restrict__ ps, int MT, int idxmask, const unsigned short* __restrict__ prev_sym, int home_mul,
@@ -416,7 +416,8 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
 #ifndef E2VQ_SWEEP_ONE_BLOCK  // (A/B switch of the probes: tools/probe/ab/build_variant.sh)
 #define E2VQ_SWEEP_ONE_BLOCK 0
 #endif
-    constexpr int NB = (TWO && FUSE && SweepImg<NC>::TWO_BLOCKS_FIT && !E2VQ_SWEEP_ONE_BLOCK) ? 2 : 1;
+    // (ONE_BLOCK: shards of fewer blocks than two per wave of the grid -- a turn of two would leave waves without work)
+    constexpr int NB = (TWO && FUSE && SweepImg<NC>::TWO_BLOCKS_FIT && !ONE_BLOCK && !E2VQ_SWEEP_ONE_BLOCK) ? 2 : 1;
     constexpr int NCB = 2 * NB;
     const long nturns = (nblocks + NB - 1) / NB;
 
@@ -1231,7 +1232,7 @@ int launch_sweep_candidates(int NC, bool two_stage, const void* fimg, const unsi
 // the fused pass over grouped frames (perm from launch_sort_by_cell): sweep, exact evaluation, outputs, cell sums.  `cells`
 // holds every frame's cell of the previous pass (incr 1) or of the parents (incr 2) and receives the new ones.
 template <int NC>
-static int launch_pass_sorted_t(bool two_stage, const void* fimg, const unsigned* perm, long T, long nblocks, const void* cimg, void* ps,
+static int launch_pass_sorted_t(bool two_stage, bool one_block, const void* fimg, const unsigned* perm, long T, long nblocks, const void* cimg, void* ps,
                                 int M, const SweepFuse& fz, void* counters, hipStream_t s)
 {
     if constexpr (SweepLds<NC>::FUSE_OK) {
@@ -1249,7 +1250,9 @@ static int launch_pass_sorted_t(bool two_stage, const void* fimg, const unsigned
                                (PreScalars*)ps, MT, idxmask, (const unsigned short*)fz.cells, fz.incr, (unsigned*)nullptr,
                                (SweepCounters*)counters, fz);
         };
-        if (two_stage)
+        if (two_stage && one_block && SweepImg<NC>::TWO_BLOCKS_FIT)
+            go(k_sweep_cand<NC, true, true, true>);
+        else if (two_stage)
             go(k_sweep_cand<NC, true, true>);
         else
             go(k_sweep_cand<NC, false, true>);
@@ -1258,7 +1261,7 @@ static int launch_pass_sorted_t(bool two_stage, const void* fimg, const unsigned
     return 1;
 }
 
-int launch_pass_sorted(int NC, bool two_stage, const void* fimg, const unsigned* perm, long T, long nblocks, const void* cimg, void* ps,
+int launch_pass_sorted(int NC, bool two_stage, bool one_block, const void* fimg, const unsigned* perm, long T, long nblocks, const void* cimg, void* ps,
                        const double* cbq, int M, const double* aos, const DevScalars* sc, const unsigned long long* l1max_bits,
                        unsigned short* sym, double* dmin, long long* rows, long long* fam, int* fb_list, unsigned short* cells, int incr,
                        void* counters, hipStream_t s)
@@ -1279,7 +1282,7 @@ int launch_pass_sorted(int NC, bool two_stage, const void* fimg, const unsigned*
     fz.M = M;
     switch (NC) {
 #define X(N) \
-    case N: return launch_pass_sorted_t<N>(two_stage, fimg, perm, T, nblocks, cimg, ps, M, fz, counters, s);
+    case N: return launch_pass_sorted_t<N>(two_stage, one_block, fimg, perm, T, nblocks, cimg, ps, M, fz, counters, s);
         E2VQ_PRE_NC_LIST(X)
 #undef X
         default: return 1;

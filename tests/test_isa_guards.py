@@ -93,10 +93,11 @@ CLEAN = [
     (r"k_reduce_recordsILi37E", "vq_prefilter", 85),          # three workgroups of eight waves per CU
     (r"k_pass_mfmaILi37ELi2ELi512ELi0E", "vq_device", 256),   # plain FP64 sweep
     (r"k_pass_smallILi37E", "vq_device", 256),                # M <= 16
-    (r"k_sweep_candILi37ELb1ELb1E", "vq_sweep", 256),         # round 5: the fused pass over grouped frames, two-stage sweep
-    (r"k_sweep_candILi37ELb0ELb1E", "vq_sweep", 256),         # ... one-stage sweep
-    (r"k_sweep_candILi37ELb1ELb0E", "vq_sweep", 256),         # candidate sweep alone (finishing kernel + reduce behind it)
-    (r"k_sweep_candILi37ELb0ELb0E", "vq_sweep", 256),
+    (r"k_sweep_candILi37ELb1ELb1ELb0E", "vq_sweep", 256),     # round 5: the fused pass over grouped frames, two-stage sweep, two blocks per turn
+    (r"k_sweep_candILi37ELb1ELb1ELb1E", "vq_sweep", 256),     # ... one block per turn (small shards)
+    (r"k_sweep_candILi37ELb0ELb1ELb0E", "vq_sweep", 256),     # ... one-stage sweep
+    (r"k_sweep_candILi37ELb1ELb0ELb0E", "vq_sweep", 256),     # candidate sweep alone (finishing kernel + reduce behind it)
+    (r"k_sweep_candILi37ELb0ELb0ELb0E", "vq_sweep", 256),
     (r"k_finishILi37E", "vq_sweep", 168),                     # twelve waves per workgroup: three per SIMD
 ]
 
@@ -126,13 +127,13 @@ def test_rotating_tile_loop(asm, pattern):
                    if not any(l.strip() in b for b in loads)), "a compiler-visible load inside the tile loop"
 
 
-@pytest.mark.parametrize("pattern", [r"k_sweep_candILi37ELb1ELb1E"])
-def test_two_stage_sweep_shape(asm, pattern):
+@pytest.mark.parametrize("pattern,coarse_mfmas", [(r"k_sweep_candILi37ELb1ELb1ELb0E", 64), (r"k_sweep_candILi37ELb1ELb1ELb1E", 32)])
+def test_two_stage_sweep_shape(asm, pattern, coarse_mfmas):
     k = Kernel(asm["vq_sweep"], pattern)
     # the coarse stage's loop: two register sets = two tiles of 4 column blocks (two blocks of 64 slots per turn: a loaded
     # tile serves four jobs) x 8 k-steps, no 15-step job inside it, and the MFMAs of a job interleaved with the previous
     # job's epilogue (never eight in a row)
-    coarse = [lp for lp in k.loops() if lp[2] == 64]
+    coarse = [lp for lp in k.loops() if lp[2] == coarse_mfmas]
     assert coarse, [lp for lp in k.loops() if lp[2]]
     first, last, _, _ = min(coarse, key=lambda lp: lp[1] - lp[0])
     run, longest = 0, 0
