@@ -131,7 +131,7 @@ int launch_pass_fallback(int NC, bool accumulate, const double* blk, const doubl
                          const int* fb_list, const int* fb_count, unsigned short* prev_sym, int incremental,
                          hipStream_t s, bool rowmajor = false, unsigned short* cells_out = nullptr);
 // (cells_out: where the listed frames' new cells are recorded -- default: in place, prev_sym)
-// the seeded first pass after a split (vq_device.hip: k_seed_family): rows <- parents' sums in the even children, X <- 0;
+// the seeded first pass after a split (vq_update.hip: k_seed_family): rows <- parents' sums in the even children, X <- 0;
 // after the pass (and its fallback sweep) launch_family_fixup moves the in-family arrivals X[i] from row 2 i to row 2 i + 1
 void launch_seed_family(const long long* parent, long long* rows, long long* X, int Mold, int NC, hipStream_t s,
                         const struct ZeroList* zero = nullptr);

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
 {
     constexpr bool ACCUM = ACC != 0;
     // incr: 0 = full accumulation; 1 = incremental (rows and cells of the previous pass persist: only frames that changed
-    // cell are moved); 2 = the seeded first pass of a level (vq_device.hip, k_seed_family): a frame's old cell is the even
+    // cell are moved); 2 = the seeded first pass of a level (vq_update.hip, k_seed_family): a frame's old cell is the even
     // child 2 * prev_sym of the cell it had at the previous size; one that lands in the odd child 2 * prev_sym + 1 adds its
     // limbs to row prev_sym of the side table `fam` and nothing else
     // ACC = 1: the cell sums as a burst of atomics per block.  ACC = 2: the contributions are RECORDED

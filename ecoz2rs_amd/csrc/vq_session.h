@@ -186,11 +186,10 @@ struct e2vq_session {
     bool last_two_stage = false;
     i64* d_rows_local = nullptr;  // world > 1: the un-reduced rows (d_rows holds the all-reduced copy)
     int rows_local_cap = 0;
-    // the seeded first pass of a level (vq_device.hip: k_seed_family): the rank's own rows of the last pass at the previous
+    // the seeded first pass of a level (vq_update.hip: k_seed_family): the rank's own rows of the last pass at the previous
     // size, stashed by e2vq_grow, and the side table of the in-family arrivals
     bool fam_enabled = true, fam_pending = false;
     int fam_M = 0, fam_cap = 0;
-                          // rows and the plain first pass with its workgroup LDS table is faster (0.96 vs 1.08 ms)
     int cells_M = 0;             // codebook size d_prev_sym's cells belong to (0: not valid)
     bool rows_local_is_current = false;  // d_rows_local (not d_rows) holds this rank's rows of the last pass
     bool rows_are_local = false; // the rows of the last pass are this rank's own sums (no collective, or d_rows_local)

@@ -1,16 +1,23 @@
-// vq_sweep.hip -- round 5: the accumulating prefiltered pass as a chain of kernels, each bound by one thing
+// vq_sweep.hip -- round 5: the accumulating prefiltered pass over frames grouped by cell
 //
 //   k_sort_*        once per level: the frames' numbers grouped by the cell they had when the level began (a counting sort of
 //                   2-byte keys: `perm`, 4 bytes per frame).  Nothing but this list is moved: every kernel below addresses
 //                   frames by their number.
-//   k_sweep_cand    (the matrix pipe) one wave = 64 *slots* of the sorted list; the B operands -- the f16 limb images of its
-//                   frames -- are gathered through `perm` from a frame-major image (256 bytes per frame at P = 36, two cache
-//                   lines).  Per frame it emits the two codewords that can be the nearest one, and whether that is certain:
-//                   4 bytes.  No FP64 frame, no LDS row, no output besides those 4 bytes.
-//   k_finish        (HBM) every frame once, in its natural order: the canonical FP64 chain for the one or two candidates
-//                   (lane = frame, rows staged in LDS by LDS-DMA), symbol / distortion out, distortion sums, and the frame's
-//                   contribution to the cell sums as 8-byte records -- what the tail of k_pass_pre_lds did inside the sweep.
-//   k_reduce_records (vq_prefilter.hip) folds the records into the rows, as in round 4.
+//   k_sweep_cand<NC, TWO, FUSE = true>   THE pass over grouped frames (seeded first pass, incremental passes): one kernel.
+//                   A turn of a wave = two blocks of 64 *slots* of the sorted list; the B operands -- the f16 limb images of
+//                   their frames -- are gathered through `perm` from a frame-major image (256 bytes per frame at P = 36, two
+//                   cache lines).  Two-stage sweep (below), then per block: the FP64 rows by LDS-DMA, the canonical FP64
+//                   chain for the one or two candidates (lane = slot), symbol / distortion / new cell out, and the block's
+//                   contributions to the cell sums reduced in the block (a handful of rows of atomics: the frames of a block
+//                   share their cells).  Bound by the CU's vector-memory path (profiles/r05_sweep_experiments.txt), which is
+//                   why a loaded codeword tile serves the four column blocks of a turn.
+//   k_sweep_cand<NC, TWO, FUSE = false> + k_finish + k_reduce_records   the same pass for frames that are NOT grouped (the
+//                   first pass after e2vq_set_codebook): the sweep emits per frame the two codewords that can be the nearest
+//                   one and whether that is certain (4 bytes); k_finish takes every frame once, in its natural order (the
+//                   canonical FP64 chain, lane = frame, rows staged in LDS by LDS-DMA; symbol / distortion out; the frame's
+//                   contribution to the cell sums as 8-byte records); k_reduce_records (vq_prefilter.hip) folds the records
+//                   into the rows, as in round 4.  The round's first version ran grouped frames through this chain too
+//                   (0.80 ms at M = 1024 against the fused kernel's 0.68).
 //
 // Why the sort: two-stage keys.  With the frames of a block coming from one cell, the codewords that can win for any of
 // them sit in one or two of the codebook's 32-codeword tiles (children of neighbouring cells are neighbours in the index).
@@ -29,9 +36,8 @@
 //     of the top two) -- over a subset of the codebook that provably contains the nearest codeword of every frame of the
 //     block, so the certification argument of vq_prefilter.hip holds unchanged for it.
 // On the bench data 5 % (M = 1024) to 12 % (M = 256) of the (block, tile) pairs are flagged when the frames are grouped,
-// 93-99 % when they are not (profiles/r05_skip_feasibility.txt): the sweep issues 0.58 of the limb products and -- more
-// to the point, since the key epilogue's VALU operations bound round 4's tile loop -- 1.5 instead of 6 VALU operations
-// per value in stage 1.  Nothing is decided by a key: a frame whose top two cannot be certified goes to the FP64
+// 93-99 % when they are not (profiles/r05_skip_feasibility.txt): the sweep issues 0.58 of the limb products and 1.5
+// instead of 6 VALU operations per value in stage 1 (the key epilogue's VALU operations bound round 4's tile loop).  Nothing is decided by a key: a frame whose top two cannot be certified goes to the FP64
 // fallback sweep as before; data without such structure only flags more tiles (the host watches the flagged fraction and
 // drops stage 1 when it does not pay).
 #include "vq_pre_common.h"
