@@ -247,6 +247,38 @@ def test_incremental_rows_match_a_full_accumulation_every_pass(oracle, monkeypat
     assert bool(calls) == collective
 
 
+@pytest.mark.parametrize("accumulate", ["sorted", "auto"])
+@pytest.mark.parametrize("M,T", [(2048, 9001), (8192, 12000)])
+def test_sorted_pass_big_codebooks(oracle, monkeypatch, accumulate, M, T):
+    """The fused pass over frames grouped by cell at the large end: 64 and 256 codeword tiles (the list of flagged tiles of a
+    turn holds one 16-bit entry per tile: 256 is its capacity, tile numbers take all eight bits), thousands of cells with a
+    frame or none, a ragged frame count (the last turn's second block is empty or partial).  Three passes with updates in
+    between -- a full one over ungrouped frames, then incremental ones on the sorted list ("sorted": two blocks per turn;
+    "auto": one, the shard is small) --, rows and codebooks against the oracle every time."""
+    monkeypatch.setenv("ECOZ2_VQ_ACCUMULATE", accumulate)
+    frames = _frames(20263, T, classes=11)
+    refl = _codebook(oracle, frames, M, seed=12)
+    rc, st = oracle.data_stats(frames)
+    sh_r, _ = oracle.shifts(st.maxabs)
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.set_codebook(refl)
+        for it in range(3):
+            cq = oracle.reflections_to_cq(refl)
+            sym_o, _dmin, rows_o = oracle.run_pass(cq, frames, sh_r, oracle.dist_exponent(cq, st.maxabs))
+            s.run_pass()
+            assert s.last_pass_info()[0]
+            kind, _two, _frac = s.last_pass_sweep()
+            # (the first pass -- frames not grouped -- runs the unfused chain, or round 4's kernel where the records of a full
+            # pass would not fit their bins: M = 8192; the incremental ones the fused kernel)
+            assert kind == 3 if it > 0 else kind in (1, 2), (it, kind)
+            assert oracle_lib.rows_match(s.get_rows(), rows_o, P), f"pass {it}"
+            refl, _failed = oracle.update(rows_o, P, sh_r, refl)
+            s.update()
+            assert np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64))
+
+
 @pytest.mark.parametrize("few_div,expect", [("0", [True] * 5), ("1", [True, False, False, False, False])])
 def test_few_records_switch_the_level_to_the_burst(oracle, monkeypatch, few_div, expect):
     """k_reduce_records publishes the pass's record count; below frames / ECOZ2_VQ_RECORDS_FEW_DIV the rest of the level adds
