@@ -79,6 +79,12 @@ echo "\$ python tools/fuzz_parity.py 300 9501 pre   (per case: P in 12, 16, ...,
 echo "  prefiltered passes drawn per case with ECOZ2_VQ_ACCUMULATE = sorted / sweep / records / burst; three passes with updates in between,"
 echo "  symbols, distortions, rows and codebooks against the strict oracle)"
 tail -4 gpurun_out/ri_fuzz.txt
+if [ -f gpurun_out/rq_fuzz_pre.txt ]; then
+echo; echo "== more of it, other seeds (tools/probe/r05/run_q.sh, same sources) =="
+echo "\$ python tools/fuzz_parity.py 700 77105 pre"; tail -1 gpurun_out/rq_fuzz_pre.txt
+echo "\$ python tools/fuzz_parity.py 300 77106        (general mode: random T, M, P; one pass + update + quantize each)"; tail -1 gpurun_out/rq_fuzz_gen.txt
+echo "\$ python tools/fuzz_parity.py 100 77107 hmm"; tail -1 gpurun_out/rq_fuzz_hmm.txt
+fi
 } > profiles/r05_fuzz.txt
 echo "published for sources $H"
 python - <<'EOF'
