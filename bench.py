@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- VQ-learn frames/s at M=1024, P=36 on N MI355X (BASELINE.json metric).
+"""bench.py -- VQ-learn frames/s at M=1024, P=36 on N MI355X (BASELINE.json metric, config 4).
 
 A "step" is one LBG pass of the REAL M=1024 level over the resident shard of every rank:
   sweep+accumulate kernel (K1+K2)  ->  int64 all-reduce of the cell sums (RCCL, N>1)
@@ -9,8 +9,12 @@ of the codebook, its rows and cells, and the rebuild of the codeword images: ins
 then passes until (DDprv-DD)/DD < eps ends the level (3 passes on this data: the first seeded with the parents' sums,
 two incremental ones), through the library's own e2vq_learn.  K steps = K such passes (whole
 levels; a remainder of K is run as the leading passes of one more level).
-Frames are synthetic (seeded, counter based: rank r holds frames [r*S, (r+1)*S) of one stream) and
-resident in HBM before the timed region.  Weak scaling: S = 2^21 frames per GPU (config 4's shard).
+Frames are synthetic (seeded, counter based: rank r holds frames [r*S, (r+1)*S) of one stream) and resident in HBM before
+the timed region.  The workload is BASELINE config 4: 2^24 frames sharded over the N GPUs -- S = 2^24 / N per GPU, so N = 1
+holds the whole set (18 GB resident) and N = 8 the 2^21-frame shards: "scaling": "strong".  (--frames-per-gpu S fixes the
+per-GPU shard instead: weak scaling.)  At N = 1 the line also carries `config.weak_scaling_anchor`: the same timed region on
+one 2^21-frame shard -- what each of eight GPUs does between two exchanges --, the per-level ladder table on that shard,
+`config.quantize` (config 3's kernel with its own roofline) and `config.robustness` (the level on other data shapes).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -37,7 +41,11 @@ sys.path.insert(0, ROOT)
 
 P = 36
 M = 1024
-FRAMES_PER_GPU = 1 << 21
+TOTAL_FRAMES = 1 << 24      # BASELINE.json config 4: 16 M frames, sharded over the GPUs of one node (all of them on one GPU at N = 1)
+ANCHOR_FRAMES = 1 << 21     # ... its per-GPU shard at N = 8
+FRAMES_PER_GPU = ANCHOR_FRAMES
+PROFILE_ROUND = "r06"       # profiles/<tag>_traffic*.json quoted in roofline.traffic (tools/summarize_profiles.py)
+PROFILE_TAGS = {1024: "r06", 512: "r06m512", 256: "r06m256"}
 SEED = 20244  # 20240 + config# 
 N_CLASSES = 20
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -89,7 +97,8 @@ def cpu_baseline(e, np):
         pass
     fast = oracle_lib.load(variant)
     strict = oracle_lib.load()
-    frames = e.synth.synth_frames(SEED, N_CLASSES, P, 0, 1 << 15)
+    # (2^20 frames = 310 MB: the sample streams from memory like the real pass, not from the caches)
+    frames = e.synth.synth_frames(SEED, N_CLASSES, P, 0, 1 << 20)
     # a plausible M=1024 codebook: reflections of 1024 of the frames
     refl = np.zeros((M, P + 1))
     for i in range(M):
@@ -470,7 +479,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU)
+    ap.add_argument("--frames-per-gpu", type=int, default=None,
+                    help="default: BASELINE config 4's 2^24 frames divided by --gpus (strong scaling: the whole set on one GPU "
+                         "at N = 1, 2^21 per GPU at N = 8); given explicitly, that many frames on every GPU (weak scaling)")
     ap.add_argument("--codebook-size", type=int, default=1024,
                     help="time this level of the ladder instead of M = 1024 (profiles of the M = 256 / 512 kernels; the "
                          "metric of BASELINE.json is the default)")
@@ -559,46 +570,45 @@ def parity_section(args, comm, sess, whole_level, sym, dmin, S, lo, M):
     return out
 
 
-def run(args, comm):
-    import numpy as np
-    import torch
+ROBUSTNESS_GENERATORS = [
+    # (name, kind, n_classes, noise, what)
+    ("bench_20_classes", 0, N_CLASSES, 0.05, "the bench data: 20 class prototypes, within-class noise 0.05"),
+    ("one_class", 0, 1, 0.05, "ONE prototype: no between-class structure at all"),
+    ("200_classes", 0, 200, 0.05, "200 class prototypes, within-class noise 0.05"),
+    ("20_classes_4x_noise", 0, N_CLASSES, 0.20, "20 class prototypes with four times the within-class noise"),
+    ("continuum_r0_2to3", 1, 6, 0.01,
+     "no classes: reflections on a smooth trajectory around the mean of the reference's whale-song predictor file "
+     "(notes.md:80-85: r[0] = 1/E about 2-3; built as lpc_rs.rs:116-131 builds its vectors: r / prediction error)"),
+]
+R04_KERNEL_MS_2P21 = 1.04  # round 4's kernel on 2^21 frames at M = 1024: no generator may be slower than that
 
-    import ecoz2rs_amd as e
 
-    M = args.codebook_size
-    FLOP_PER_FRAME_PASS = 2 * M * (P + 1)
-    rank, world, local = comm.rank, comm.world, comm.local
-    S = args.frames_per_gpu
-    lo = rank * S
-    frames = e.synth.synth_frames(SEED, N_CLASSES, P, lo, S)
+class LevelBench:
+    """one session on S resident frames with the ladder run up to M / 2 and that point saved: times the real level M"""
 
-    sess = e.VqSession(P, device=local)
-    comm.attach(sess)
-    sess.set_frames(frames)  # H2D + blocked re-layout; resident from here on
-    del frames
-    sess.prepare()
-    sess.init_codebook()
-    os.environ["ECOZ2_VQ_QUIET"] = "1"
-    t_ladder = time.time()
-    levels = sess.learn(0.05, M // 2)  # real LBG ladder 2..512 (untimed) -> realistic codebook state
-    sess.synchronize()
-    t_ladder = time.time() - t_ladder
-    sess.save_state()  # the converged M / 2 codebook, its DD, and the rows and cells the next level's seeded first pass starts from
-    sym = torch.empty(S, dtype=torch.int16, device=f"cuda:{local}")
-    dmin = torch.empty(S, dtype=torch.float64, device=f"cuda:{local}")
-    EPS = 0.05
+    def __init__(self, e, torch, comm, local, frames, M, eps=0.05):
+        self.e, self.torch, self.comm, self.local, self.M, self.EPS = e, torch, comm, local, M, eps
+        self.S = frames.shape[0]
+        self.sess = e.VqSession(P, device=local)
+        comm.attach(self.sess)
+        self.sess.set_frames(frames)  # H2D + re-layout; resident from here on
+        self.sess.prepare()
+        self.sess.init_codebook()
+        t0 = time.time()
+        self.levels_below = self.sess.learn(eps, M // 2)  # real LBG ladder 2..M/2 (untimed) -> realistic codebook state
+        self.sess.synchronize()
+        self.ladder_below_s = time.time() - t0
+        self.sess.save_state()  # the converged M / 2 codebook, its DD, and the rows and cells the seeded first pass starts from
 
-    def restore():
-        sess.restore_state()
+    def whole_level(self):
+        """the level through the library's LBG driver (e2vq_learn): restore, split, passes until convergence"""
+        self.sess.restore_state()
+        return self.sess.learn(self.EPS, self.M)[0]
 
-    def whole_level():
-        """the M = 1024 level through the library's LBG driver (e2vq_learn): split + passes until convergence"""
-        restore()
-        return sess.learn(EPS, M)[0]
-
-    def leading_passes(n):
+    def leading_passes(self, n):
         """the first n passes of the level, step by step (same calls, same order as e2vq_learn's loop)"""
-        restore()
+        sess = self.sess
+        sess.restore_state()
         sess.grow()
         for i in range(n):
             sess.run_pass()
@@ -607,99 +617,81 @@ def run(args, comm):
                 sess.update()
         return st_
 
-    def fence():
-        sess.synchronize()
-        torch.cuda.synchronize(local)
-        comm.barrier()
-        sess.synchronize()
+    def fence(self):
+        self.sess.synchronize()
+        self.torch.cuda.synchronize(self.local)
+        self.comm.barrier()
+        self.sess.synchronize()
 
-    # warm-up: whole levels (at least one: it also tells how many passes the level takes on this data)
-    lv = whole_level()
-    L = lv.passes
-    done = L
-    while done < args.warmup:
-        whole_level()
-        done += L
-    sess.enable_timing(True)  # HIP events around the sweep kernel of every pass, summed inside the library
-    sess.enable_collective_timing(True)  # ... and around every call of the exchange
-    fence()
-    launches_before = sess.launch_counts_by_kernel()  # (k_pass_pre_lds, k_sweep_cand, plain)
-    ar_before = comm.counters()
-    t0 = time.perf_counter()
-    steps_left = args.steps
-    while steps_left >= L:
-        st = whole_level()
-        assert st.passes == L
-        steps_left -= L
-    if steps_left:
-        st = leading_passes(steps_left)
-    fence()
-    dt = time.perf_counter() - t0
-    ar_now = comm.counters()
-    ar_timed = {k: ar_now[k] - ar_before[k] for k in ("n", "bytes")}
-    # the dominant kernel alone (the sweep), and the pass's kernels together (sweep + k_reduce_records where the accumulate
-    # is a kernel of its own)
-    kernel_ms_total, kernel_passes = sess.timing_sweep_total()
-    pass_kernels_ms_total = sess.timing_total()[0]
-    assert kernel_passes == args.steps, (kernel_passes, args.steps)
-    ar_ms, ar_n, ar_b = sess.collective_timing()
-    sess.enable_collective_timing(False)
-    prefiltered, fallback_frames = sess.last_pass_info()
-    launches_after = sess.launch_counts_by_kernel()
-    timed_lds, timed_sweep, timed_plain = (launches_after[k] - launches_before[k] for k in range(3))
-    timed_pre = timed_lds + timed_sweep
-    sweep_kind, two_stage, flagged_frac = sess.last_pass_sweep()
-    dt = comm.max_over_ranks(dt)
-    collective = comm.describe(ar_timed)
-    if collective is not None:
-        # device time between the events the library records around its calls of the exchange (the collective's kernels and
-        # their wait for the other ranks), this rank, timed region
-        collective["allreduce_calls_timed"] = ar_n
-        collective["allreduce_bytes_per_call"] = ar_b // max(1, ar_n)
-        collective["allreduce_us_per_call"] = 1e3 * ar_ms / max(1, ar_n)
-        collective["allreduce_ms_per_step"] = ar_ms / max(1, args.steps)
-
-    parity = None
-    if not args.no_parity:
-        parity = parity_section(args, comm, sess, whole_level, sym, dmin, S, lo, M)
-
-    extras = not args.no_extras
-    steady_ms = steady_kernel_ms = e2e_s = q_rate = None
-    e2e_levels, level_detail, big = [], [], None
-    if extras:
-        # ---- steady state (informational): back-to-back iterations on the converged codebook, where the
-        # incremental accumulate has almost nothing left to move -- round 1's headline regime, kept as an extra key
-        whole_level()
-        for _ in range(3):
-            sess.iterate(sym, dmin)
-        sess.enable_timing(True)
-        fence()
+    def timed(self, steps, warmup):
+        """W warm-up passes (whole levels), then EXACTLY `steps` passes between two fences; the wall time is this rank's"""
+        sess = self.sess
+        lv = self.whole_level()
+        L = lv.passes
+        done = L
+        while done < warmup:
+            self.whole_level()
+            done += L
+        sess.enable_timing(True)  # HIP events around the sweep kernel of every pass, summed inside the library
+        sess.enable_collective_timing(True)  # ... and around every call of the exchange
+        sess.sweep_executed(reset=True)
+        self.fence()
+        launches_before = sess.launch_counts_by_kernel()  # (k_pass_pre_lds, k_sweep_cand, plain)
+        ar_before = self.comm.counters()
         t0 = time.perf_counter()
-        for _ in range(10):
-            sess.iterate(sym, dmin)
-        fence()
-        steady_ms = (time.perf_counter() - t0) / 10 * 1e3
-        steady_kernel_ms = sess.timing_total()[0] / 10
+        left = steps
+        while left >= L:
+            st = self.whole_level()
+            assert st.passes == L
+            left -= L
+        if left:
+            st = self.leading_passes(left)
+        self.fence()
+        dt = time.perf_counter() - t0
+        ar_now = self.comm.counters()
+        r = {"dt": dt, "L": L, "st": st, "steps": steps,
+             "ar_timed": {k: ar_now[k] - ar_before[k] for k in ("n", "bytes")}}
+        # the dominant kernel alone (the sweep), and the pass's kernels together (sweep + k_reduce_records where the accumulate
+        # is a kernel of its own)
+        r["kernel_ms_total"], r["kernel_passes"] = sess.timing_sweep_total()
+        r["pass_kernels_ms_total"] = sess.timing_total()[0]
+        assert r["kernel_passes"] == steps, (r["kernel_passes"], steps)
+        r["ar_ms"], r["ar_n"], r["ar_b"] = sess.collective_timing()
+        sess.enable_collective_timing(False)
+        r["prefiltered"], r["fallback_frames"] = sess.last_pass_info()
+        la = sess.launch_counts_by_kernel()
+        r["launches_before"] = launches_before
+        r["timed_lds"], r["timed_sweep"], r["timed_plain"] = (la[k] - launches_before[k] for k in range(3))
+        r["sweep_kind"], r["two_stage"], r["flagged_frac_first_pass"] = sess.last_pass_sweep()
+        # what the fused sorted passes of the timed region executed, counted by the kernels: (tile, column block) jobs
+        fl, jobs, one = sess.sweep_executed(reset=True)
+        r["executed"] = {"flagged_jobs": fl, "two_stage_jobs": jobs, "one_stage_jobs": one}
+        r["ksteps"] = (8.0 * jobs + 15.0 * fl + 15.0 * one) / (jobs + one) if (jobs + one) > 0 else 15.0
+        r["flagged_frac"] = fl / jobs if jobs > 0 else -1.0
+        return r
 
-        # ---- secondary figures (SURVEY 8d ii / iii), outside the timed region, informational --------------------
+    def ladder_report(self, prefiltered, collective):
+        """the whole ladder 2 .. M in one library call, then level by level (a synchronisation per level: ~30 us each) with the
+        sweep kernel's event time: per level {passes, kernel ms per pass, step ms per pass, what bounds the level's sweep,
+        fraction of that bound}"""
+        sess, S, M = self.sess, self.S, self.M
         sess.enable_timing(False)
         sess.init_codebook()
-        fence()
+        self.fence()
         t0 = time.perf_counter()
-        e2e_levels = sess.learn(0.05, M)  # the whole ladder 2..M with the real convergence rule, one library call
-        fence()
+        e2e_levels = sess.learn(self.EPS, M)
+        self.fence()
         e2e_s = time.perf_counter() - t0
-        # the same ladder level by level (a synchronisation per level: ~30 us each), with the sweep kernel's event time:
-        # per level {passes, kernel ms per pass, step ms per pass, what bounds the level's sweep, fraction of that bound}
+        detail = []
         sess.init_codebook()
         m = 2
         while m <= M:
             sess.enable_timing(True)
-            sess.enable_collective_timing(collective is not None)
-            fence()
+            sess.enable_collective_timing(collective)
+            self.fence()
             t0 = time.perf_counter()
-            lvm = sess.learn(0.05, m)[0]
-            fence()
+            lvm = sess.learn(self.EPS, m)[0]
+            self.fence()
             wall = time.perf_counter() - t0
             kms, kn = sess.timing_total()
             lar_ms, lar_n, _ = sess.collective_timing()
@@ -716,69 +708,227 @@ def run(args, comm):
                 bound, bound_ms = "hbm (306 B per frame-pass)", hbm_ms
             else:
                 bound, bound_ms = "fp64 mfma (2 M (P+1) flop per frame-pass)", fp64_ms
-            level_detail.append({"M": m, "passes": lvm.passes, "kernel_ms": kms / max(1, kn), "step_ms": wall / lvm.passes * 1e3,
-                                 "bound": bound, "bound_ms": bound_ms, "frac_of_bound": bound_ms / (kms / max(1, kn)),
-                                 "sweep_kind": lkind, "flagged_fraction": lfrac if ltwo else None})
-            if collective is not None:
-                level_detail[-1]["allreduce_us_per_call"] = 1e3 * lar_ms / max(1, lar_n)
-                level_detail[-1]["allreduce_bytes"] = m * e.lib.e2vq_row_stride(P) * 8
+            detail.append({"M": m, "passes": lvm.passes, "kernel_ms": kms / max(1, kn), "step_ms": wall / lvm.passes * 1e3,
+                           "bound": bound, "bound_ms": bound_ms, "frac_of_bound": bound_ms / (kms / max(1, kn)),
+                           "sweep_kind": lkind, "flagged_fraction": lfrac if ltwo else None})
+            if collective:
+                detail[-1]["allreduce_us_per_call"] = 1e3 * lar_ms / max(1, lar_n)
+                detail[-1]["allreduce_ms_per_step"] = lar_ms / max(1, lvm.passes)
+                detail[-1]["allreduce_bytes"] = m * self.e.lib.e2vq_row_stride(P) * 8
             m *= 2
         sess.enable_timing(False)
         sess.enable_collective_timing(False)
+        return {
+            "what": f"whole LBG ladder M=2..{M}, eps={self.EPS}, {S} resident frames per rank, all ranks, one library call",
+            "seconds": round(e2e_s, 5),
+            "frames_per_sec": self.comm.world * S / e2e_s,
+            "passes_per_level": [lv.passes for lv in e2e_levels],
+            "levels": detail,
+            "levels_note": "the same ladder run level by level (one synchronisation per level): sweep-kernel time per pass "
+                           "from HIP events, step = wall time of the level / its passes (with N > 1: allreduce_ms_per_step = "
+                           "device time of the exchange per pass, inside step_ms); bound = what the level's sweep is priced "
+                           "against (HBM for M <= 32, the FP64 matrix pipe for the plain sweep of M = 64, the f16 limb "
+                           "products actually issued for the prefiltered levels)",
+        }
+
+    def close(self):
+        self.sess.close()
+
+
+def robustness_section(e, torch, comm, local, M, S):
+    """Untimed extra (VERDICT r05 task 2): the headline level on data of other shapes.  Per generator: the ladder 2 .. M/2, then
+    the level M as the ladder runs it -- flagged share of the two-stage sweep's jobs (first pass), whether the host kept two
+    stages for the rest of the level, sweep-kernel ms per pass by pass, and the same level on the plain FP64 sweep: codebook
+    bytes, pass count and DD must be identical."""
+    import hashlib
+
+    out = {"what": f"the M={M} level on {S} frames of other generators (one GPU, untimed extras): does the two-stage sweep's gain "
+                   "survive data without the bench data's cluster structure, and does the host's switch to one stage (flagged "
+                   "share above 0.45 on the level's first pass) pick the faster kernel?",
+           "round4_kernel_ms_on_2p21_frames": R04_KERNEL_MS_2P21, "frames": S, "generators": []}
+    for name, kind, ncls, noise, what in ROBUSTNESS_GENERATORS:
+        row = {"generator": name, "what": what, "synth": {"kind": kind, "n_classes": ncls, "noise": noise, "seed": SEED}}
+        try:
+            frames = e.synth.synth_frames_kind(SEED, kind, ncls, noise, P, 0, S)
+            row["mean_r0"] = float(frames[:4096, 0].mean())
+            lb = LevelBench(e, torch, comm, local, frames, M)
+            del frames
+            sess = lb.sess
+            lb.whole_level()  # (warm)
+            # pass by pass: kernel time of each, the sweep that served it
+            sess.restore_state()
+            sess.grow()
+            passes = []
+            for i in range(64):
+                sess.enable_timing(True)
+                sess.run_pass()
+                st = sess.pass_stats()
+                ms = sess.timing_sweep_total()[0]
+                kd, two, ff = sess.last_pass_sweep()
+                passes.append({"kernel_ms": ms, "sweep_kind": kd, "two_stage": two})
+                if i == 0:
+                    row["flagged_fraction_first_pass"] = ff
+                    dd_prev = sess.prev_distortion()
+                ratio = (dd_prev - st.DD) / st.DD
+                dd_prev = st.DD
+                if i > 0 and not ratio >= lb.EPS:
+                    break
+                sess.update()
+            sess.enable_timing(False)
+            row["passes"] = len(passes)
+            row["per_pass"] = passes
+            row["kernel_ms_per_pass"] = sum(p["kernel_ms"] for p in passes) / len(passes)
+            row["two_stage_kept"] = bool(passes[-1]["two_stage"])
+            row["slower_than_round4"] = bool(max(p["kernel_ms"] for p in passes) * ((1 << 21) / S) > R04_KERNEL_MS_2P21)
+            # the level through e2vq_learn, prefiltered and plain: identical bytes?
+            lv_pre = lb.whole_level()
+            cb_pre = sess.get_codebook()
+            sess.set_prefilter(False)
+            lv_plain = lb.whole_level()
+            cb_plain = sess.get_codebook()
+            sess.set_prefilter(True)
+            row["level_passes_learn"] = lv_pre.passes
+            row["codebook_sha16"] = hashlib.sha256(cb_pre.tobytes()).hexdigest()[:16]
+            row["equals_plain_sweep"] = bool(cb_plain.tobytes() == cb_pre.tobytes() and lv_plain.passes == lv_pre.passes and
+                                             lv_plain.DD.hex() == lv_pre.DD.hex())
+            lb.close()
+        except Exception as ex:  # informational: never fails the bench line by itself
+            row["error"] = repr(ex)
+        out["generators"].append(row)
+    out["all_equal_plain_sweep"] = all(g.get("equals_plain_sweep") for g in out["generators"])
+    out["any_slower_than_round4"] = any(g.get("slower_than_round4") for g in out["generators"])
+    return out
+
+
+def quantize_section(e, torch, local, sess, S, M, sym, dmin):
+    """config 3's kernel on S device-resident frames against the session's M-codeword codebook: frames/s, and the roofline of
+    its sweep kernel (HIP events on the session's stream around e2vq_quantize_device: codebook image ready, so the events
+    bracket the sweep + the FP64 fallback sweep)"""
+    fr = torch.from_numpy(e.synth.synth_frames(SEED, N_CLASSES, P, 0, S)).cuda(local)
+    st = torch.cuda.current_stream(local)
+    best = None
+    for _ in range(4):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(local)
+        t0 = time.perf_counter()
+        ev0.record(st)
+        sess.quantize_device(fr, S, sym, dmin)
+        ev1.record(st)
+        sess.synchronize()
+        wall = time.perf_counter() - t0
+        ms = ev0.elapsed_time(ev1)
+        if best is None or ms < best[0]:
+            best = (ms, wall)
+    del fr
+    ms, wall = best
+    exec_tf = 2 * 16 * 15.0 * M * S / (ms * 1e-3) / 1e12
+    return {
+        "frames": S, "codebook_size": M,
+        "frames_per_sec_device_resident": S / wall,
+        "kernel_ms": ms,
+        "roofline_quantize": {
+            "bound": "mfma", "kernel": "k_pass_pre<37,6,512> (fused quantize: limb images built from the row-major payload in the "
+                                       "kernel, one-stage f16-limb sweep with all 15 k-steps, FP64 evaluation of the certified top "
+                                       "two from the frames staged in LDS) + the FP64 fallback sweep of uncertified frames",
+            "achieved": exec_tf, "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": exec_tf / F16_PEAK_TFLOPS,
+            "work_per_launch": f"480 f16 MFMA flop x {M} codewords x {S} frames (15 k-steps per pair: frames in their natural "
+                               "order flag 93-99 % of the tiles, nothing to skip)",
+            "hbm_algorithmic_GBs": 298 * S / (ms * 1e-3) / 1e9, "hbm_frac": 298 * S / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "timing": "HIP events on the stream the kernels run on (the session is bound to torch's current stream)",
+        },
+    }
+
+
+def run(args, comm):
+    import numpy as np
+    import torch
+
+    import ecoz2rs_amd as e
+
+    M = args.codebook_size
+    FLOP_PER_FRAME_PASS = 2 * M * (P + 1)
+    rank, world, local = comm.rank, comm.world, comm.local
+    # config 4 (BASELINE.json): 2^24 frames sharded over the ranks -- one GPU holds them all (18 GB resident)
+    strong = args.frames_per_gpu is None
+    S = TOTAL_FRAMES // world if strong else args.frames_per_gpu
+    lo = rank * S
+    os.environ["ECOZ2_VQ_QUIET"] = "1"
+    frames = e.synth.synth_frames(SEED, N_CLASSES, P, lo, S)
+    lb = LevelBench(e, torch, comm, local, frames, M)
+    del frames
+    sess, EPS = lb.sess, lb.EPS
+    t_ladder = lb.ladder_below_s
+    sym = torch.empty(S, dtype=torch.int16, device=f"cuda:{local}")
+    dmin = torch.empty(S, dtype=torch.float64, device=f"cuda:{local}")
+
+    tm = lb.timed(args.steps, args.warmup)
+    L, st = tm["L"], tm["st"]
+    kernel_ms_total, kernel_passes, pass_kernels_ms_total = tm["kernel_ms_total"], tm["kernel_passes"], tm["pass_kernels_ms_total"]
+    prefiltered, fallback_frames = tm["prefiltered"], tm["fallback_frames"]
+    launches_before, timed_lds, timed_sweep, timed_plain = tm["launches_before"], tm["timed_lds"], tm["timed_sweep"], tm["timed_plain"]
+    sweep_kind, two_stage, flagged_frac, ksteps = tm["sweep_kind"], tm["two_stage"], tm["flagged_frac"], tm["ksteps"]
+    dt = comm.max_over_ranks(tm["dt"])
+    collective = comm.describe(tm["ar_timed"])
+    if collective is not None:
+        # device time between the events the library records around its calls of the exchange (the collective's kernels and
+        # their wait for the other ranks), this rank, timed region
+        collective["allreduce_calls_timed"] = tm["ar_n"]
+        collective["allreduce_bytes_per_call"] = tm["ar_b"] // max(1, tm["ar_n"])
+        collective["allreduce_us_per_call"] = 1e3 * tm["ar_ms"] / max(1, tm["ar_n"])
+        collective["allreduce_ms_per_step"] = tm["ar_ms"] / max(1, args.steps)
+
+    parity = None
+    if not args.no_parity:
+        parity = parity_section(args, comm, sess, lb.whole_level, sym, dmin, S, lo, M)
+
+    extras = not args.no_extras
+    steady_ms = steady_kernel_ms = None
+    ladder = quant = anchor = robust = None
+    if extras:
+        # ---- steady state (informational): back-to-back iterations on the converged codebook, where the
+        # incremental accumulate has almost nothing left to move -- round 1's headline regime, kept as an extra key
+        lb.whole_level()
+        for _ in range(3):
+            sess.iterate(sym, dmin)
+        sess.enable_timing(True)
+        lb.fence()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            sess.iterate(sym, dmin)
+        lb.fence()
+        steady_ms = (time.perf_counter() - t0) / 10 * 1e3
+        steady_kernel_ms = sess.timing_total()[0] / 10
+        # ---- secondary figures (SURVEY 8d ii / iii), outside the timed region, informational --------------------
+        ladder = lb.ladder_report(prefiltered, collective is not None)
         if world == 1:
-            fr = torch.from_numpy(e.synth.synth_frames(SEED, N_CLASSES, P, lo, S)).cuda(local)
-            for _ in range(3):
-                torch.cuda.synchronize(local)
-                t0 = time.perf_counter()
-                sess.quantize_device(fr, S, sym, dmin)
-                sess.synchronize()
-                q_rate = max(q_rate or 0.0, S / (time.perf_counter() - t0))
-            del fr
-        # ---- config 4's whole set (2^24 frames) on ONE GPU: strong-scaling reference point, informational ----------------
-        if world == 1 and M == 1024 and S == FRAMES_PER_GPU and not os.environ.get("ECOZ2_BENCH_SKIP_16M"):
-            try:
-                T16 = 1 << 24
-                t0 = time.perf_counter()
-                fr16 = e.synth.synth_frames(SEED, N_CLASSES, P, 0, T16)
-                synth_s = time.perf_counter() - t0
-                with e.VqSession(P, device=local) as s16:
-                    t0 = time.perf_counter()
-                    s16.set_frames(fr16)
-                    s16.prepare()
-                    s16.synchronize()
-                    upload_s = time.perf_counter() - t0
-                    del fr16
-                    s16.init_codebook()
-                    s16.learn(0.05, M // 2)
-                    s16.enable_timing(True)
-                    s16.synchronize()
-                    t0 = time.perf_counter()
-                    lv16 = s16.learn(0.05, M)[0]
-                    s16.synchronize()
-                    level_s = time.perf_counter() - t0
-                    kms16, kn16 = s16.timing_total()
-                    s16.enable_timing(False)
-                    s16.init_codebook()
-                    s16.synchronize()
-                    t0 = time.perf_counter()
-                    lad16 = s16.learn(0.05, M)
-                    s16.synchronize()
-                    ladder_s = time.perf_counter() - t0
-                big = {
-                    "what": f"config 4's whole training set ({T16} frames) resident on ONE GPU: the M={M} level and the whole ladder",
-                    "frames": T16,
-                    "host_synth_seconds": round(synth_s, 2),
-                    "upload_relayout_statistics_seconds": round(upload_s, 3),
-                    "level_passes": lv16.passes,
-                    "level_kernel_ms_per_pass": kms16 / max(1, kn16),
-                    "level_ms_per_pass": level_s / lv16.passes * 1e3,
-                    "level_frames_per_sec": T16 * lv16.passes / level_s,
-                    "ladder_seconds": round(ladder_s, 4),
-                    "ladder_frames_per_sec": T16 / ladder_s,
-                    "ladder_passes_per_level": [x.passes for x in lad16],
-                }
-            except Exception as ex:  # (a box short of host memory: the figure is informational)
-                big = {"error": repr(ex)}
+            lb.whole_level()  # (the level's final codebook)
+            quant = quantize_section(e, torch, local, sess, min(S, 10_000_000), M, sym, dmin)
+    lb_S = S
+    if extras and world == 1 and M == 1024 and strong and not os.environ.get("ECOZ2_BENCH_SKIP_ANCHOR"):
+        # ---- config 4's per-GPU shard (2^21 frames) on this one GPU: what each of the 8 ranks does between two exchanges --
+        # the anchor a SCALE run at N = 8 compares with (shard-size effect apart from the collective's cost)
+        try:
+            lb.close()
+            lb = None
+            del sym, dmin
+            torch.cuda.empty_cache()
+            fa = e.synth.synth_frames(SEED, N_CLASSES, P, 0, ANCHOR_FRAMES)
+            la = LevelBench(e, torch, comm, local, fa, M)
+            del fa
+            ta = la.timed(args.steps, args.warmup)
+            anchor = {
+                "what": f"the same timed region on config 4's per-GPU shard ({ANCHOR_FRAMES} frames = 2^24 / 8) resident on this one "
+                        "GPU: the N = 8 point of the strong-scaling curve without its exchange",
+                "frames": ANCHOR_FRAMES, "value": ANCHOR_FRAMES * args.steps / ta["dt"], "ms_per_step": ta["dt"] / args.steps * 1e3,
+                "kernel_ms": ta["kernel_ms_total"] / ta["kernel_passes"], "passes_per_level": ta["L"],
+                "ksteps_per_pair": ta["ksteps"], "flagged_fraction": ta["flagged_frac"],
+                "learn_end_to_end": la.ladder_report(ta["prefiltered"], False),
+            }
+            la.close()
+            if not os.environ.get("ECOZ2_BENCH_SKIP_ROBUSTNESS"):
+                robust = robustness_section(e, torch, comm, local, M, ANCHOR_FRAMES)
+        except Exception as ex:  # (informational)
+            anchor = {"error": repr(ex)}
 
     small = None
     if extras and rank == 0 and world == 1 and M == 1024 and not os.environ.get("ECOZ2_BENCH_SKIP_SMALL"):
@@ -787,19 +937,21 @@ def run(args, comm):
         k_ms = kernel_ms_total / kernel_passes
         frames_per_launch = S
         # PMC traffic cannot be collected inside this process: it comes from separate rocprofv3 --pmc passes over this
-        # same command (tools/summarize_profiles.py -> profiles/r05_traffic*.json).  The file records the hash of the
-        # kernel sources it was measured on; a figure measured on other sources is reported as stale (null).
+        # same command (tools/profile_bench.sh + tools/summarize_profiles.py -> profiles/<tag>_traffic*.json).  The file records
+        # the hash of the kernel sources and the frames per launch it was measured on; a figure measured on other sources or
+        # another shard size is reported as stale (null).
         traffic, traffic_detail = None, None
-        tname = ("r05_traffic" if prefiltered else "r05np_traffic") + ("" if M == 1024 else f"_M{M}") + ("" if prefiltered else "_noprefilter") + ".json"
+        tag = PROFILE_TAGS.get(M, f"{PROFILE_ROUND}m{M}") if prefiltered else f"{PROFILE_ROUND}np"
+        tname = f"{tag}_traffic" + ("" if M == 1024 else f"_M{M}") + ("" if prefiltered else "_noprefilter") + ".json"
         tpath = os.path.join(ROOT, "profiles", tname)
-        if os.path.exists(tpath) and S == FRAMES_PER_GPU:
+        if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                fresh = tj.get("kernel_sources_sha16") == kernel_sources_sha16()
+                fresh = tj.get("kernel_sources_sha16") == kernel_sources_sha16() and tj.get("frames_per_launch") == S
                 traffic = tj.get("hbm_bytes_per_launch") if fresh else None
-                traffic_detail = {"fetch_bytes": tj.get("fetch_bytes"), "write_bytes": tj.get("write_bytes"),
+                traffic_detail = {"file": "profiles/" + tname, "fetch_bytes": tj.get("fetch_bytes"), "write_bytes": tj.get("write_bytes"),
                                   "algorithmic_bytes": tj.get("algorithmic_bytes_per_launch"),
-                                  "measured_on_sources": tj.get("kernel_sources_sha16"),
+                                  "measured_on_sources": tj.get("kernel_sources_sha16"), "measured_on_frames": tj.get("frames_per_launch"),
                                   "stale": not fresh, "note": tj.get("note")}
             except Exception:
                 traffic = None
@@ -807,12 +959,11 @@ def run(args, comm):
         achieved_gbs = BYTES_PER_FRAME_PASS * frames_per_launch / (k_ms * 1e-3) / 1e9
         roofline_algorithmic = None
         if prefiltered:
-            # dominant kernel: the prefiltered sweep.  The work it EXECUTES is 15 f16 MFMA k-steps per (frame, codeword)
-            # pair (exact integer limb products) -- priced against the dense f16 MFMA peak of the guide; the FP64 chain
-            # runs only for the two certified candidates of a frame.
-            # k-steps of v_mfma_f32_32x32x16_f16 executed per (frame, codeword) pair: 15 for a one-stage sweep; two stages: 8 for
-            # every pair + all 15 again for the flagged (tile, column block) jobs (their share is measured by the kernel)
-            ksteps = (8 + 15 * flagged_frac) if (two_stage and flagged_frac >= 0) else 15.0
+            # dominant kernel: the prefiltered sweep.  The work it EXECUTES is f16 MFMA k-steps (exact integer limb products)
+            # -- priced against the dense f16 MFMA peak of the guide; the FP64 chain runs only for the two certified
+            # candidates of a frame.  k-steps of v_mfma_f32_32x32x16_f16 per (frame, codeword) pair: 15 for a one-stage sweep;
+            # two stages: 8 for every pair + all 15 again for the flagged (tile, column block) jobs -- counted by the kernels of
+            # EVERY timed pass (e2vq_sweep_executed), jobs-weighted
             exec_tf = 2 * 16 * ksteps * M * frames_per_launch / (k_ms * 1e-3) / 1e12
             if sweep_kind == 3:
                 kname, kdesc = "k_sweep_cand", (
@@ -847,10 +998,13 @@ def run(args, comm):
                                      "count": timed_sweep if kname == "k_sweep_cand" else timed_lds,
                                      "plain_first": launches_before[2], "plain_count": timed_plain},
                 "work_per_launch": f"{2 * 16 * ksteps:.1f} f16 MFMA flop x {M} codewords x {S} frames "
-                                   f"(limb products actually issued: {ksteps:.2f} k-steps per pair"
-                                   + (f", flagged fraction {flagged_frac:.3f}" if two_stage and flagged_frac >= 0 else "") + ")",
+                                   f"(limb products actually issued: {ksteps:.3f} k-steps per pair, counted by the kernels over "
+                                   f"all {kernel_passes} timed passes"
+                                   + (f"; flagged share of the jobs {flagged_frac:.4f}" if flagged_frac >= 0 else "") + ")",
                 "ksteps_per_pair": ksteps,
-                "two_stage": bool(two_stage), "flagged_fraction": flagged_frac if two_stage else None,
+                "executed_jobs": tm["executed"],
+                "two_stage": bool(two_stage), "flagged_fraction": flagged_frac if flagged_frac >= 0 else None,
+                "flagged_fraction_first_pass_of_level": tm["flagged_frac_first_pass"] if two_stage else None,
                 "one_stage_equivalent": {
                     "what": "the limb products a one-stage sweep issues (15 k-steps per pair: round 4's count) / this kernel's "
                             "time: what the same pass would need on round 4's kernel to be as fast -- a speed-up figure",
@@ -893,17 +1047,19 @@ def run(args, comm):
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"vq learn, the real M={M} level at P={P}: {S} frames per GPU (config 4 shard: 16M frames "
-                            f"over 8 GPUs); per repetition the point where the M={M // 2} level ended is restored (device copies "
+                "workload": (f"vq learn, BASELINE config 4: {TOTAL_FRAMES} frames at P={P} sharded over {world} GPU(s) "
+                             f"({S} per GPU, all resident)" if strong else f"vq learn, {S} frames per GPU at P={P}") +
+                            f", the real M={M} level; per repetition the point where the M={M // 2} level ended is restored (device copies "
                             f"and the rebuild of the codeword images: inside the timed region), split, and passes run until "
                             f"(DDprv-DD)/DD < {EPS} ({L} passes: the first seeded with the parents' sums -- in-family frames "
                             f"add once or not at all --, {L - 1} incremental ones); a step = one such pass; eps={EPS} ladder 2..{M // 2} run untimed first",
                 "frames_per_gpu": S,
+                "frames_total": world * S,
                 "codebook_size": M,
                 "prediction_order": P,
                 "passes_per_level": L,
@@ -915,27 +1071,18 @@ def run(args, comm):
                 "final_avg_distortion": st.avg_distortion,
                 "parity": parity,
                 "timed_sweep_launches": {"k_sweep_cand": timed_sweep, "k_pass_pre_lds": timed_lds, "plain": timed_plain},
-                "steady_state": None if not extras else {
+                "steady_state": None if steady_ms is None else {
                     "what": "back-to-back iterations on the converged codebook (incremental accumulate nearly idle): "
                             "round 1's headline regime, informational",
                     "ms_per_step": steady_ms,
                     "kernel_ms": steady_kernel_ms,
                     "frames_per_sec": world * S / (steady_ms * 1e-3),
                 },
-                "learn_end_to_end": None if not extras else {
-                    "what": f"whole LBG ladder M=2..{M}, eps=0.05, resident frames, all ranks, one library call",
-                    "seconds": round(e2e_s, 4),
-                    "frames_per_sec": world * S / e2e_s,
-                    "passes_per_level": [lv.passes for lv in e2e_levels],
-                    "levels": level_detail,
-                    "levels_note": "the same ladder run level by level (one synchronisation per level): sweep-kernel time "
-                                   "per pass from HIP events, step = wall time of the level / its passes; bound = what the "
-                                   "level's sweep is priced against (HBM for M <= 32, the FP64 matrix pipe for the plain "
-                                   "sweep of 64 <= M <= 128, the f16 limb products actually issued for the prefiltered "
-                                   "levels; the first, full pass of M = 256 runs the plain sweep)",
-                },
-                "quantize_frames_per_sec_device_resident": q_rate,
-                "strong_scaling_16M": big,
+                "learn_end_to_end": ladder,
+                "quantize": quant,
+                "quantize_frames_per_sec_device_resident": None if quant is None else quant["frames_per_sec_device_resident"],
+                "weak_scaling_anchor": anchor,
+                "robustness": robust,
                 "small_corpus": small,
             },
             "roofline": roofline,
@@ -953,7 +1100,8 @@ def run(args, comm):
             out["cpu_baseline"] = cpu_baseline(e, np)
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    sess.close()
+    if lb is not None:
+        lb.close()
     if parity is not None and not parity["ok"]:
         raise SystemExit(f"bench.py: PARITY FAILED on rank {rank}: {parity}")
 

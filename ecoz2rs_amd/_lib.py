@@ -92,6 +92,7 @@ _sig("e2vq_iterate", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Leve
 _sig("e2vq_last_pass_info", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64))
 _sig("e2vq_last_pass_records", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64))
 _sig("e2vq_last_pass_sweep", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double))
+_sig("e2vq_sweep_executed", C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int)
 _sig("e2vq_set_prev_distortion", C.c_int, C.c_void_p, C.c_double)
 _sig("e2vq_get_prev_distortion", C.c_int, C.c_void_p, C.POINTER(C.c_double))
 _sig("e2vq_sweep_launch_counts", C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
@@ -112,6 +113,7 @@ _sig("e2vq_cbook_read", C.c_int, C.c_char_p, C.c_void_p, C.c_int)
 _sig("e2vq_cbook_write", C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p)
 _sig("e2vq_seq_write", C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64)
 _sig("e2vq_synth_frames", C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p)
+_sig("e2vq_synth_frames_kind", C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int64, C.c_int64, C.c_void_p)
 
 
 def check(rc):

@@ -86,11 +86,13 @@ int launch_reduce_records(int NC, const double* aos, const PassRecords& plan, bo
 // round 5 (vq_sweep.hip): the accumulating prefiltered pass as sort (once per level) + candidate sweep + finishing kernel +
 // launch_reduce_records.  sweep_supported: the order has a prefiltered sweep and its rows fit the finishing kernel's LDS.
 bool sweep_supported(int NC, int M);
+bool sweep_fused_supported(int NC, int M);   // ... and the fused sorted pass (launch_pass_sorted) as well
 size_t sweep_frame_image_bytes(int NC, long nblocks64);
 // frame-major limb image (same limbs as launch_prefilter_frames, whose scales `ea` it uses) from the row-major resident copy
 void launch_sweep_frames(const double* aos, long T, long nblocks64, int NC, const int* ea, void* img, hipStream_t s);
 size_t sort_scratch_bytes();                 // zero it once; holds the sort's histogram / cursor and the sweep's counters
-void* sweep_counters_of(void* sort_scratch); // two unsigned 64-bit words: flagged jobs, jobs (added to by every two-stage sweep)
+void* sweep_counters_of(void* sort_scratch); // two unsigned 64-bit words: flagged jobs, jobs (the sweeps whose share the host fetches: launch_sweep_counters_out)
+void* sweep_totals_of(void* sort_scratch);   // the same pair for every other two-stage sweep (read back by e2vq_sweep_executed)
 // perm[slot] = frame, frames grouped by key (< nbins <= 8192); perm holds nblocks64 * 64 slots
 int launch_sort_by_cell(const unsigned short* key, long T, long nblocks64, int nbins, void* scratch, unsigned* perm, hipStream_t s);
 // cand[frame] = c1 | c2 << 13 | amb << 26 | cert << 27.  perm == nullptr: slots are frames.  home_mul: 0 = no home tile,

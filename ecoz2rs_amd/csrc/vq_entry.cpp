@@ -319,6 +319,21 @@ extern "C" int ecoz2_vq_learn_using_base_codebook(const char* base_codebook, dou
 {
     if (!base_codebook || !predictor_filenames || num_predictors < 1)
         return e2vq_set_error("ecoz2_vq_learn_using_base_codebook: bad arguments");
+    // The reference hands this name over as `base_codebook.as_ptr()` of a Rust String (src/ecoz2_lib/mod.rs:295): bytes without
+    // a terminator of their own -- what a C reader finds behind them is whatever the heap holds up to the next NUL.  The names
+    // this path produces and consumes end in ".cbook" (src/vq/mod.rs:27-33: `-B <codebook>`): when the string as given names no
+    // file but a prefix ending in ".cbook" does, that prefix is the name.
+    std::string base_name(base_codebook);
+    {
+        FILE* probe = fopen(base_name.c_str(), "rb");
+        if (probe) {
+            fclose(probe);
+        } else {
+            const size_t at = base_name.find(".cbook");
+            if (at != std::string::npos && at + 6 < base_name.size()) base_name.resize(at + 6);
+        }
+    }
+    base_codebook = base_name.c_str();
     char cls[96];
     int P, M;
     if (e2vq_cbook_info(base_codebook, cls, &P, &M)) return 1;

@@ -105,9 +105,10 @@ static int session_init(e2vq_session* s)
     HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
     s->stream = s->own_stream;
     HIPCHK(hipMalloc(&s->d_sc, sizeof(DevScalars)));
-    HIPCHK(hipMalloc(&s->d_maxabs, 8));
+    // max |x| and the two status words side by side: e2vq_prepare reduces them over the ranks as ONE maximum of two words
+    HIPCHK(hipMalloc(&s->d_maxabs, 16));
+    s->d_flags = (int*)(s->d_maxabs + 1);
     HIPCHK(hipMalloc(&s->d_l1max, 8));
-    HIPCHK(hipMalloc(&s->d_flags, 2 * sizeof(int)));
     HIPCHK(hipMalloc(&s->d_stats, (size_t)(2 * s->NC + 3) * 8));
     HIPCHK(hipMalloc(&s->d_lstats, 64 * 8 * 8));
     HIPCHK(hipMemset(s->d_lstats, 0, 64 * 8 * 8));
@@ -196,7 +197,7 @@ extern "C" void e2vq_session_destroy(e2vq_session* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* ptrs[] = {s->d_cbT, s->sv.refl, s->sv.rows, s->sv.rows_local, s->sv.cells, s->d_rows_parent, s->d_fam, s->d_aos, s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs, s->d_flags,
+    void* ptrs[] = {s->d_cbT, s->sv.refl, s->sv.rows, s->sv.rows_local, s->sv.cells, s->d_rows_parent, s->d_fam, s->d_aos, s->d_refl_spec, s->d_cbq_spec, s->d_cbm_spec, s->d_l1max_spec, s->d_cbm, s->d_blk,   s->d_refl,  s->d_refl_next, s->d_cbq,  s->d_l1max, s->d_sc,   s->d_maxabs,
                     s->d_stats, s->d_rows,  s->d_S,         s->d_within, s->d_lstats, s->d_qaos, s->d_qblk,   s->d_qsym,
                     s->d_qdmin, s->d_colmax, s->d_ea, s->d_fimg, s->d_fg, s->d_cimg2[0], s->d_cimg2[1], s->d_ps2[0], s->d_ps2[1], s->d_ps, s->d_fblist, s->d_prev_sym, s->d_rows_local, s->d_recs, s->d_rec_counts, s->d_fimgF, s->d_perm, s->d_cand, s->d_sort,
                     s->d_ea_q, s->d_qfimg, s->d_qfg, s->d_qfblist, s->d_qcimg};
@@ -469,16 +470,17 @@ extern "C" int e2vq_prepare(e2vq_session* s)
         e2vq::launch_maxabs(s->d_blk, count, s->d_maxabs, s->d_flags, s->stream);
     }
     s->maxabs_scanned = false;  // the all-reduce below overwrites the local maximum: rescan if prepare runs again
-    if (e2vq_reduce(s, s->d_maxabs, 1, 1)) return 1;
+    // one exchange for both maxima: max |x|, and -- the two status words as one unsigned 64-bit word right behind it -- bad
+    // data in ANY shard: every rank learns of it and all of them stop below together, instead of one rank leaving the others
+    // to a collective it will never join (round 6: one call instead of two; the sums further down need the scale this
+    // maximum defines, so they remain a second one)
+    if (e2vq_reduce(s, s->d_maxabs, 2, 1)) return 1;
     e2vq::launch_finish_scalars(s->d_maxabs, s->d_sc, s->stream);
     HIPCHK(hipMemsetAsync(s->d_stats, 0, (size_t)(2 * s->NC + 3) * 8, s->stream));
     e2vq::launch_global_sums(s->d_blk, s->nblocks, s->NC, s->FB, s->d_sc, s->d_stats, s->stream);
     const i64 Tl = s->T;
     HIPCHK(hipMemcpyAsync(s->d_stats + 2 * s->NC + 2, &Tl, 8, hipMemcpyHostToDevice, s->stream));
     if (e2vq_reduce(s, s->d_stats, 2 * s->NC + 3, 0)) return 1;
-    // every rank learns of bad data in ANY shard (the two status words as one unsigned 64-bit maximum): all of them stop
-    // here together instead of one rank leaving the others to a collective it will never join
-    if (e2vq_reduce(s, s->d_flags, 1, 1)) return 1;
     e2vq::launch_finish_q(s->d_stats, s->NC, s->d_sc, s->stream);
     int flags[2];
     i64 Ttot = 0;
@@ -505,6 +507,14 @@ int e2vq_codebook_prepare(e2vq_session* s, bool redefined, bool grown, int zeroe
 {
     if (redefined) s->incr_valid = false;
     if (!grown) s->fam_pending = false;  // (set / init: whatever e2vq_grow stashed belongs to another codebook)
+    if (redefined && !grown) {
+        // a codebook from outside (set / init / restore): the sorted list groups the frames by the cells of ANOTHER codebook --
+        // still a permutation, so a pass over it would be exact, but its two-stage sweep would flag most tiles -- and what
+        // the flagged share of some earlier level said about two stages says nothing about this one
+        s->perm_M = 0;
+        s->two_stage_off_until_M = 0;
+        s->last_flagged_frac = -1.0;
+    }
     s->img_valid[0] = s->img_valid[1] = false;  // the codebook in d_cbq is a new one
     s->cb_version++;
     if (e2vq::has_cell_update(s->NC)) {

@@ -493,7 +493,17 @@ inline uint64_t splitmix64(uint64_t x)
 
 inline double u01(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
 
-void synth_one(uint64_t seed, int n_classes, int P, int64_t t, double* r)
+// kind 1: the mean reflections of the continuum -- orders 1 ... 10 from the Levinson recursion on the first vector the
+// reference prints of its whale-song predictor file (notes.md:80-85: r = 2.35985, 0.32431, -0.69968, ...), beyond them the
+// same alternating pattern fading out, so that r[0] = 1 / E comes out at 2-3 as in that file
+inline double continuum_mean(int i)
+{
+    static const double k10[10] = {-0.1374, 0.3215, -0.1127, 0.2911, -0.1795, 0.2471, -0.1894, 0.2684, -0.1666, 0.2325};
+    if (i <= 10) return k10[i - 1];
+    return ((i & 1) ? -0.13 : 0.20) * pow(0.96, (double)(i - 10));
+}
+
+void synth_one(uint64_t seed, int kind, int n_classes, double noise, int P, int64_t t, double* r)
 {
     const uint64_t ft = splitmix64(seed ^ splitmix64((uint64_t)t + 0x51ED270Bull));
     const int cls = (int)(ft % (uint64_t)n_classes);
@@ -501,15 +511,28 @@ void synth_one(uint64_t seed, int n_classes, int P, int64_t t, double* r)
     double decay = 1.0;
     for (int i = 1; i <= P; ++i) {
         decay *= 0.97;
-        const uint64_t hp = splitmix64(seed * 0x2545F4914F6CDD1Dull + (uint64_t)cls * 1000003ull + (uint64_t)i);
-        const double proto = (u01(hp) * 1.4 - 0.7) * decay;
+        double proto;
+        if (kind == 1) {
+            // a smooth path through reflection space: n_classes slow sinusoids per coefficient (periods 50 ... 5000 frames,
+            // i.e. 0.75 ... 75 s of 15 ms offsets), amplitudes fading with the order
+            proto = continuum_mean(i);
+            const double amp = 0.13 * (i <= 10 ? 1.0 : pow(0.96, (double)(i - 10))) / sqrt((double)n_classes);
+            for (int j = 0; j < n_classes; ++j) {
+                const uint64_t hs = splitmix64(seed * 0x2545F4914F6CDD1Dull + (uint64_t)j * 1000003ull + (uint64_t)i);
+                const double period = 50.0 * pow(100.0, u01(splitmix64(hs ^ 0xA5A5A5A5ull)));
+                proto += amp * sin(6.283185307179586 * ((double)t / period + u01(hs)));
+            }
+        } else {
+            const uint64_t hp = splitmix64(seed * 0x2545F4914F6CDD1Dull + (uint64_t)cls * 1000003ull + (uint64_t)i);
+            proto = (u01(hp) * 1.4 - 0.7) * decay;
+        }
         double g = -6.0;
         uint64_t h = splitmix64(ft + (uint64_t)i * 0xD1B54A32D192ED03ull);
         for (int j = 0; j < 12; ++j) {
             h = splitmix64(h);
             g += u01(h);
         }
-        double v = proto + 0.05 * g;
+        double v = proto + noise * g;
         if (v > 0.95) v = 0.95;
         if (v < -0.95) v = -0.95;
         k[i] = v;
@@ -536,9 +559,11 @@ void synth_one(uint64_t seed, int n_classes, int P, int64_t t, double* r)
 
 }  // namespace
 
-extern "C" int e2vq_synth_frames(uint64_t seed, int n_classes, int P, int64_t first, int64_t count, double* frames)
+extern "C" int e2vq_synth_frames_kind(uint64_t seed, int kind, int n_classes, double noise, int P, int64_t first, int64_t count,
+                                      double* frames)
 {
-    if (n_classes < 1 || P < 1 || P > 200 || count < 0) return e2vq_set_error("e2vq_synth_frames: bad arguments");
+    if (n_classes < 1 || P < 1 || P > 200 || count < 0 || kind < 0 || kind > 1 || !(noise >= 0.0 && noise <= 1.0))
+        return e2vq_set_error("e2vq_synth_frames: bad arguments");
     unsigned nt = std::thread::hardware_concurrency();
     if (nt == 0) nt = 1;
     if (nt > 32) nt = 32;
@@ -547,9 +572,14 @@ extern "C" int e2vq_synth_frames(uint64_t seed, int n_classes, int P, int64_t fi
     for (unsigned w = 0; w < nt; ++w) {
         th.emplace_back([=]() {
             const int64_t a = count * w / nt, b = count * (w + 1) / nt;
-            for (int64_t i = a; i < b; ++i) synth_one(seed, n_classes, P, first + i, frames + (size_t)i * (P + 1));
+            for (int64_t i = a; i < b; ++i) synth_one(seed, kind, n_classes, noise, P, first + i, frames + (size_t)i * (P + 1));
         });
     }
     for (auto& t : th) t.join();
     return 0;
+}
+
+extern "C" int e2vq_synth_frames(uint64_t seed, int n_classes, int P, int64_t first, int64_t count, double* frames)
+{
+    return e2vq_synth_frames_kind(seed, 0, n_classes, 0.05, P, first, count, frames);
 }

@@ -109,7 +109,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     // (from sweep_min_M codewords on: at M = 128 a pass is bound by reading its frames, which round 4's kernel does in
     // their natural order -- 0.35 against 0.40 ms on 2^21 frames; at 256 the two are level, beyond it the sorted pass wins)
     const bool fused = keep && mode != 0 && (family || incremental) && s->sweep2_enabled && s->fused_enabled && s->d_fimgF &&
-                       s->d_aos && s->M >= s->sweep_min_M && e2vq::sweep_supported(s->NC, s->M);
+                       s->d_aos && s->M >= s->sweep_min_M && e2vq::sweep_fused_supported(s->NC, s->M);
     // round 4: contributions recorded by the sweep, folded into the rows by k_reduce_records
     e2vq::PassRecords recplan{};
     bool records = false;
@@ -206,7 +206,8 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         if (fused) {
             // round 5, frames grouped: [sort] -> ONE kernel (two-stage sweep, exact evaluation, outputs, cell sums in the block)
             const int incr = family ? 2 : 1;
-            if (incr == 2 || s->perm_M != s->M) {
+            const bool resort = incr == 2 || s->perm_M != s->M;
+            if (resort) {
                 if (e2vq::launch_sort_by_cell(s->d_prev_sym, s->T, s->nblocks, incr == 2 ? s->M / 2 : s->M, s->d_sort, s->d_perm,
                                               s->stream))
                     return e2vq_set_error("sort by cell: unsupported size");
@@ -214,12 +215,14 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             }
             // (two stages need tiles to skip: from eight tiles on; below, the home tile alone is a quarter or half of the codebook)
             const bool two = s->M >= 256 && s->M > s->two_stage_off_until_M;
-            // the flagged fraction is looked at once per level: on its first pass
-            const bool count = two && incr == 2;
+            // the host looks at the flagged fraction once per grouping of the frames: on the first pass behind every sort (a
+            // level's seeded first pass; the first incremental pass over a codebook that was set or restored from outside).
+            // The other two-stage passes add their jobs to a second pair of words (e2vq_sweep_executed reads them back).
+            const bool count = two && resort;
             s->last_kind = 3;
             s->n_sweep_launches++;
             s->last_two_stage = two;
-            if (incr == 2) s->last_flagged_frac = -1.0;
+            if (resort) s->last_flagged_frac = -1.0;
             if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream));  // (again: behind the sort)
             // (a turn of the kernel's loop takes two blocks of 64 slots where the shard has at least two per wave of the grid --
             // 256 workgroups of 8 waves --, one where it has not; ECOZ2_VQ_ACCUMULATE=sorted: two, whatever the size)
@@ -227,8 +230,9 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             if (e2vq::launch_pass_sorted(s->NC, two, one_block, s->d_fimgF, s->d_perm, s->T, s->nblocks, d_cimg, d_ps, s->d_cbq, s->M, s->d_aos,
                                          s->d_sc, s->d_l1max, (unsigned short*)device_sym, (double*)device_dmin, rows,
                                          family ? s->d_fam : nullptr, s->d_fblist, s->d_prev_sym, incr,
-                                         count ? e2vq::sweep_counters_of(s->d_sort) : nullptr, s->stream))
+                                         count ? e2vq::sweep_counters_of(s->d_sort) : (two ? e2vq::sweep_totals_of(s->d_sort) : nullptr), s->stream))
                 return e2vq_set_error("fused sorted pass: unsupported configuration");
+            if (!two) s->sw_one_stage_jobs += 2ull * (u64)(s->M / 32) * (u64)s->nblocks;  // (every job with all its k-steps)
             if (s->timing) {
                 HIPCHK(hipEventRecord(s->ev1, s->stream));
                 s->timed = true;
@@ -358,6 +362,26 @@ extern "C" int e2vq_last_pass_sweep(e2vq_session* s, int* kind, int* two_stage, 
     if (kind) *kind = s->last_prefiltered ? s->last_kind : 0;
     if (two_stage) *two_stage = s->last_two_stage ? 1 : 0;
     if (flagged_fraction) *flagged_fraction = s->last_flagged_frac;
+    return 0;
+}
+
+// (tile, 32-frame column block) jobs of the two-stage sweeps since the last reset: how many there were and how many ran
+// stage 2 -- every fused sorted pass counts (one atomic per wave), so that the k-steps a timed region EXECUTED can be stated:
+// (jobs * 8 + flagged * 15 + one_stage_jobs * 15) MFMAs at P = 36; one_stage_jobs: the jobs of the fused passes that ran
+// without a coarse stage.  Synchronises the stream.
+extern "C" int e2vq_sweep_executed(e2vq_session* s, int64_t* flagged, int64_t* jobs, int64_t* one_stage_jobs, int reset)
+{
+    HIPCHK(hipSetDevice(s->device));
+    u64 dev[2] = {0, 0};
+    if (s->d_sort) {
+        HIPCHK(hipMemcpyAsync(dev, e2vq::sweep_totals_of(s->d_sort), sizeof dev, hipMemcpyDeviceToHost, s->stream));
+        if (reset) HIPCHK(hipMemsetAsync(e2vq::sweep_totals_of(s->d_sort), 0, sizeof dev, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    if (flagged) *flagged = (int64_t)(dev[0] + s->sw_host_flagged);
+    if (jobs) *jobs = (int64_t)(dev[1] + s->sw_host_jobs);
+    if (one_stage_jobs) *one_stage_jobs = (int64_t)s->sw_one_stage_jobs;
+    if (reset) s->sw_host_flagged = s->sw_host_jobs = s->sw_one_stage_jobs = 0;
     return 0;
 }
 
@@ -633,9 +657,12 @@ int e2vq_pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_faile
     if (s->sw_pending) {  // (stored by the finishing kernel of a two-stage sweep, likewise ahead on the queue)
         const u64 fl = s->h_stats->sw_flagged, jobs = s->h_stats->sw_jobs;
         s->sw_pending = false;
+        s->sw_host_flagged += fl;
+        s->sw_host_jobs += jobs;
         s->last_flagged_frac = jobs ? (double)fl / (double)jobs : -1.0;
-        // most tiles flagged: the coarse stage is wasted on this data -- one stage for the rest of this level (the next level's
-        // first pass tries again: finer cells, more tiles)
+        // most tiles flagged: the coarse stage is wasted on this data -- one stage for the rest of this level.  The switch is
+        // per codebook: a larger one (the next level: finer cells, more tiles) tries again, and so does any codebook defined
+        // from outside (e2vq_codebook_prepare clears it)
         if (jobs && s->last_flagged_frac > s->two_stage_max_frac) s->two_stage_off_until_M = s->M;
     }
     i64 l[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -176,6 +176,8 @@ struct e2vq_session {
     double two_stage_max_frac = 0.45;
     int two_stage_off_until_M = 0;   // one-stage sweeps while M <= this
     bool sw_pending = false;         // a two-stage sweep's counters have not been read yet
+    u64 sw_host_flagged = 0, sw_host_jobs = 0;  // counters the host has fetched since the last e2vq_sweep_executed(reset)
+    u64 sw_one_stage_jobs = 0;                  // jobs of the fused passes that ran one-stage since then
     void* d_fimgF = nullptr;         // frame-major limb image (gathered through d_perm)
     unsigned* d_perm = nullptr;      // slot -> frame, grouped by the cell at the level's start
     unsigned* d_cand = nullptr;      // per frame: the two candidates + flags

@@ -1146,6 +1146,19 @@ bool sweep_supported(int NC, int M)
     }
 }
 
+// the fused sorted pass (launch_pass_sorted) on top of that: its rows fit the waves' LDS regions, its flagged-tile list the
+// codebook's tiles -- asked BEFORE anything of the pass is enqueued (e2vq_pass falls back to the record kernels otherwise)
+bool sweep_fused_supported(int NC, int M)
+{
+    if (!sweep_supported(NC, M) || M / 32 > 256) return false;
+    switch (NC) {
+#define X(N) case N: return SweepLds<N>::FUSE_OK;
+        E2VQ_PRE_NC_LIST(X)
+#undef X
+        default: return false;
+    }
+}
+
 size_t sweep_frame_image_bytes(int NC, long nblocks64)
 {
     switch (NC) {
@@ -1183,7 +1196,7 @@ void launch_sweep_counters_out(void* counters, void* host_counters, hipStream_t 
     hipLaunchKernelGGL(k_sweep_counters_out, dim3(1), dim3(1), 0, s, (SweepCounters*)counters, (unsigned long long*)host_counters);
 }
 
-size_t sort_scratch_bytes() { return (size_t)2 * SORT_MAX_BINS * sizeof(int) + sizeof(SweepCounters); }
+size_t sort_scratch_bytes() { return (size_t)2 * SORT_MAX_BINS * sizeof(int) + 2 * sizeof(SweepCounters); }
 
 // scratch: sort_scratch_bytes() bytes, zeroed once by the caller when it is allocated (the kernels leave the histogram zeroed)
 int launch_sort_by_cell(const unsigned short* key, long T, long nblocks64, int nbins, void* scratch, unsigned* perm, hipStream_t s)
@@ -1203,6 +1216,9 @@ int launch_sort_by_cell(const unsigned short* key, long T, long nblocks64, int n
 }
 
 void* sweep_counters_of(void* sort_scratch) { return (char*)sort_scratch + (size_t)2 * SORT_MAX_BINS * sizeof(int); }
+// a second pair of words: the sweeps whose flagged share the host does not fetch (the passes behind a level's first) add here,
+// so that the executed k-steps of a timed region can be read back afterwards (e2vq_sweep_executed)
+void* sweep_totals_of(void* sort_scratch) { return (char*)sweep_counters_of(sort_scratch) + sizeof(SweepCounters); }
 
 int launch_sweep_candidates(int NC, bool two_stage, const void* fimg, const unsigned* perm, long T, long nblocks, const void* cimg,
                             const void* ps, int M, const unsigned short* prev_sym, int home_mul, unsigned* cand, void* counters,

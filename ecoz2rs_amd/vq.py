@@ -277,6 +277,12 @@ class VqSession:
         check(lib.e2vq_last_pass_sweep(self._h, C.byref(k), C.byref(t), C.byref(f)))
         return k.value, bool(t.value), f.value
 
+    def sweep_executed(self, reset=False):
+        """(flagged jobs, two-stage jobs, one-stage jobs) of the fused sorted passes since the last reset: e2vq_sweep_executed."""
+        f, j, o = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.e2vq_sweep_executed(self._h, C.byref(f), C.byref(j), C.byref(o), int(reset)))
+        return f.value, j.value, o.value
+
     def last_pass_info(self):
         """(prefiltered sweep used?, frames it left to the full FP64 sweep) of the last run_pass."""
         used, n = C.c_int(), C.c_int64()

@@ -190,6 +190,11 @@ int e2vq_last_pass_records(e2vq_session *s, int *recorded, int64_t *records);
  * two-stage pass had to finish with all weight levels (-1: not measured at this level; valid once e2vq_pass_stats has
  * returned for that pass) */
 int e2vq_last_pass_sweep(e2vq_session *s, int *kind, int *two_stage, double *flagged_fraction);
+/* what the fused sorted passes (kind 3) EXECUTED since the last reset, counted by the kernels themselves (one atomic per
+ * wave, every pass): *jobs = (tile, 32-frame column block) jobs of the two-stage passes -- each ran the coarse k-steps --,
+ * *flagged = those of them that also ran stage 2 with all k-steps, *one_stage_jobs = jobs of the passes that ran without a
+ * coarse stage (all k-steps each).  Synchronises the stream; reset != 0 zeroes the counts. */
+int e2vq_sweep_executed(e2vq_session *s, int64_t *flagged, int64_t *jobs, int64_t *one_stage_jobs, int reset);
 /* number of training-pass sweep launches so far, by kernel family (k_pass_pre / k_pass_mfma+generic): lets a
  * kernel trace of a whole run be cut to the dispatches of a timed region */
 int e2vq_sweep_launch_counts(e2vq_session *s, int64_t *prefiltered, int64_t *plain);
@@ -249,6 +254,17 @@ int e2vq_seq_write(const char *path, const char *class_name, int M, const uint16
 /* Synthetic gain-normalised autocorrelation frames [first, first+count) of the stream
  * (seed, n_classes): counter-based, so any shard regenerates identical frames. */
 int e2vq_synth_frames(uint64_t seed, int n_classes, int P, int64_t first, int64_t count, double *frames);
+/* The same stream with its shape exposed (bench.py's config.robustness, tests):
+ *   kind 0  class prototypes + noise: reflection k_i = prototype(class, i) + noise * g, g ~ N(0, 1) (12 uniforms);
+ *           e2vq_synth_frames is (kind 0, noise 0.05).
+ *   kind 1  a continuum, no classes: the reflections of frame t follow a smooth trajectory in t (a few slow sinusoids per
+ *           coefficient around a low-gain mean: r[0] = 1 / E about 2-3 as in the reference's whale-song predictor file,
+ *           notes.md:80-85; neighbouring frames overlap as 45 ms windows at 15 ms offsets do) + noise * g.  n_classes is
+ *           the number of sinusoids per coefficient.
+ * Frames are gain-normalised autocorrelation sequences r / E built by the inverse Levinson recursion, as lpc_rs.rs:116-131
+ * hands them to vq learn. */
+int e2vq_synth_frames_kind(uint64_t seed, int kind, int n_classes, double noise, int P, int64_t first, int64_t count,
+                           double *frames);
 
 #ifdef __cplusplus
 }

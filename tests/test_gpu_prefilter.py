@@ -279,6 +279,62 @@ def test_sorted_pass_big_codebooks(oracle, monkeypatch, accumulate, M, T):
             assert np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64))
 
 
+def test_two_stage_sweep_is_dropped_when_most_tiles_are_flagged(oracle, monkeypatch):
+    """The host's switch (vq_pass.cpp: flagged share of the first pass behind a sort above 0.45 -> one stage for the rest of the
+    level).  A codebook WITHOUT the ladder's tree order -- codewords drawn from the frames at random, so the codewords near a
+    frame are scattered over the tiles -- flags most (tile, column block) jobs: pass 0 (frames not grouped) runs the unfused
+    chain, pass 1 sorts, runs two stages and measures, passes 2.. run the fused kernel with ONE stage.  Symbols, distortions,
+    rows and codebooks equal the oracle's on every pass, whichever sweep ran; a codebook grown by the ladder on the same
+    frames keeps its two stages."""
+    monkeypatch.setenv("ECOZ2_VQ_ACCUMULATE", "sorted")  # (the fused sorted pass from M = 64 on, two blocks per turn)
+    T, M = 40947, 256  # (640 blocks: whole turns of two)
+    frames = _frames(20271, T, classes=8)
+    refl = _codebook(oracle, frames, M, seed=31)
+    rc, st = oracle.data_stats(frames)
+    sh_r, _ = oracle.shifts(st.maxabs)
+    sym, dmin = _DeviceBuffer(2 * T), _DeviceBuffer(8 * T)
+    seen = []
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.set_codebook(refl)
+        s.sweep_executed(reset=True)
+        for it in range(5):
+            cq = oracle.reflections_to_cq(refl)
+            sym_o, dmin_o, rows_o = oracle.run_pass(cq, frames, sh_r, oracle.dist_exponent(cq, st.maxabs))
+            s.run_pass(sym.ptr.value, dmin.ptr.value)
+            s.pass_stats()
+            kind, two, frac = s.last_pass_sweep()
+            seen.append((kind, two, frac))
+            assert np.array_equal(sym.to_host(np.uint16), sym_o), f"pass {it}"
+            assert np.array_equal(dmin.to_host(np.uint64), dmin_o.view(np.uint64)), f"pass {it}"
+            assert oracle_lib.rows_match(s.get_rows(), rows_o, P), f"pass {it}"
+            refl, _failed = oracle.update(rows_o, P, sh_r, refl)
+            s.update()
+            assert np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64))
+        flagged, jobs, one_stage_jobs = s.sweep_executed()
+    sym.free()
+    dmin.free()
+    assert seen[0][0] in (1, 2)                                   # frames not grouped yet
+    assert seen[1][0] == 3 and seen[1][1] and seen[1][2] > 0.45   # sorted, two stages, most jobs flagged: measured
+    assert all(k == 3 and not two for k, two, _f in seen[2:]), seen  # ... so the rest of the level runs one stage
+    nblocks = (T + 63) // 64
+    assert jobs == 2 * (M // 32) * nblocks and one_stage_jobs == 3 * jobs and flagged == round(seen[1][2] * jobs)
+    # the ladder's own codebook of the same size on the same frames: tree-ordered, two stages throughout
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        s.learn(0.05, M // 2)
+        s.grow()
+        for it in range(3):
+            s.run_pass()
+            s.pass_stats()
+            kind, two, frac = s.last_pass_sweep()
+            assert kind == 3 and two and 0.0 <= frac < 0.45, (it, kind, two, frac)
+            s.update()
+
+
 @pytest.mark.parametrize("few_div,expect", [("0", [True] * 5), ("1", [True, False, False, False, False])])
 def test_few_records_switch_the_level_to_the_burst(oracle, monkeypatch, few_div, expect):
     """k_reduce_records publishes the pass's record count; below frames / ECOZ2_VQ_RECORDS_FEW_DIV the rest of the level adds

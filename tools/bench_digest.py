@@ -21,9 +21,10 @@ def digest(cmd, path):
     d = json.loads(line)
     c, r = d["config"], d["roofline"]
     print(f"$ {cmd}")
-    print(f"  value {d['value'] / 1e9:.4f} G frames/s, ms_per_step {d['ms_per_step']:.4f}, n_gpus {d['n_gpus']}, kernel_ms {r['kernel_ms']:.4f}"
-          f" (+ accumulate kernel {r['accumulate_kernel_ms']:.4f}), roofline.frac {r['frac']:.4f}"
-          + (f" ({r['ksteps_per_pair']:.2f} k-steps per pair, flagged {r['flagged_fraction']:.3f};"
+    print(f"  value {d['value'] / 1e9:.4f} G frames/s ({c.get('frames_per_gpu')} frames per GPU, scaling {d.get('scaling')}), ms_per_step {d['ms_per_step']:.4f}, "
+          f"n_gpus {d['n_gpus']}, kernel_ms {r['kernel_ms']:.4f}"
+          f" (+ accumulate kernel {r.get('accumulate_kernel_ms', 0.0):.4f}), roofline.frac {r['frac']:.4f}"
+          + (f" ({r['ksteps_per_pair']:.3f} k-steps per pair counted over the timed passes, flagged {r['flagged_fraction']:.4f};"
              f" one-stage equivalent {r['one_stage_equivalent']['frac_of_peak']:.3f})" if r.get("two_stage") else ""))
     print(f"  sweep launches in the timed region {json.dumps(c.get('timed_sweep_launches'))}")
     par = obj(c.get("parity"))
@@ -39,6 +40,31 @@ def digest(cmd, path):
         if any("allreduce_us_per_call" in l for l in lv):
             print("\n  per level allreduce_us_per_call: " + ", ".join(f"M={l['M']}: {l['allreduce_us_per_call']:.1f}" for l in lv
                                                                       if "allreduce_us_per_call" in l))
+    an = obj(c.get("weak_scaling_anchor"))
+    if isinstance(an, dict) and "value" in an:
+        print(f"\n  anchor ({an['frames']} frames on one GPU): value {an['value'] / 1e9:.4f} G frames/s, ms_per_step {an['ms_per_step']:.4f}, "
+              f"kernel_ms {an['kernel_ms']:.4f}, {an['ksteps_per_pair']:.3f} k-steps per pair")
+        al = an["learn_end_to_end"]
+        print(f"  anchor ladder {al['seconds'] * 1e3:.2f} ms, passes {al['passes_per_level']}; per level kernel ms / step ms per pass: "
+              + ", ".join(f"M={l['M']}: {l['kernel_ms']:.3f} / {l['step_ms']:.3f}" for l in al["levels"]))
+    elif an:
+        print("\n  anchor " + json.dumps(an)[:300])
+    rb = obj(c.get("robustness"))
+    if isinstance(rb, dict):
+        print(f"\n  robustness (M = {c.get('codebook_size')} level on {rb['frames']} frames; all equal the plain sweep: {rb['all_equal_plain_sweep']}; "
+              f"any slower than round 4's {rb['round4_kernel_ms_on_2p21_frames']} ms: {rb['any_slower_than_round4']}):")
+        for g in rb["generators"]:
+            if "error" in g:
+                print(f"    {g['generator']:22s} ERROR {g['error']}")
+                continue
+            print(f"    {g['generator']:22s} r0 {g['mean_r0']:8.2f}  flagged(first pass) {g['flagged_fraction_first_pass']:.3f}  two stages kept {g['two_stage_kept']}  "
+                  f"kernel ms per pass {[round(p['kernel_ms'], 3) for p in g['per_pass']]} kinds {[(p['sweep_kind'], int(p['two_stage'])) for p in g['per_pass']]}  "
+                  f"equals plain {g['equals_plain_sweep']}")
+    qz = obj(c.get("quantize"))
+    if isinstance(qz, dict):
+        rq = qz["roofline_quantize"]
+        print(f"\n  quantize ({qz['frames']} frames, M = {qz['codebook_size']}): {qz['frames_per_sec_device_resident'] / 1e9:.3f} G frames/s, kernels {qz['kernel_ms']:.3f} ms, "
+              f"roofline_quantize.frac {rq['frac']:.3f} ({rq['achieved']:.0f} TF executed)")
     s16 = obj(c.get("strong_scaling_16M"))
     if isinstance(s16, dict):
         print(f"\n  16 M frames on one GPU: M = 1024 level {s16['level_ms_per_pass']:.3f} ms per pass (kernels "

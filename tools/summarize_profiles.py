@@ -102,6 +102,8 @@ def main():
     b = bench_line("kt")
     hint = b["roofline"]["trace_dispatches"]
     M = b["config"].get("codebook_size", 1024)
+    global T
+    T = b["config"].get("frames_per_gpu", T)
     L = b["config"]["passes_per_level"]
     if hint["kernel"] == "k_pass_pre" and hint["count"] != b["steps"]:
         L = max(1, hint["count"] * L // b["steps"])  # (some passes of the level ran the plain sweep: M = 256)
@@ -116,7 +118,11 @@ def main():
         "note": f"timed region = {len(d) // L} repetitions of the real M={M} level ({L} passes: the first seeded with the parents' sums, "
                 "the others incremental); bench.py's HIP-event average over the same launches is bench_kernel_ms",
         "bench_kernel_ms": b["roofline"]["kernel_ms"], "bench_ms_per_step": b["ms_per_step"], "bench_value": b["value"],
-        "vgpr": rows[0].get("VGPR_Count"), "accum_vgpr": rows[0].get("Accum_VGPR_Count"),
+        # (rocprofv3 reports the architectural and the accumulation registers separately; the wave's allocation -- what
+        # bounds the occupancy: 512 per SIMD lane -- is their sum)
+        "arch_vgpr": rows[0].get("VGPR_Count"), "accum_vgpr": rows[0].get("Accum_VGPR_Count"),
+        "unified_vgpr": (int(rows[0].get("VGPR_Count") or 0) + int(rows[0].get("Accum_VGPR_Count") or 0)) or None,
+        "frames_per_launch": T,
         "lds_bytes": rows[0].get("LDS_Block_Size"), "grid": rows[0].get("Grid_Size"), "workgroup": rows[0].get("Workgroup_Size"),
         "kernel_sources_sha16": kernel_sources_sha16(),
         "source": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --steps 21 "
@@ -147,7 +153,8 @@ def main():
         w, wsel = counters(newest(f"{SRC}/{TAG}_write/*/*_counter_collection.csv"), hw)
         prefiltered = hint["kernel"] in ("k_pass_pre", "k_sweep_cand")
         tj = {
-            "kernel": out["kernel"] + f" at M={M}, 2^21 frames per launch (bench.py --steps 6: two repetitions of the {L}-pass level)",
+            "kernel": out["kernel"] + f" at M={M}, {T} frames per launch (bench.py --steps 6: two repetitions of the {L}-pass level)",
+            "frames_per_launch": T,
             "FETCH_SIZE_KB_raw": f["FETCH_SIZE"], "WRITE_SIZE_KB_raw": w["WRITE_SIZE"],
             "FETCH_SIZE_KB_per_step": [x["FETCH_SIZE"] for x in fsel], "WRITE_SIZE_KB_per_step": [x["WRITE_SIZE"] for x in wsel],
             "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> doubled "
