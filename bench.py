@@ -735,51 +735,82 @@ class LevelBench:
         self.sess.close()
 
 
+def level_pass_by_pass(lb):
+    """the level M of a LevelBench step by step (same calls, same order as e2vq_learn's loop), synchronised around every pass:
+    per pass the sweep kernels' event time, the wall time of pass + statistics + update, which sweep ran, how many frames it
+    left to the FP64 fallback sweep, and what the host has decided by then"""
+    sess = lb.sess
+    sess.restore_state()
+    sess.grow()
+    passes = []
+    dd_prev = sess.prev_distortion()
+    for i in range(64):
+        sess.enable_timing(True)
+        sess.synchronize()
+        t0 = time.perf_counter()
+        sess.run_pass()
+        st = sess.pass_stats()
+        sess.synchronize()
+        wall = time.perf_counter() - t0
+        ms = sess.timing_total()[0]
+        kd, two, ff = sess.last_pass_sweep()
+        one_until, plain_from, unc = sess.sweep_policy_state()
+        passes.append({"kernel_ms": ms, "step_ms": wall * 1e3, "sweep_kind": kd, "two_stage": two,
+                       "uncertified_frames": unc, "flagged_fraction": ff if (i == 0 and two) else None,
+                       "decided": {"one_stage_until_M": one_until, "plain_sweep_from_M": plain_from}})
+        ratio = (dd_prev - st.DD) / st.DD
+        dd_prev = st.DD
+        if i > 0 and not ratio >= lb.EPS:
+            break
+        sess.update()
+    sess.enable_timing(False)
+    return passes
+
+
 def robustness_section(e, torch, comm, local, M, S):
     """Untimed extra (VERDICT r05 task 2): the headline level on data of other shapes.  Per generator: the ladder 2 .. M/2, then
-    the level M as the ladder runs it -- flagged share of the two-stage sweep's jobs (first pass), whether the host kept two
-    stages for the rest of the level, sweep-kernel ms per pass by pass, and the same level on the plain FP64 sweep: codebook
-    bytes, pass count and DD must be identical."""
+    the level M pass by pass five ways -- the product (the host's switches at their defaults), one stage behind the measuring
+    pass, two stages whatever the flagged share, round 4's kernel throughout (k_pass_pre_lds + k_reduce_records: ECOZ2_VQ_ACCUMULATE=records), the plain FP64 sweep -- and the
+    level through e2vq_learn prefiltered and plain: codebook bytes, pass count and DD must be identical."""
     import hashlib
 
     out = {"what": f"the M={M} level on {S} frames of other generators (one GPU, untimed extras): does the two-stage sweep's gain "
-                   "survive data without the bench data's cluster structure, and does the host's switch to one stage (flagged "
-                   "share above 0.45 on the level's first pass) pick the faster kernel?",
-           "round4_kernel_ms_on_2p21_frames": R04_KERNEL_MS_2P21, "frames": S, "generators": []}
+                   "survive data without the bench data's cluster structure, do the host's switches (one stage above a flagged "
+                   "share; plain sweep above an uncertified share) pick the fastest kernel, and what does a pass cost on data "
+                   "shaped like the reference's own corpus?  kernel_ms = the sweep kernels of a pass (HIP events), step_ms = wall "
+                   "time of pass + statistics + update, synchronised (the FP64 fallback sweep of uncertified frames is in step_ms "
+                   "only)",
+           "round4_kernel_ms_on_2p21_frames_bench_data": R04_KERNEL_MS_2P21, "frames": S, "generators": []}
+
+    def brief(passes):
+        return {"passes": len(passes), "kernel_ms": [round(p["kernel_ms"], 4) for p in passes],
+                "step_ms": [round(p["step_ms"], 4) for p in passes],
+                "sweeps": [("plain" if p["sweep_kind"] == 0 else f"kind{p['sweep_kind']}" + ("/two-stage" if p["two_stage"] else "/one-stage"))
+                           for p in passes],
+                "uncertified_fraction": [None if p["uncertified_frames"] < 0 else round(p["uncertified_frames"] / S, 5) for p in passes],
+                "step_ms_per_pass": sum(p["step_ms"] for p in passes) / len(passes)}
+
     for name, kind, ncls, noise, what in ROBUSTNESS_GENERATORS:
         row = {"generator": name, "what": what, "synth": {"kind": kind, "n_classes": ncls, "noise": noise, "seed": SEED}}
         try:
             frames = e.synth.synth_frames_kind(SEED, kind, ncls, noise, P, 0, S)
             row["mean_r0"] = float(frames[:4096, 0].mean())
             lb = LevelBench(e, torch, comm, local, frames, M)
-            del frames
             sess = lb.sess
             lb.whole_level()  # (warm)
-            # pass by pass: kernel time of each, the sweep that served it
-            sess.restore_state()
-            sess.grow()
-            passes = []
-            for i in range(64):
-                sess.enable_timing(True)
-                sess.run_pass()
-                st = sess.pass_stats()
-                ms = sess.timing_sweep_total()[0]
-                kd, two, ff = sess.last_pass_sweep()
-                passes.append({"kernel_ms": ms, "sweep_kind": kd, "two_stage": two})
-                if i == 0:
-                    row["flagged_fraction_first_pass"] = ff
-                    dd_prev = sess.prev_distortion()
-                ratio = (dd_prev - st.DD) / st.DD
-                dd_prev = st.DD
-                if i > 0 and not ratio >= lb.EPS:
-                    break
-                sess.update()
-            sess.enable_timing(False)
-            row["passes"] = len(passes)
-            row["per_pass"] = passes
-            row["kernel_ms_per_pass"] = sum(p["kernel_ms"] for p in passes) / len(passes)
-            row["two_stage_kept"] = bool(passes[-1]["two_stage"])
-            row["slower_than_round4"] = bool(max(p["kernel_ms"] for p in passes) * ((1 << 21) / S) > R04_KERNEL_MS_2P21)
+            sess.set_sweep_policy(-1.0, -1.0)  # (defaults; forgets what the warm-up decided)
+            prod = level_pass_by_pass(lb)
+            row["flagged_fraction_first_pass"] = prod[0]["flagged_fraction"]
+            row["product"] = brief(prod)
+            row["product"]["decided"] = prod[-1]["decided"]
+            sess.set_sweep_policy(0.0, 1.0)   # one stage from the second pass on (round 4's kernel), never the plain sweep
+            row["one_stage_after_first_pass"] = brief(level_pass_by_pass(lb))
+            sess.set_sweep_policy(1.0, 1.0)   # two stages whatever the flagged share
+            row["sorted_two_stage"] = brief(level_pass_by_pass(lb))
+            sess.set_prefilter(False)
+            row["plain_sweep"] = brief(level_pass_by_pass(lb))
+            sess.set_prefilter(True)
+            sess.set_sweep_policy(0.45, 0.40)
             # the level through e2vq_learn, prefiltered and plain: identical bytes?
             lv_pre = lb.whole_level()
             cb_pre = sess.get_codebook()
@@ -792,11 +823,30 @@ def robustness_section(e, torch, comm, local, M, S):
             row["equals_plain_sweep"] = bool(cb_plain.tobytes() == cb_pre.tobytes() and lv_plain.passes == lv_pre.passes and
                                              lv_plain.DD.hex() == lv_pre.DD.hex())
             lb.close()
+            # round 4's kernel on the same frames (the accumulate is chosen when a session is created)
+            old = os.environ.get("ECOZ2_VQ_ACCUMULATE")
+            os.environ["ECOZ2_VQ_ACCUMULATE"] = "records"
+            try:
+                lb4 = LevelBench(e, torch, comm, local, frames, M)
+                lb4.sess.set_sweep_policy(-1.0, 1.0)
+                lb4.whole_level()
+                row["round4_kernel"] = brief(level_pass_by_pass(lb4))
+                lb4.close()
+            finally:
+                if old is None:
+                    os.environ.pop("ECOZ2_VQ_ACCUMULATE", None)
+                else:
+                    os.environ["ECOZ2_VQ_ACCUMULATE"] = old
+            del frames
+            variants = {k: row[k]["step_ms_per_pass"] for k in ("product", "one_stage_after_first_pass", "sorted_two_stage", "plain_sweep", "round4_kernel")}
+            row["step_ms_per_pass"] = {k: round(v, 4) for k, v in variants.items()}
+            row["fastest"] = min(variants, key=variants.get)
+            row["product_over_fastest"] = variants["product"] / min(variants.values())
         except Exception as ex:  # informational: never fails the bench line by itself
             row["error"] = repr(ex)
         out["generators"].append(row)
     out["all_equal_plain_sweep"] = all(g.get("equals_plain_sweep") for g in out["generators"])
-    out["any_slower_than_round4"] = any(g.get("slower_than_round4") for g in out["generators"])
+    out["worst_product_over_fastest"] = max((g.get("product_over_fastest", 0.0) for g in out["generators"]), default=None)
     return out
 
 

@@ -93,6 +93,8 @@ _sig("e2vq_last_pass_info", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C
 _sig("e2vq_last_pass_records", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64))
 _sig("e2vq_last_pass_sweep", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double))
 _sig("e2vq_sweep_executed", C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int)
+_sig("e2vq_set_sweep_policy", C.c_int, C.c_void_p, C.c_double, C.c_double)
+_sig("e2vq_sweep_policy_state", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64))
 _sig("e2vq_set_prev_distortion", C.c_int, C.c_void_p, C.c_double)
 _sig("e2vq_get_prev_distortion", C.c_int, C.c_void_p, C.POINTER(C.c_double))
 _sig("e2vq_sweep_launch_counts", C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))

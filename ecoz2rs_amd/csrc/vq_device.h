@@ -178,6 +178,8 @@ struct PublishArgs {
     volatile unsigned long long* h_seq2;
     unsigned long long seq;
     volatile unsigned long long* h_err;  // set to seq if a flag did not arrive within the publisher's spin cap
+    const int* fb_count;                 // (optional) the fallback count of the pass's prefiltered sweep ...
+    long long* h_fb;                     // ... and where the publisher copies it (-1 when there is none)
 };
 void launch_cell_update(const long long* rows, int M, int NC, const DevScalars* sc, const double* refl_in,
                         double* refl_out, double* cbq, double* cbm, unsigned long long* l1max_bits, double* within,

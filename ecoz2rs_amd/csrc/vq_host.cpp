@@ -514,6 +514,7 @@ int e2vq_codebook_prepare(e2vq_session* s, bool redefined, bool grown, int zeroe
         s->perm_M = 0;
         s->two_stage_off_until_M = 0;
         s->last_flagged_frac = -1.0;
+        s->pre_off_from_M = 0;
     }
     s->img_valid[0] = s->img_valid[1] = false;  // the codebook in d_cbq is a new one
     s->cb_version++;

@@ -40,6 +40,7 @@ bool e2vq_use_prefilter(const e2vq_session* s, int mode)
           e2vq::prefilter_supports(s->NC, s->M)))
         return false;
     if (mode == 0) return true;
+    if (s->pre_off_from_M && s->M >= s->pre_off_from_M) return false;  // (too many uncertified frames on this data: round 6)
     // an accumulating prefiltered pass needs the row-major resident copy with LDS room for a block of it, and an accumulate
     // that takes its rows: records, or -- rows of at most 80 elements -- the burst of atomics.  Anything else runs the
     // plain FP64 sweep (round 2's accumulating kernel, which served those cases, left in round 5).
@@ -104,12 +105,19 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     // the first pass after a split, seeded with the parents' sums (e2vq_grow stashed them): k_seed_family
     bool family = s->fam_pending && keep && !incremental && s->d_aos && 2 * s->fam_M == s->M && mode != 0;
     s->fam_pending = false;
+    s->last_first_of_level = !incremental;  // (the pass right behind a split: twin codewords, more uncertified frames)
     // round 5: the frames are grouped by cell (a seeded first pass, or an incremental one) -> the fused sorted pass: sweep,
     // exact evaluation, outputs and the cell sums reduced in the block, one kernel (vq_sweep.hip); no records
     // (from sweep_min_M codewords on: at M = 128 a pass is bound by reading its frames, which round 4's kernel does in
     // their natural order -- 0.35 against 0.40 ms on 2^21 frames; at 256 the two are level, beyond it the sorted pass wins)
+    // round 6: ... where its two-stage sweep pays.  On data that flags most tiles (a level's first sorted pass measures it:
+    // two_stage_off_until_M) the frames gain nothing from being grouped, and round 4's kernel -- frames in their natural
+    // order, read sequentially -- is the faster one-stage pass: 1.05 against 1.2-1.3 ms at M = 1024 on 2^21 frames
+    // (bench.py config.robustness).  ECOZ2_VQ_ACCUMULATE=sorted keeps the sorted pass, one stage or two (tests).
+    const bool two_ok = s->M >= 256 && s->M > s->two_stage_off_until_M;
     const bool fused = keep && mode != 0 && (family || incremental) && s->sweep2_enabled && s->fused_enabled && s->d_fimgF &&
-                       s->d_aos && s->M >= s->sweep_min_M && e2vq::sweep_fused_supported(s->NC, s->M);
+                       s->d_aos && s->M >= s->sweep_min_M && e2vq::sweep_fused_supported(s->NC, s->M) &&
+                       (two_ok || s->two_blocks_always);
     // round 4: contributions recorded by the sweep, folded into the rows by k_reduce_records
     e2vq::PassRecords recplan{};
     bool records = false;
@@ -214,7 +222,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
                 s->perm_M = s->M;
             }
             // (two stages need tiles to skip: from eight tiles on; below, the home tile alone is a quarter or half of the codebook)
-            const bool two = s->M >= 256 && s->M > s->two_stage_off_until_M;
+            const bool two = two_ok;
             // the host looks at the flagged fraction once per grouping of the frames: on the first pass behind every sort (a
             // level's seeded first pass; the first incremental pass over a codebook that was set or restored from outside).
             // The other two-stage passes add their jobs to a second pair of words (e2vq_sweep_executed reads them back).
@@ -248,7 +256,8 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
                                        (double*)device_dmin, rows, s->d_fblist, e2vq::prefilter_fallback_count(d_ps), s->d_prev_sym,
                                        incr, s->stream);
             if (family) e2vq::launch_family_fixup(rows, s->d_fam, s->fam_M, s->NC, s->stream);
-        } else if (records && s->sweep2_enabled && s->d_fimgF && s->M >= s->sweep_min_M && e2vq::sweep_supported(s->NC, s->M)) {
+        } else if (records && s->sweep2_enabled && s->d_fimgF && s->M >= s->sweep_min_M && e2vq::sweep_supported(s->NC, s->M) &&
+                   (two_ok || s->two_blocks_always || !s->fused_enabled || !(family || incremental))) {
             // round 5: [sort] -> candidate sweep -> finishing kernel (exact evaluation, outputs, records) -> reduce
             const int incr = family ? 2 : (incremental ? 1 : 0);
             if (incr != 0 && (incr == 2 || s->perm_M != s->M)) {
@@ -259,7 +268,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             }
             const bool sorted = incr != 0 && s->perm_M == s->M;
             // (two stages need tiles to skip: from eight tiles on; below, the home tile alone is a quarter or half of the codebook)
-            const bool two = sorted && s->M >= 256 && s->M > s->two_stage_off_until_M;
+            const bool two = sorted && two_ok;
             s->last_kind = 2;
             s->n_sweep_launches++;
             s->last_two_stage = two;
@@ -382,6 +391,32 @@ extern "C" int e2vq_sweep_executed(e2vq_session* s, int64_t* flagged, int64_t* j
     if (jobs) *jobs = (int64_t)(dev[1] + s->sw_host_jobs);
     if (one_stage_jobs) *one_stage_jobs = (int64_t)s->sw_one_stage_jobs;
     if (reset) s->sw_host_flagged = s->sw_host_jobs = s->sw_one_stage_jobs = 0;
+    return 0;
+}
+
+// The two switches the host makes from what a pass measured (both only choose kernels: results are the same bits either way).
+//   two_stage_max_fraction  flagged share of a level's first sorted pass above which the rest of the level runs without the
+//                           coarse stage (0 = never two stages beyond the measuring pass, 1 = always)
+//   max_uncertified_fraction share of a pass's frames the prefiltered sweep may leave to the FP64 fallback sweep before the
+//                           plain FP64 sweep takes over from that codebook size on (1 = never)
+// A negative argument leaves the value as it is.  Also clears what earlier passes of this session decided.
+extern "C" int e2vq_set_sweep_policy(e2vq_session* s, double two_stage_max_fraction, double max_uncertified_fraction)
+{
+    if (two_stage_max_fraction >= 0.0) s->two_stage_max_frac = two_stage_max_fraction;
+    if (max_uncertified_fraction >= 0.0) s->pre_max_uncertified = max_uncertified_fraction;
+    s->two_stage_off_until_M = 0;
+    s->pre_off_from_M = 0;
+    return 0;
+}
+
+// what the last passes decided: *one_stage_until_M = codebook sizes up to this run the sorted pass without a coarse stage
+// (0: none), *plain_from_M = training passes from this codebook size on run the plain FP64 sweep (0: none),
+// *uncertified = frames the last prefiltered pass left to the fallback sweep (-1: the last pass was not prefiltered)
+extern "C" int e2vq_sweep_policy_state(e2vq_session* s, int* one_stage_until_M, int* plain_from_M, int64_t* uncertified)
+{
+    if (one_stage_until_M) *one_stage_until_M = s->two_stage_off_until_M;
+    if (plain_from_M) *plain_from_M = s->pre_off_from_M;
+    if (uncertified) *uncertified = s->last_fb;
     return 0;
 }
 
@@ -624,6 +659,8 @@ int e2vq_pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_faile
         pub.h_failed = &dstats->failed;
         pub.h_seq2 = (volatile u64*)&dstats->seq2;
         pub.h_err = (volatile u64*)&dstats->err;
+        pub.fb_count = s->last_prefiltered ? e2vq::prefilter_fallback_count(s->d_ps2[s->img_last]) : nullptr;
+        pub.h_fb = (long long*)&dstats->fb;
         pub.seq = ++s->stats_seq;
         e2vq::launch_cell_update(s->d_rows, s->M, s->NC, s->d_sc, s->d_refl, s->d_refl_spec, s->d_cbq_spec,
                                  s->d_cbm_spec, s->d_l1max_spec, s->d_within, s->d_lstats, s->stream,
@@ -654,6 +691,15 @@ int e2vq_pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_faile
         s->rec_last_total = s->h_stats->rec_total;
         s->rec_pending = false;
     }
+    if (fused) {  // (the publisher copied the pass's fallback count along)
+        s->last_fb = s->last_prefiltered ? (i64)s->h_stats->fb : -1;
+        // (a level's first pass runs on twins -- every codeword next to its sibling -- and certifies fewer frames than the
+        // passes behind it: 0.47 against 0.27 on the continuum data of bench.py; it is given half as much rope again)
+        const double limit = s->last_first_of_level ? std::min(1.0, 1.5 * s->pre_max_uncertified) : s->pre_max_uncertified;
+        if (s->last_fb >= 0 && s->T > 0 && (double)s->last_fb > limit * (double)s->T &&
+            (!s->pre_off_from_M || s->M < s->pre_off_from_M))
+            s->pre_off_from_M = s->M;
+    }
     if (s->sw_pending) {  // (stored by the finishing kernel of a two-stage sweep, likewise ahead on the queue)
         const u64 fl = s->h_stats->sw_flagged, jobs = s->h_stats->sw_jobs;
         s->sw_pending = false;
@@ -664,6 +710,9 @@ int e2vq_pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_faile
         // per codebook: a larger one (the next level: finer cells, more tiles) tries again, and so does any codebook defined
         // from outside (e2vq_codebook_prepare clears it)
         if (jobs && s->last_flagged_frac > s->two_stage_max_frac) s->two_stage_off_until_M = s->M;
+        // (nearly every job flagged: the next size will not look different -- its first pass is not spent on finding out; the
+        // size after that tries again)
+        if (jobs && s->last_flagged_frac > 0.8 && s->last_flagged_frac > s->two_stage_max_frac) s->two_stage_off_until_M = 2 * s->M;
     }
     i64 l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int slot = 0; slot < 64; ++slot)

@@ -72,7 +72,7 @@ struct e2vq_session {
     bool spec_valid = false;
     bool spec_zeroed = false;  // the pass prologue zeroed d_l1max_spec and the shadow image's scalars
     hipEvent_t ev_stats = nullptr;
-    struct HostStats { i64 l[64 * 8]; u64 l1bits; volatile u64 seq; i64 failed; volatile u64 seq2; volatile u64 err; volatile i64 rec_total; volatile u64 sw_flagged, sw_jobs; }* h_stats = nullptr;  // pinned, host-mapped
+    struct HostStats { i64 l[64 * 8]; u64 l1bits; volatile u64 seq; i64 failed; volatile u64 seq2; volatile u64 err; volatile i64 rec_total; volatile u64 sw_flagged, sw_jobs; volatile i64 fb; }* h_stats = nullptr;  // pinned, host-mapped
     long verified_passes = 0;
     bool verify_publish = false;  // ECOZ2_VQ_VERIFY_PUBLISH: recompute every published statistic on the host from the rows
     bool failed_pending = false;              // the failed-recursion count of stats_seq has not been read yet (seq2)
@@ -174,6 +174,15 @@ struct e2vq_session {
     bool fused_enabled = true;       // ECOZ2_VQ_ACCUMULATE=sweep: grouped passes as sweep + finishing kernel + reduce too (A/B)
     int sweep_min_M = 256;           // smallest codebook of the round-5 kernels (ECOZ2_VQ_ACCUMULATE=sorted / sweep: 64)
     double two_stage_max_frac = 0.45;
+    // round 6: the share of a pass's frames the prefiltered sweep could not certify is published with the statistics; above
+    // pre_max_uncertified the FP64 fallback sweep of those frames costs more than the prefilter saves (data whose distortions
+    // are a small difference of large terms: DESIGN 4.2) -- the plain sweep takes over from this codebook size on, until a
+    // codebook is defined from outside
+    double pre_max_uncertified = 0.40;  // (round 4's kernel + the list-driven FP64 sweep of a share u of 2^21 frames at M = 1024:
+                                        // 1.0 + 4.8 u ms against the plain sweep's 2.9: bench.py config.robustness)
+    bool last_first_of_level = false;
+    int pre_off_from_M = 0;          // plain FP64 sweep for training passes while M >= this (0: never)
+    i64 last_fb = -1;                // uncertified frames of the last prefiltered pass (-1: not a prefiltered pass)
     int two_stage_off_until_M = 0;   // one-stage sweeps while M <= this
     bool sw_pending = false;         // a two-stage sweep's counters have not been read yet
     u64 sw_host_flagged = 0, sw_host_jobs = 0;  // counters the host has fetched since the last e2vq_sweep_executed(reset)

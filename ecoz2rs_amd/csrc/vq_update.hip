@@ -163,9 +163,15 @@ __device__ __forceinline__ double lane_shl1(double x)
     return __hiloint2double(hi, lo);
 }
 // ((0.0 + x[first]) + x[first+1]) + ... + x[last], the terms taken from lanes first..last (wave-uniform bounds)
+template <bool CONST_BOUNDS = false>
 __device__ __forceinline__ double lane_ordered_sum(double x, int first, int last)
 {
     double sum = 0.0;
+    if constexpr (CONST_BOUNDS) {  // (first / last are constants after the caller's loop has been unrolled)
+#pragma unroll
+        for (int i = first; i <= last; ++i) sum += lane_bcast(x, i);
+        return sum;
+    }
     int i = first;
     for (; i + 3 <= last; i += 4) {
         const double t0 = lane_bcast(x, i), t1 = lane_bcast(x, i + 1), t2 = lane_bcast(x, i + 2),
@@ -191,14 +197,21 @@ __device__ __forceinline__ void step_up(int lane, int k, double akk, double& a, 
     arev = lane_shr1(arev);
 }
 
+// NCT > 0 (round 6): the order is a compile-time constant -- every loop below is unrolled, every broadcast comes from a
+// CONSTANT lane, and the 666 + 3 x 37 dependent additions of a cell are straight-line code: two v_readlane (independent of
+// the chain: issued ahead) and one v_add_f64 per term, no loop counter, no branch.  With run-time bounds (NCT = 0: the other
+// orders) a term cost ~75 cycles -- scalar loop control and a lane select from an SGPR in front of every group of four --;
+// the order of the additions, and with it every bit of the result, is the same either way (src/lpc/lpca_r_rs.rs:17-24).
+template <int NCT>
 __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
-    const i64* __restrict__ rows, int M, int NC, const DevScalars* __restrict__ sc, const double* refl_in,
+    const i64* __restrict__ rows, int M, int NC_rt, const DevScalars* __restrict__ sc, const double* refl_in,
     double* refl_out, double* __restrict__ cbq, double* __restrict__ cbm, int MT, u64* __restrict__ l1max_bits,
     double* __restrict__ within, i64* __restrict__ lstats, const int* __restrict__ ea, int* __restrict__ eC_biased,
     PublishArgs pub)
 {
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int m = blockIdx.x * CU_WAVES + wib;
+    const int NC = NCT ? NCT : NC_rt;
     const int P = NC - 1, RS = (2 * NC + 5 + 7) & ~7, NPAD = (NC + 7) & ~7;
     const int nb = (M + CU_WAVES - 1) / CU_WAVES;  // workgroups that own cells
     if (pub.flags && (int)blockIdx.x == nb) {      // the publisher (dispatched last: every cell workgroup is under way)
@@ -231,6 +244,9 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
             pub.h_within[i] = __longlong_as_double(
                 (i64)__hip_atomic_load((const u64*)&within[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (threadIdx.x == 0) *pub.h_l1 = __hip_atomic_load(pub.l1max_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the frames the pass's prefiltered sweep could not certify: the host weighs them against the plain sweep)
+        if (threadIdx.x == 1 && pub.h_fb)
+            *pub.h_fb = pub.fb_count ? (long long)__hip_atomic_load(pub.fb_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1ll;
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
         if (cnt != 0) {  // wave-uniform
             S = act ? unfix(row[2 * lane], row[2 * lane + 1], sc->sh_r) : 0.0;
             // within-cell term: ss = sum_n S_n^2 (ascending n), / count
-            w = lane_ordered_sum(S * S, 0, P) / (double)cnt;
+            w = lane_ordered_sum<(NCT > 0)>(S * S, 0, P) / (double)cnt;
         }
         if (lane == 0)
             __hip_atomic_store((u64*)&within[m], (u64)__double_as_longlong(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -313,9 +329,10 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
                 status = 1;
             } else {
                 double pe = r0;
+#pragma unroll
                 for (int k = 1; k <= P; ++k) {
                     // sum = ((0 - a[k-1] r[1]) - a[k-2] r[2]) - ... - a[0] r[k]   (x - y == x + (-y), exactly)
-                    const double sum = lane_ordered_sum(-(arev * S), 1, k);
+                    const double sum = lane_ordered_sum<(NCT > 0)>(-(arev * S), 1, k);
                     const double akk = sum / pe;
                     if (lane == k) rcn = akk;
                     step_up(lane, k, akk, a, arev);
@@ -347,19 +364,21 @@ __global__ __launch_bounds__(64 * CU_WAVES) void k_cell_update(
         if (!have_a) {  // step-up from the reflections (same element-wise updates as inside lpca_r)
             a = lane == 0 ? 1.0 : 0.0;
             arev = lane == 1 ? 1.0 : 0.0;
+#pragma unroll
             for (int k = 1; k <= P; ++k) step_up(lane, k, lane_bcast(rcn, k), a, arev);
         }
         if (!act) a = 0.0;
 
         // ---- raas: raa[n] = sum_{i=0}^{P-n} a[i]*a[i+n]  (ascending i) -> cq ------------------------------
         double raa = 0.0, ash = a;  // ash = a[lane + i]
+#pragma unroll
         for (int i = 0; i <= P; ++i) {
             const double t = raa + lane_bcast(a, i) * ash;
             raa = i + lane <= P ? t : raa;
             ash = lane_shl1(ash);
         }
         const double c = !act ? 0.0 : (lane == 0 ? raa : 2.0 * raa);
-        const double l1 = lane_ordered_sum(fabs(c), 0, P);
+        const double l1 = lane_ordered_sum<(NCT > 0)>(fabs(c), 0, P);
         if (lane == 0) {  // monotone max: skip the atomic unless it can still raise the value
             const u64 bits = (u64)__double_as_longlong(l1);
             if (bits > __hip_atomic_load(l1max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
@@ -631,9 +650,13 @@ void launch_cell_update(const i64* rows, int M, int NC, const DevScalars* sc, co
     const int MT = (M + 15) / 16;
     PublishArgs p{};
     if (pub) p = *pub;
-    hipLaunchKernelGGL(k_cell_update, dim3((M + CU_WAVES - 1) / CU_WAVES + (p.flags ? 1 : 0)), dim3(64 * CU_WAVES), 0,
-                       s, rows, M, NC, sc, refl_in, refl_out, cbq, cbm, MT, l1max_bits, within, lstats, ea, eC_biased,
-                       p);
+    const dim3 grid((M + CU_WAVES - 1) / CU_WAVES + (p.flags ? 1 : 0)), block(64 * CU_WAVES);
+    if (NC == 37)  // P = 36, the reference's default order (src/lpc/mod.rs:17-74) and BASELINE's: straight-line code
+        hipLaunchKernelGGL(k_cell_update<37>, grid, block, 0, s, rows, M, NC, sc, refl_in, refl_out, cbq, cbm, MT, l1max_bits, within,
+                           lstats, ea, eC_biased, p);
+    else
+        hipLaunchKernelGGL(k_cell_update<0>, grid, block, 0, s, rows, M, NC, sc, refl_in, refl_out, cbq, cbm, MT, l1max_bits, within,
+                           lstats, ea, eC_biased, p);
 }
 
 // One launch in front of a pass instead of up to four memsets: the rows (what = 1: every word, 2: the four

@@ -283,6 +283,16 @@ class VqSession:
         check(lib.e2vq_sweep_executed(self._h, C.byref(f), C.byref(j), C.byref(o), int(reset)))
         return f.value, j.value, o.value
 
+    def set_sweep_policy(self, two_stage_max_fraction=-1.0, max_uncertified_fraction=-1.0):
+        """The host's two kernel switches (results never change): see e2vq_set_sweep_policy; negative = leave as it is."""
+        check(lib.e2vq_set_sweep_policy(self._h, float(two_stage_max_fraction), float(max_uncertified_fraction)))
+
+    def sweep_policy_state(self):
+        """(one-stage sorted passes up to this M, plain sweep from this M on, uncertified frames of the last prefiltered pass)"""
+        a, b, u = C.c_int(), C.c_int(), C.c_int64()
+        check(lib.e2vq_sweep_policy_state(self._h, C.byref(a), C.byref(b), C.byref(u)))
+        return a.value, b.value, u.value
+
     def last_pass_info(self):
         """(prefiltered sweep used?, frames it left to the full FP64 sweep) of the last run_pass."""
         used, n = C.c_int(), C.c_int64()

@@ -195,6 +195,16 @@ int e2vq_last_pass_sweep(e2vq_session *s, int *kind, int *two_stage, double *fla
  * *flagged = those of them that also ran stage 2 with all k-steps, *one_stage_jobs = jobs of the passes that ran without a
  * coarse stage (all k-steps each).  Synchronises the stream; reset != 0 zeroes the counts. */
 int e2vq_sweep_executed(e2vq_session *s, int64_t *flagged, int64_t *jobs, int64_t *one_stage_jobs, int reset);
+/* The two switches the host makes from what a pass measured; both only choose kernels -- codebooks, symbols and statistics are
+ * the same bits either way.  two_stage_max_fraction: flagged share of a level's first sorted pass above which the rest of the
+ * level runs without the coarse stage.  max_uncertified_fraction: share of a pass's frames the prefiltered sweep may leave to
+ * the FP64 fallback sweep before the plain FP64 sweep takes over from that codebook size on (data whose distortions are small
+ * differences of large terms certify poorly).  Negative: unchanged.  Clears earlier decisions. */
+int e2vq_set_sweep_policy(e2vq_session *s, double two_stage_max_fraction, double max_uncertified_fraction);
+/* what the passes so far decided: sorted passes run one stage up to *one_stage_until_M (0: none); training passes run the plain
+ * sweep from *plain_from_M on (0: none); *uncertified = frames the last prefiltered pass left to the fallback sweep (-1: the
+ * last pass was not prefiltered).  Valid once e2vq_pass_stats has returned for the pass. */
+int e2vq_sweep_policy_state(e2vq_session *s, int *one_stage_until_M, int *plain_from_M, int64_t *uncertified);
 /* number of training-pass sweep launches so far, by kernel family (k_pass_pre / k_pass_mfma+generic): lets a
  * kernel trace of a whole run be cut to the dispatches of a timed region */
 int e2vq_sweep_launch_counts(e2vq_session *s, int64_t *prefiltered, int64_t *plain);

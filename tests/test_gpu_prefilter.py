@@ -271,8 +271,9 @@ def test_sorted_pass_big_codebooks(oracle, monkeypatch, accumulate, M, T):
             assert s.last_pass_info()[0]
             kind, _two, _frac = s.last_pass_sweep()
             # (the first pass -- frames not grouped -- runs the unfused chain, or round 4's kernel where the records of a full
-            # pass would not fit their bins: M = 8192; the incremental ones the fused kernel)
-            assert kind == 3 if it > 0 else kind in (1, 2), (it, kind)
+            # pass would not fit their bins: M = 8192; the incremental ones the fused kernel -- "auto": until its first sorted
+            # pass has found most tiles flagged, as a codebook drawn from the frames at random makes them, then round 4's kernel)
+            assert (kind == 3 or (accumulate == "auto" and it > 1 and kind == 1)) if it > 0 else kind in (1, 2), (it, kind)
             assert oracle_lib.rows_match(s.get_rows(), rows_o, P), f"pass {it}"
             refl, _failed = oracle.update(rows_o, P, sh_r, refl)
             s.update()
@@ -320,6 +321,27 @@ def test_two_stage_sweep_is_dropped_when_most_tiles_are_flagged(oracle, monkeypa
     assert all(k == 3 and not two for k, two, _f in seen[2:]), seen  # ... so the rest of the level runs one stage
     nblocks = (T + 63) // 64
     assert jobs == 2 * (M // 32) * nblocks and one_stage_jobs == 3 * jobs and flagged == round(seen[1][2] * jobs)
+    # the product's accumulate (no ECOZ2_VQ_ACCUMULATE): once the sorted pass has measured that most jobs are flagged, the rest of
+    # the level runs round 4's kernel -- frames in their natural order -- instead of a one-stage sorted pass; same bits
+    monkeypatch.delenv("ECOZ2_VQ_ACCUMULATE")
+    refl = _codebook(oracle, frames, M, seed=31)
+    seen = []
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.set_codebook(refl)
+        for it in range(4):
+            cq = oracle.reflections_to_cq(refl)
+            _sym_o, _dmin_o, rows_o = oracle.run_pass(cq, frames, sh_r, oracle.dist_exponent(cq, st.maxabs))
+            s.run_pass()
+            s.pass_stats()
+            seen.append(s.last_pass_sweep()[:2] + (s.sweep_policy_state()[0],))
+            assert oracle_lib.rows_match(s.get_rows(), rows_o, P), f"pass {it}"
+            refl, _failed = oracle.update(rows_o, P, sh_r, refl)
+            s.update()
+            assert np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64))
+    assert seen[1][:2] == (3, True) and seen[1][2] >= M and all(k == 1 for k, _two, _u in seen[2:]), seen
+    monkeypatch.setenv("ECOZ2_VQ_ACCUMULATE", "sorted")
     # the ladder's own codebook of the same size on the same frames: tree-ordered, two stages throughout
     with e.VqSession(P) as s:
         s.set_frames(frames)

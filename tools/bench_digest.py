@@ -52,14 +52,18 @@ def digest(cmd, path):
     rb = obj(c.get("robustness"))
     if isinstance(rb, dict):
         print(f"\n  robustness (M = {c.get('codebook_size')} level on {rb['frames']} frames; all equal the plain sweep: {rb['all_equal_plain_sweep']}; "
-              f"any slower than round 4's {rb['round4_kernel_ms_on_2p21_frames']} ms: {rb['any_slower_than_round4']}):")
+              f"worst product / fastest variant: {rb.get('worst_product_over_fastest')}):")
         for g in rb["generators"]:
             if "error" in g:
                 print(f"    {g['generator']:22s} ERROR {g['error']}")
                 continue
-            print(f"    {g['generator']:22s} r0 {g['mean_r0']:8.2f}  flagged(first pass) {g['flagged_fraction_first_pass']:.3f}  two stages kept {g['two_stage_kept']}  "
-                  f"kernel ms per pass {[round(p['kernel_ms'], 3) for p in g['per_pass']]} kinds {[(p['sweep_kind'], int(p['two_stage'])) for p in g['per_pass']]}  "
-                  f"equals plain {g['equals_plain_sweep']}")
+            print(f"    {g['generator']:22s} r0 {g['mean_r0']:8.2f}  flagged(first pass) {g['flagged_fraction_first_pass']}  equals plain {g['equals_plain_sweep']}  "
+                  f"step ms per pass {g['step_ms_per_pass']}  fastest {g['fastest']}  product/fastest {g['product_over_fastest']:.3f}  decided {g['product'].get('decided')}")
+            for k in ("product", "one_stage_after_first_pass", "sorted_one_stage", "sorted_two_stage", "round4_kernel", "plain_sweep"):
+                if k not in g:
+                    continue
+                v = g[k]
+                print(f"        {k:17s} kernel ms {v['kernel_ms']}  step ms {v['step_ms']}  {v['sweeps']}  uncertified {v['uncertified_fraction']}")
     qz = obj(c.get("quantize"))
     if isinstance(qz, dict):
         rq = qz["roofline_quantize"]

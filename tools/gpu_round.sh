@@ -24,6 +24,8 @@ for step in "$@"; do
              python tools/bench_digest.py "python bench.py $arg"=$OUT/${TAG}_bench.json | cut -c1-900 ;;
     flagged) timeout -k 10 600 python tools/probe/flagged_probe.py $arg > $OUT/${TAG}_flagged.txt 2>&1 || { tail -20 $OUT/${TAG}_flagged.txt; exit 1; }
              cut -c1-400 $OUT/${TAG}_flagged.txt ;;
+    fallback) timeout -k 10 600 python tools/probe/fallback_probe.py $arg > $OUT/${TAG}_fallback.txt 2>&1 || { tail -20 $OUT/${TAG}_fallback.txt; exit 1; }
+             cut -c1-400 $OUT/${TAG}_fallback.txt ;;
     stamps)  ECOZ2VQ_LIB=tools/probe/ab/stamp/libecoz2vq.so timeout -k 10 400 python tools/probe/sweep_stamps.py > $OUT/${TAG}_stamps.txt 2>&1 || { tail -20 $OUT/${TAG}_stamps.txt; exit 1; }
              grep -v "pass 1" $OUT/${TAG}_stamps.txt | cut -c1-420 ;;
     exp)     EXP_MODES=${arg:-0,1,2,3,0} ECOZ2VQ_LIB=tools/probe/ab/stamp/libecoz2vq.so timeout -k 10 400 python tools/probe/sweep_exp.py > $OUT/${TAG}_exp.txt 2>&1 || { tail -20 $OUT/${TAG}_exp.txt; exit 1; }
