@@ -131,7 +131,8 @@ void launch_prefilter_quantize_scales(const double* cbq, int M, int NC, int* ea,
 int launch_pass_fallback(int NC, bool accumulate, const double* blk, const double* cbm, int M, const DevScalars* sc,
                          const unsigned long long* l1max_bits, unsigned short* sym, double* dmin, long long* rows,
                          const int* fb_list, const int* fb_count, unsigned short* prev_sym, int incremental,
-                         hipStream_t s, bool rowmajor = false, unsigned short* cells_out = nullptr);
+                         hipStream_t s, bool rowmajor = false, unsigned short* cells_out = nullptr, bool long_list = false);
+// (long_list: the caller expects tens of per cent of the frames on the list -- the sweep then runs in the plain pass's shape)
 // (cells_out: where the listed frames' new cells are recorded -- default: in place, prev_sym)
 // the seeded first pass after a split (vq_update.hip: k_seed_family): rows <- parents' sums in the even children, X <- 0;
 // after the pass (and its fallback sweep) launch_family_fixup moves the in-family arrivals X[i] from row 2 i to row 2 i + 1

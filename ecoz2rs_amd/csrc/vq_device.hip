@@ -210,6 +210,10 @@ __global__ void k_blockify_mfma(const double* __restrict__ aos, long T, int NC, 
 // with coalesced 16-B loads and picks its B operands from there, so no re-layout pass is needed.
 // SRC = 2 (fallback of the prefiltered pass): the frames are those listed in fb_list[0 .. *fb_count), read from the
 // blocked layout one coefficient at a time; T and nblocks come from the device-side count.
+// SRC = 3 (round 6): the same list swept like the plain pass -- four frame tiles per wave, every wave the whole codebook --
+// for data on which the list is LONG (tens of per cent of the frames: distortions that are small differences of large terms
+// certify poorly): the short-list kernel loads every codeword tile for 16 frames and ran at 0.6 of the plain
+// sweep's rate per frame there.
 template <int NC, int MODE, int TPBM, int SRC = 0>
 __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict__ blk, long T, long nblocks,
                                                        const double* __restrict__ cbm, int MT, int M,
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
                                                        int list_rowmajor = 0, unsigned short* cells_out = nullptr)
 {
     constexpr bool AOS = SRC == 1;
+    constexpr bool LIST = SRC == 2 || SRC == 3;
     // frame tiles (of 16) per wave: the fallback list is short, so its waves take one tile each -- four times as
     // many waves, each a quarter of the latency of a full 64-frame sweep.  Prediction orders 41 .. 80 (round 4): two
     // tiles -- a wave takes one 32-frame half of a block, whose operands (up to 88 registers) fit beside two sets of
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
     // ... and the waves of a workgroup split the codebook of ONE tile between them (the list is latency-bound: a
     // single wave walking all M / 16 codeword tiles takes ~50 us at M = 1024), then combine through LDS
     constexpr int SPLIT = SRC == 2 ? TPBM / 64 : 1;
-    if constexpr (SRC == 2) {
+    if constexpr (LIST) {
         T = *fb_count;
         nblocks = (T + FPB - 1) / FPB;
     }
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-        } else if constexpr (SRC == 2) {
+        } else if constexpr (LIST) {
 #pragma unroll
             for (int ft = NFT; ft < 4; ++ft)
 #pragma unroll
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
             const int is = q == 0 ? idx[0] : q == 1 ? idx[1] : q == 2 ? idx[2] : idx[3];
             long t = b * FPB + lane;
             const bool live = t < T && lane < FPB;
-            if constexpr (SRC == 2) t = live ? fb_list[t] : 0;
+            if constexpr (LIST) t = live ? fb_list[t] : 0;
             if (live) {
                 if (sym) sym[t] = (unsigned short)is;
                 if (dmin) dmin[t] = bs;
@@ -489,21 +494,28 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_mfma(const double* __restrict_
 
         E2VQ_MSTAMP(2)  // combine, prefetch request, outputs
         // ---- accumulate: int32 row images [frame][2n+limb | count, d, d2] -> exact 64-bit adds ----
-        if constexpr (MODE == 2 && SRC == 2) {
+        if constexpr (MODE == 2 && LIST) {
             // fallback of a prefiltered pass: incremental like the pass it completes (vq_accum.h)
-            const long slot = b * FPB + j;
-            const long t = slot < T ? fb_list[slot] : -1;
             // (incr == 2: the first pass after a split, rows seeded with the parents' sums -- the frame counts as sitting
             // in the even child of its old cell; see k_seed_family)
-            const int oldidx[4] = {(incr && t >= 0) ? (incr == 2 ? 2 : 1) * (int)prev_sym[t] : 0, 0, 0, 0};
+            int oldidx[4] = {0, 0, 0, 0};
+            long tq = -1;  // the listed frame of THIS lane's slot b * FPB + lane (frame tile q, column j)
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) {
+                const long slot = b * FPB + 16 * ft + j;
+                const long t = slot < T ? fb_list[slot] : -1;
+                oldidx[ft] = (incr && t >= 0) ? (incr == 2 ? 2 : 1) * (int)prev_sym[t] : 0;
+                if (NFT == 1 || ft == q) tq = t;
+            }
             accumulate_block<NC, MODE, false, NFT, true>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2, b, T,
                                                          lane, {false, false, false, false}, incr != 0, oldidx);
             // (the new cell goes to cells_out when the caller keeps two cell arrays and swaps them: k_accum_ranges)
-            if (q == 0 && t >= 0) {
+            const int newc = NFT == 1 ? idx[0] : (q == 0 ? idx[0] : q == 1 ? idx[1] : q == 2 ? idx[2] : idx[3]);
+            if ((NFT > 1 || q == 0) && tq >= 0) {
                 if (cells_out)
-                    cells_out[t] = (unsigned short)idx[0];
+                    cells_out[tq] = (unsigned short)newc;
                 else if (prev_sym)
-                    prev_sym[t] = (unsigned short)idx[0];
+                    prev_sym[tq] = (unsigned short)newc;
             }
         } else if constexpr (MODE != 0)
             accumulate_block<NC, MODE, false, NFT>(Bf, best, idx, img, lacc, rows, lds_cells, sh_r, sh_d, sh_d2, b, T, lane,
@@ -1033,9 +1045,31 @@ int launch_pass(int NC, int mode, const double* blk, long T, long nblocks, const
 int launch_pass_fallback(int NC, bool accumulate, const double* blk, const double* cbm, int M, const DevScalars* sc,
                          const u64* l1max_bits, unsigned short* sym, double* dmin, i64* rows, const int* fb_list,
                          const int* fb_count, unsigned short* prev_sym, int incremental, hipStream_t s, bool rowmajor,
-                         unsigned short* cells_out)
+                         unsigned short* cells_out, bool long_list)
 {
     const int MT = (M + 15) / 16;
+    if (long_list && !mfma_is_wide(NC)) {
+        // round 6: the list is expected to be long (the caller saw the count of the pass before): four frame tiles per wave,
+        // every wave the whole codebook -- the plain sweep's shape and rate
+        switch (NC) {
+#define X(N)                                                                                                           \
+    case N: {                                                                                                          \
+        const size_t lds = (size_t)8 * 16 * (2 * N + 5 + IMG_STRIDE_PAD) * 4;                                          \
+        if (accumulate)                                                                                                \
+            hipLaunchKernelGGL((k_pass_mfma<N, 2, 512, 3>), dim3(256), dim3(512), lds, s, blk, 0L, 0L, cbm, MT, M, sc,  \
+                               l1max_bits, sym, dmin, rows, 0, fb_list, fb_count, prev_sym, incremental,              \
+                               rowmajor ? 1 : 0, cells_out);                                                           \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_pass_mfma<N, 0, 512, 3>), dim3(256), dim3(512), lds, s, blk, 0L, 0L, cbm, MT, M, sc,  \
+                               l1max_bits, sym, dmin, rows, 0, fb_list, fb_count, (unsigned short*)nullptr, 0,          \
+                               rowmajor ? 1 : 0);                                                                      \
+        return 0;                                                                                                      \
+    }
+            E2VQ_PRE_NC_LIST(X)
+#undef X
+            default: break;
+        }
+    }
     switch (NC) {
 #define X(N)                                                                                                           \
     case N: {                                                                                                          \

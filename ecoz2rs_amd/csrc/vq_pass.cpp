@@ -197,6 +197,9 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
     const bool record_cells = !s->last_prefiltered && mode != 0 && s->fam_enabled && s->pre_enabled &&
                               s->d_prev_sym && s->d_aos && !device_sym && 2 * s->M >= s->pre_min_M &&
                               e2vq::prefilter_supports(s->NC, 2 * s->M);
+    // (the FP64 sweep of the uncertified frames: in the plain pass's shape when the pass before left more than 2 % of the
+    // frames to it -- the list's length is not known on the host when the kernels are enqueued, the last one's is)
+    const bool long_list = s->last_fb >= 0 && (double)s->last_fb > 0.02 * (double)s->T;
     if (s->last_prefiltered) {
         // f16 limb image of the current codebook, prefiltered sweep (exact evaluation of the certified top two),
         // then the full FP64 sweep of whatever it could not certify
@@ -254,7 +257,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             }
             e2vq::launch_pass_fallback(s->NC, true, s->d_blk, s->d_cbm, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                                        (double*)device_dmin, rows, s->d_fblist, e2vq::prefilter_fallback_count(d_ps), s->d_prev_sym,
-                                       incr, s->stream);
+                                       incr, s->stream, false, nullptr, long_list);
             if (family) e2vq::launch_family_fixup(rows, s->d_fam, s->fam_M, s->NC, s->stream);
         } else if (records && s->sweep2_enabled && s->d_fimgF && s->M >= s->sweep_min_M && e2vq::sweep_supported(s->NC, s->M) &&
                    (two_ok || s->two_blocks_always || !s->fused_enabled || !(family || incremental))) {
@@ -300,7 +303,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
             }
             e2vq::launch_pass_fallback(s->NC, true, s->d_blk, s->d_cbm, s->M, s->d_sc, s->d_l1max, (unsigned short*)device_sym,
                                        (double*)device_dmin, rows, s->d_fblist, e2vq::prefilter_fallback_count(d_ps), s->d_prev_sym,
-                                       incr, s->stream);
+                                       incr, s->stream, false, nullptr, long_list);
             if (family) e2vq::launch_family_fixup(rows, s->d_fam, s->fam_M, s->NC, s->stream);
         } else {
             if (e2vq::launch_pass_prefiltered(s->NC, mode != 0, s->d_blk, s->T, s->nblocks, s->d_fimg, s->d_fg, d_cimg, d_ps,
@@ -324,7 +327,7 @@ extern "C" int e2vq_pass(e2vq_session* s, void* device_sym, void* device_dmin)
         e2vq::launch_pass_fallback(s->NC, mode != 0, s->d_blk, s->d_cbm, s->M, s->d_sc, s->d_l1max,
                                    (unsigned short*)device_sym, (double*)device_dmin, rows, s->d_fblist,
                                    e2vq::prefilter_fallback_count(d_ps), keep ? s->d_prev_sym : nullptr,
-                                   family ? 2 : (incremental ? 1 : 0), s->stream);
+                                   family ? 2 : (incremental ? 1 : 0), s->stream, false, nullptr, long_list);
         if (family) e2vq::launch_family_fixup(rows, s->d_fam, s->fam_M, s->NC, s->stream);
         }
     } else {

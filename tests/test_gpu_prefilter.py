@@ -357,6 +357,58 @@ def test_two_stage_sweep_is_dropped_when_most_tiles_are_flagged(oracle, monkeypa
             s.update()
 
 
+@pytest.mark.parametrize("T", [20011, 65536])
+def test_long_fallback_lists_take_the_wide_sweep(oracle, monkeypatch, T):
+    """Data shaped like the reference's own corpus (r[0] = 1 / E about 2-3, no classes: e2vq_synth_frames_kind 1): the
+    distortions are small differences of large terms and the three-limb keys leave 5-30 % of the frames uncertified.  From
+    the second prefiltered pass on the host knows that and enqueues the FP64 fallback sweep in the plain pass's shape
+    (k_pass_mfma<.., SRC = 3>: four frame tiles per wave); seeded and incremental passes, symbols, distortions, rows and
+    codebooks against the oracle, then the whole ladder against oracle.learn."""
+    frames = e.synth.synth_frames_kind(20281, 1, 6, 0.01, P, 0, T)
+    rc, st = oracle.data_stats(frames)
+    sh_r, _ = oracle.shifts(st.maxabs)
+    sym, dmin = _DeviceBuffer(2 * T), _DeviceBuffer(8 * T)
+    shares = []
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        s.set_sweep_policy(-1.0, 1.0)  # (never the plain sweep: the prefiltered pass and its fallback are what is tested)
+        s.learn(0.05, 128)
+        for M in (256, 512):
+            s.grow()
+            refl = s.get_codebook()
+            for it in range(3):
+                cq = oracle.reflections_to_cq(refl)
+                sym_o, dmin_o, rows_o = oracle.run_pass(cq, frames, sh_r, oracle.dist_exponent(cq, st.maxabs))
+                s.run_pass(sym.ptr.value, dmin.ptr.value)
+                s.pass_stats()
+                assert s.last_pass_info()[0]
+                shares.append(s.sweep_policy_state()[2] / T)
+                assert np.array_equal(sym.to_host(np.uint16), sym_o), (M, it)
+                assert np.array_equal(dmin.to_host(np.uint64), dmin_o.view(np.uint64)), (M, it)
+                assert oracle_lib.rows_match(s.get_rows(), rows_o, P), (M, it)
+                refl, _failed = oracle.update(rows_o, P, sh_r, refl)
+                s.update()
+                assert np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64))
+    sym.free()
+    dmin.free()
+    # (a pass behind one that left more than 2 % of the frames uncertified enqueues the wide sweep: that happened)
+    assert any(x > 0.02 for x in shares[:-1]), shares
+    # the whole ladder, switches at their defaults (the plain sweep may take over where more than 40 % stay uncertified)
+    rc, levels_o, cbs_o = oracle.learn(frames, 0.05, 1024)
+    assert rc == 0
+    cbs = []
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.init_codebook()
+        levels = s.learn(0.05, 1024, callback=lambda *a: cbs.append(a))
+        refl = s.get_codebook()
+    assert [l.passes for l in levels] == [lv["passes"] for lv in levels_o] and cbs == cbs_o
+    assert np.array_equal(refl.view(np.uint64), levels_o[-1]["reflections"].view(np.uint64))
+
+
 @pytest.mark.parametrize("few_div,expect", [("0", [True] * 5), ("1", [True, False, False, False, False])])
 def test_few_records_switch_the_level_to_the_burst(oracle, monkeypatch, few_div, expect):
     """k_reduce_records publishes the pass's record count; below frames / ECOZ2_VQ_RECORDS_FEW_DIV the rest of the level adds
