@@ -715,7 +715,8 @@ int e2vq_pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_faile
         if (jobs && s->last_flagged_frac > s->two_stage_max_frac) s->two_stage_off_until_M = s->M;
         // (nearly every job flagged: the next size will not look different -- its first pass is not spent on finding out; the
         // size after that tries again)
-        if (jobs && s->last_flagged_frac > 0.8 && s->last_flagged_frac > s->two_stage_max_frac) s->two_stage_off_until_M = 2 * s->M;
+        if (jobs && s->last_flagged_frac > 0.8 && s->last_flagged_frac > s->two_stage_max_frac)
+            s->two_stage_off_until_M = (s->last_flagged_frac > 0.98 ? 4 : 2) * s->M;
     }
     i64 l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int slot = 0; slot < 64; ++slot)

@@ -213,6 +213,14 @@ __device__ __forceinline__ void pre_epilogue_slice(const f16v (&PREV)[3], int pt
         k1 = med3f(k1, key, ninf);
     }
 }
+// A lower bound of a frame's FOURTH-smallest key from the three smallest each lane half kept for it (a1 <= a2 <= a3 of the one
+// half's codewords, b1 <= b2 <= b3 of the other's): every key a half did not keep is >= its third, so the fourth smallest of
+// all is at least the fourth smallest of {a1, a2, a3, a3, b1, b2, b3, b3} = min_i max(A_i, B_(4-i)) = min(a3, b3, max(a2, b2)).
+// (The three smallest of all are exact: a key that was not kept has three kept ones of its own half below it.)
+__device__ __forceinline__ float pre_fourth_bound(float a2, float a3, float b2, float b3)
+{
+    return __builtin_fminf(__builtin_fminf(a3, b3), __builtin_fmaxf(a2, b2));
+}
 // the whole epilogue of a job at once (behind the last tile of a block)
 template <int NC>
 __device__ __forceinline__ void pre_epilogue(const f16v (&PREV)[3], int ptile, float& k1, float& k2, float& k3, int maskv, float ninf)

@@ -292,8 +292,8 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 
         E2VQ_STAMP(1)  // tile loop
         // ---- per frame: merge the two lane halves (rows 4h..4h+3 of every 8), certify the top two -------------
-        int c1[2], c2[2];
-        bool cert[2], amb[2];
+        int c1[2], c2[2], c3[2];
+        bool cert[2], amb[2], amb3[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             const int hb = (lane >> 5) << 2;
@@ -311,6 +311,12 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             amb[cb] = !(u2 > t1 + tau);  // the runner-up is within reach: it needs the exact evaluation too
             c1[cb] = __float_as_int(t1) & ~idxmask;
             c2[cb] = __float_as_int(u2) & ~idxmask;
+            // round 6 (fused quantize): where the third key is within reach too, the top THREE are evaluated if every other
+            // codeword is out of reach -- pre_fourth_bound: a lower bound of the frame's fourth-smallest key from what the two
+            // lane halves kept.  (The same argument as for two: a codeword whose key exceeds t1 + tau cannot be the nearest.)
+            c3[cb] = __float_as_int(w3) & ~idxmask;
+            amb3[cb] = QF && !cert[cb] && t1 >= 1.0e-30f && t1 < 1.0e37f && pre_fourth_bound(a2, a3, b2, b3) > t1 + tau;
+            if (QF) cert[cb] = cert[cb] || amb3[cb];
         }
 
         if constexpr (QF) {
@@ -346,13 +352,32 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             }
             // (a runner-up whose key is out of reach cannot win: comparing it anyway changes nothing)
             const bool take_b = d2 < d1 || (d2 == d1 && cb2 < ca);
+            double bestq = take_b ? d2 : d1;
+            int idxq = take_b ? cb2 : ca;
+            const bool third = hsel ? amb3[1] : amb3[0];
+            if (__ballot(third) != 0) {  // (wave-uniform; rare on data that certifies well)
+                const int cc = hsel ? c3[1] : c3[0];
+                const double2* r3 = (const double2*)(cbq + (long)cc * NPADQ);
+#pragma unroll
+                for (int n2 = 0; n2 < NH; ++n2) y[n2] = third ? r3[n2] : make_double2(0.0, 0.0);
+                double d3 = 0.0;
+#pragma unroll
+                for (int n2 = 0; n2 < NH; ++n2) {
+                    if ((n2 & 3) == 0) asm volatile("" ::: "memory");
+                    d3 = __builtin_fma(fr[2 * n2], y[n2].x, d3);
+                    if (2 * n2 + 1 < NC) d3 = __builtin_fma(fr[2 * n2 + 1], y[n2].y, d3);
+                }
+                const bool take_c = third && (d3 < bestq || (d3 == bestq && cc < idxq));
+                bestq = take_c ? d3 : bestq;
+                idxq = take_c ? cc : idxq;
+            }
             const long t = b * 64 + lane;
             if (t < T) {
                 if (!certl) {
                     fb_list[atomicAdd(&ps->fb_count, 1)] = (int)t;
                 } else {
-                    if (sym) sym[t] = (unsigned short)(take_b ? cb2 : ca);
-                    if (dmin) dmin[t] = take_b ? d2 : d1;
+                    if (sym) sym[t] = (unsigned short)idxq;
+                    if (dmin) dmin[t] = bestq;
                 }
             }
             // (the next block's LDS-DMA overwrites the stage: this block's reads are complete first)
@@ -653,9 +678,16 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         const bool live = t < T;
         const float g = live ? fgs[ln] : 0.f;
         const float tau = 1.27f * (512.f * (g + ymax1 + (NC + 4.0f)) + relk * t1);
-        const bool cert = t1 >= 1.0e-30f && t1 < 1.0e37f && w3 > t1 + tau;
+        const bool keyok = t1 >= 1.0e-30f && t1 < 1.0e37f;
+        const bool cert2 = keyok && w3 > t1 + tau;
         const bool amb = !(u2 > t1 + tau);  // the runner-up is within reach: it needs the exact evaluation too
-        const int c1 = __float_as_int(t1) & ~idxmask, c2 = __float_as_int(u2) & ~idxmask;
+        // round 6: the third key within reach as well -- the top THREE are evaluated exactly where every other codeword is out
+        // of reach (pre_fourth_bound: a lower bound of the frame's fourth-smallest key from what the two lane halves kept; the
+        // argument is the one for two candidates).  On data whose distortions are small differences of large terms this
+        // certifies about half of the frames two candidates leave to the FP64 fallback sweep.
+        const bool amb3 = !cert2 && keyok && pre_fourth_bound(a2, a3, b2, b3) > t1 + tau;
+        const bool cert = cert2 || amb3;
+        const int c1 = __float_as_int(t1) & ~idxmask, c2 = __float_as_int(u2) & ~idxmask, c3 = __float_as_int(w3) & ~idxmask;
         const int old = (ACCUM && incr) ? (incr == 2 ? 2 : 1) * (int)prevs[ln] : 0;
         E2VQ_STAMP(2)  // merge, certification
 
@@ -695,6 +727,21 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
             const bool take_b = amb && (d2 < d1 || (d2 == d1 && c2 < c1));
             best = take_b ? d2 : d1;
             idx = take_b ? c2 : c1;
+            if (__ballot(amb3) != 0) {  // (wave-uniform; the third candidate's row takes the runner-up's registers)
+                const double2* r3 = (const double2*)(cbq + (long)c3 * NPAD);
+#pragma unroll
+                for (int n2 = 0; n2 < NH; ++n2) y[n2] = amb3 ? r3[n2] : make_double2(0.0, 0.0);
+                double d3 = 0.0;
+#pragma unroll
+                for (int n2 = 0; n2 < NH; ++n2) {
+                    if ((n2 & 3) == 0) asm volatile("" ::: "memory");
+                    d3 = __builtin_fma(fr[2 * n2], y[n2].x, d3);
+                    if (2 * n2 + 1 < NC) d3 = __builtin_fma(fr[2 * n2 + 1], y[n2].y, d3);
+                }
+                const bool take_c = amb3 && (d3 < best || (d3 == best && c3 < idx));
+                best = take_c ? d3 : best;
+                idx = take_c ? c3 : idx;
+            }
         }
         const bool skip = !cert;
         idx = skip ? 0 : idx;
