@@ -32,6 +32,12 @@ for step in "$@"; do
              cut -c1-330 $OUT/${TAG}_exp.txt ;;
     profiles) IFS=: read -r ptag pargs <<< "$arg"
              ECOZ2_BENCH_SKIP_SMALL=1 ECOZ2_BENCH_SKIP_ROBUSTNESS=1 bash tools/profile_bench.sh ${ptag:-$TAG} $pargs || exit 1 ;;
+    quantprof) QT=${arg:-r06q}; ( cd /tmp && export TMPDIR=/tmp && R=$OLDPWD && Q="python3 $R/tools/quantize_profile.py" &&
+               rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/${QT}_kt" -- $Q > "$R/$OUT/${QT}_kt.json" 2> "$R/$OUT/${QT}_kt.err" && echo "kernel trace done" &&
+               rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/$OUT/${QT}_fetch" -- $Q 10000000 3 > "$R/$OUT/${QT}_fetch.json" 2> "$R/$OUT/${QT}_fetch.err" && echo "fetch done" &&
+               rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$R/$OUT/${QT}_write" -- $Q 10000000 3 > "$R/$OUT/${QT}_write.json" 2> "$R/$OUT/${QT}_write.err" && echo "write done" &&
+               rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d "$R/$OUT/${QT}_sq1" -- $Q 10000000 3 > "$R/$OUT/${QT}_sq1.json" 2> "$R/$OUT/${QT}_sq1.err" && echo "sq1 done" &&
+               rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d "$R/$OUT/${QT}_sq2" -- $Q 10000000 3 > "$R/$OUT/${QT}_sq2.json" 2> "$R/$OUT/${QT}_sq2.err" && echo "sq2 done" ) || { tail -5 $OUT/${QT}_*.err; exit 1; } ;;
     ab)      for v in ${arg//:/ }; do
                if [ "$v" = base ]; then unset ECOZ2VQ_LIB; else export ECOZ2VQ_LIB=$PWD/tools/probe/ab/$v/libecoz2vq.so; fi
                ECOZ2_BENCH_SKIP_SMALL=1 ECOZ2_BENCH_SKIP_ROBUSTNESS=1 timeout -k 10 600 python bench.py --no-cpu-baseline > $OUT/${TAG}_ab_$v.json 2> $OUT/${TAG}_ab_$v.err || { tail -20 $OUT/${TAG}_ab_$v.err; exit 1; }

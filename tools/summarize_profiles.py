@@ -118,10 +118,8 @@ def main():
         "note": f"timed region = {len(d) // L} repetitions of the real M={M} level ({L} passes: the first seeded with the parents' sums, "
                 "the others incremental); bench.py's HIP-event average over the same launches is bench_kernel_ms",
         "bench_kernel_ms": b["roofline"]["kernel_ms"], "bench_ms_per_step": b["ms_per_step"], "bench_value": b["value"],
-        # (rocprofv3 reports the architectural and the accumulation registers separately; the wave's allocation -- what
-        # bounds the occupancy: 512 per SIMD lane -- is their sum)
-        "arch_vgpr": rows[0].get("VGPR_Count"), "accum_vgpr": rows[0].get("Accum_VGPR_Count"),
-        "unified_vgpr": (int(rows[0].get("VGPR_Count") or 0) + int(rows[0].get("Accum_VGPR_Count") or 0)) or None,
+        # (no register counts here: rocprofv3's VGPR_Count column is not the wave's allocation on gfx950 -- it printed 128 for a
+        # kernel whose descriptor says 256; tests/test_isa_guards.py reads the counts from the compiled ISA and pins them)
         "frames_per_launch": T,
         "lds_bytes": rows[0].get("LDS_Block_Size"), "grid": rows[0].get("Grid_Size"), "workgroup": rows[0].get("Workgroup_Size"),
         "kernel_sources_sha16": kernel_sources_sha16(),
