@@ -135,8 +135,14 @@ def fuzz_prefilter(n, rng, oracle):
         # same without the fused pass, 2 round 4's fused kernel with recorded contributions, 3 the same with its burst of atomics
         acc = int(rng.integers(0, 4))
         os.environ["ECOZ2_VQ_ACCUMULATE"] = ("sorted", "sweep", "records", "burst")[acc]
+        # (round 6) the host's switches: three cases in four pin the prefiltered kernels (never the plain sweep, whatever share of
+        # the frames stays uncertified on these adversarial codebooks); one in four runs the product's defaults, where the
+        # plain sweep may take over -- the results have to be the same bits either way
+        pinned = rng.random() < 0.75
         with e.VqSession(P) as s:
             s.set_frames(frames); s.prepare(); s.set_codebook(refl)
+            if pinned:
+                s.set_sweep_policy(-1.0, 1.0)
             for it in range(3):
                 cq = oracle.reflections_to_cq(refl)
                 Ed = oracle.dist_exponent(cq, st.maxabs)
@@ -147,7 +153,7 @@ def fuzz_prefilter(n, rng, oracle):
                 fallback += nfb; frames_total += T
                 # (P = 40 without records: rows of 83 elements, which the burst of atomics cannot add -- the plain sweep serves)
                 expect_used = not (P == 40 and acc == 3)
-                good = (used == expect_used and oracle_lib.rows_match(rows, rows_o, P) and ls.DD == ls_o.DD and ls.sigma == ls_o.sigma
+                good = ((used == expect_used or not pinned) and oracle_lib.rows_match(rows, rows_o, P) and ls.DD == ls_o.DD and ls.sigma == ls_o.sigma
                         and ls.inertia == ls_o.inertia
                         and np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64)))
                 if not good:
