@@ -208,7 +208,10 @@ __device__ unsigned long long g_pre_stamps[32];
 // straight from L2 (9 KB per 32 codewords at NC = 37; 16 B per lane and granule) -- measured as fast as a workgroup-shared
 // LDS ring (tools/probe/pre_sweep.hip -DDIRECT_L2), and it lets the two waves of a SIMD drift apart so that one sweeps
 // (matrix pipe) while the other is in its latency-bound evaluate / accumulate phase.
-template <int NC, int MODE, int TPBM>
+// ROT (round 6, fused quantize): a rotating tile loop -- the next tile requested granule by granule behind the current tile's last
+// readers (inline asm, hand-placed waits: pre_job) -- in place of a loop that loads a tile and uses it at once (every tile's L2
+// latency exposed but for the SIMD's other wave).  Needs at least two tiles.
+template <int NC, int MODE, int TPBM, bool ROT = false>
 __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__ blk, long T, long nblocks,
                                                   const h8* __restrict__ fimg, const float* __restrict__ fg,
                                                   const h8* __restrict__ cimg, PreScalars* __restrict__ ps,
@@ -229,8 +232,8 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
     E2VQ_STAMP_DECL
     constexpr int NS = (NC + 3) / 4, NP = (NS + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int q = lane >> 4, j = lane & 15;
+    // (the wave's index as a scalar: block numbers and the LDS stage stay in SGPRs -- the rotating loop has no VGPR to spare)
+    const int lane0 = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long wave = (long)blockIdx.x * (TPBM >> 6) + wib;
     const long nwaves = (long)gridDim.x * (TPBM >> 6);
     double* stage = (double*)smem + wib * (64 * NC);                       // QF: the wave's 64 row-major FP64 frames
@@ -249,18 +252,23 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
     float ninf = -__builtin_inff();
     asm volatile("" : "+v"(ninf));
     const float ymax1 = __int_as_float(ps->ymax_bits);
-    const float relk = 2.0f / (float)(1u << (22 - __builtin_popcount(~idxmask)));  // 2 rho, rho = 2^-(22-idxbits)
+    // 2 rho, rho = 2^-(22-idxbits): put together from its bit pattern, so that it stays in a scalar register (as a float
+    // division it lived in a VGPR across the tile loop)
+    const float relk = __int_as_float((127 + __builtin_popcount(~idxmask) - 21) << 23);
 
     // Waves w and w + 4 of an 8-wave workgroup share a SIMD.  Started together they would reach their evaluate /
     // accumulate phases together; half a block period of delay for waves 4..7 makes the phases alternate.
     if (stagger && TPBM == 512 && nblocks >= 2 * nwaves && wib >= 4)
         for (int i = 0; i < stagger * MT / 8; ++i) __builtin_amdgcn_s_sleep(127);  // ~8k cycles each; a tile ~2k
 
+    (void)lane0;
     for (long b = wave; b < nblocks; b += nwaves) {
         E2VQ_STAMP_START
         // ---- f16 limb images of the wave's 64 frames: B operands, resident for the sweep ----------
         h8 B[2][PK::PAIRS];
         float gq[2] = {0.f, 0.f};
+        // (ROT: the lane index afresh in front of and behind the tile loop, so that nothing derived from it lives across it)
+        int lane = ROT ? pre_fresh_lane() : lane0;
         if constexpr (QF) {
             pre_build_block<NC>(aos, b, T, lane, stage, eas, B, gq);
         } else {
@@ -280,15 +288,40 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[l][r] = l == 2 ? 3.0e38f : 0.f;
 
-        for (int t = 0; t < MT; ++t) {
-            h8 A[PK::NU];
+        if constexpr (ROT) {
+            static_assert(MODE == 6, "the rotating loop serves the fused quantize");
+            constexpr int NU = PK::NU;
+            constexpr unsigned TILE_IMG = (unsigned)PK::TILE_E * 16u;
+            const char* cimg_c = (const char*)cimg;
+            const unsigned lo_t = (unsigned)pre_fresh_lane() * 16u;
+            // ONE register set (two made this kernel spill -- 36 registers, with scratch reloads inside a loop whose waits count
+            // the vector-memory operations in flight: not an option): job 1 of tile t is the last reader of the set; behind the
+            // last use of each granule it requests the same granule of tile t + 1 (inline asm), and job 0 of tile t + 1 waits
+            // for each in front of its first use with s_waitcnt vmcnt(NU - 1 - rank).  Half a tile of MFMAs (and the partner
+            // wave's) lies between a request and its use, where the plain loop had none.
+            h8 A[NU];
+            pre_load_tile_asm<NC>(A, cimg_c, lo_t);  // tile 0: one exposed L2 latency per block
+            pre_job<NC, 0, false>(acc0, B[0], A, acc1, 0xffff, k1[1], k2[1], k3[1], maskv, ninf, nullptr, 0u);
+            pre_job<NC, 0, true>(acc1, B[1], A, acc0, 0, k1[0], k2[0], k3[0], maskv, ninf, cimg_c + TILE_IMG, lo_t);
+            for (int t = 1; t < MT - 1; ++t) {
+                pre_job<NC, NU, false>(acc0, B[0], A, acc1, t - 1, k1[1], k2[1], k3[1], maskv, ninf, nullptr, 0u);
+                pre_job<NC, 0, true>(acc1, B[1], A, acc0, t, k1[0], k2[0], k3[0], maskv, ninf, cimg_c + (size_t)(t + 1) * TILE_IMG, lo_t);
+            }
+            pre_job<NC, NU, false>(acc0, B[0], A, acc1, MT - 2, k1[1], k2[1], k3[1], maskv, ninf, nullptr, 0u);
+            pre_job<NC, 0, false>(acc1, B[1], A, acc0, MT - 1, k1[0], k2[0], k3[0], maskv, ninf, nullptr, 0u);
+        } else {
+            for (int t = 0; t < MT; ++t) {
+                h8 A[PK::NU];
 #pragma unroll
-            for (int u = 0; u < PK::NU; ++u) A[u] = cimg[(long)t * PK::TILE_E + u * 64 + lane];
-            // (t = 0: the "previous" accumulators hold 3e38)
-            pre_job_pinned<NC>(acc0, B[0], A, acc1, (t - 1) & 0xffff, k1[1], k2[1], k3[1], maskv, ninf);
-            pre_job_pinned<NC>(acc1, B[1], A, acc0, t, k1[0], k2[0], k3[0], maskv, ninf);
+                for (int u = 0; u < PK::NU; ++u) A[u] = cimg[(long)t * PK::TILE_E + u * 64 + lane];
+                // (t = 0: the "previous" accumulators hold 3e38)
+                pre_job_pinned<NC>(acc0, B[0], A, acc1, (t - 1) & 0xffff, k1[1], k2[1], k3[1], maskv, ninf);
+                pre_job_pinned<NC>(acc1, B[1], A, acc0, t, k1[0], k2[0], k3[0], maskv, ninf);
+            }
         }
         pre_epilogue<NC>(acc1, MT - 1, k1[1], k2[1], k3[1], maskv, ninf);
+        if constexpr (ROT) lane = pre_fresh_lane();
+        const int q = lane >> 4, j = lane & 15;
 
         E2VQ_STAMP(1)  // tile loop
         // ---- per frame: merge the two lane halves (rows 4h..4h+3 of every 8), certify the top two -------------
@@ -1351,12 +1384,22 @@ static int launch_pass_prefiltered_t(bool accumulate, const double* blk, long T,
         if constexpr (fused_quantize_fits(NC)) {
             constexpr int QT = fused_quantize_waves(NC) * 64;
             const size_t lds6 = (size_t)(QT / 64) * 64 * NC * 8 + (size_t)NC * sizeof(int);
-            (void)hipFuncSetAttribute((const void*)k_pass_pre<NC, 6, QT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      E2VQ_LDS_BYTES);
-            hipLaunchKernelGGL((k_pass_pre<NC, 6, QT>), dim3(pre_grid(nblocks, QT / 64, 256)), dim3(QT), lds6, s, (const double*)nullptr, T, nblocks,
-                               (const h8*)nullptr, (const float*)nullptr, (const h8*)cimg, (PreScalars*)ps, cbq, M / 32,
-                               idxmask, sc, (const u64*)l1max_bits, sym, dmin, rows, fb_list, stagger, prev_sym, 0, aos,
-                               ea_fused);
+            auto goq = [&](auto kernel) {
+                (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E2VQ_LDS_BYTES);
+                hipLaunchKernelGGL(kernel, dim3(pre_grid(nblocks, QT / 64, 256)), dim3(QT), lds6, s, (const double*)nullptr, T, nblocks,
+                                   (const h8*)nullptr, (const float*)nullptr, (const h8*)cimg, (PreScalars*)ps, cbq, M / 32,
+                                   idxmask, sc, (const u64*)l1max_bits, sym, dmin, rows, fb_list, stagger, prev_sym, 0, aos,
+                                   ea_fused);
+            };
+            // (round 6: the rotating tile loop from two tiles on, eight waves per workgroup; P = 40's seven-wave instantiation
+            // keeps the plain loop)
+            if constexpr (QT == 512) {
+                if (M / 32 >= 2) {
+                    goq(k_pass_pre<NC, 6, QT, true>);
+                    return 0;
+                }
+            }
+            goq(k_pass_pre<NC, 6, QT, false>);
         } else {
             return 1;
         }

@@ -89,7 +89,8 @@ class Kernel:
 CLEAN = [
     (r"k_pass_pre_ldsILi37ELb1ELi2E", "vq_prefilter", 256),   # round 4's fused pass (M = 128; ECOZ2_VQ_ACCUMULATE=records)
     (r"k_pass_pre_ldsILi37ELb1ELi1E", "vq_prefilter", 256),   # ... with the burst of atomics
-    (r"k_pass_preILi37ELi6ELi512E", "vq_prefilter", 256),     # fused quantize
+    (r"k_pass_preILi37ELi6ELi512ELb1E", "vq_prefilter", 256), # fused quantize, rotating tile loop (round 6: one register set)
+    (r"k_pass_preILi37ELi6ELi512ELb0E", "vq_prefilter", 256), # ... the plain loop (a single tile)
     (r"k_reduce_recordsILi37E", "vq_prefilter", 85),          # three workgroups of eight waves per CU
     (r"k_pass_mfmaILi37ELi2ELi512ELi0E", "vq_device", 256),   # plain FP64 sweep
     (r"k_pass_smallILi37E", "vq_device", 256),                # M <= 16
@@ -122,6 +123,27 @@ def test_rotating_tile_loop(asm, pattern):
     # operand loads of the loop are the inline-asm ones, each behind its hazard padding (v_readlane -> VMEM address)
     loads = [b for b in k.asm_blocks() if any("global_load_dwordx4" in x for x in b)]
     assert len(loads) == 36  # four loading tiles x 9 unique granules
+    assert all(b[0].startswith("s_nop 4") for b in loads)
+    assert not any(l.strip().startswith("global_load_dwordx4") for l in body
+                   if not any(l.strip() in b for b in loads)), "a compiler-visible load inside the tile loop"
+
+
+def test_quantize_rotating_tile_loop(asm):
+    """Round 6: the fused quantize kernel's tile loop -- ONE register set, the next tile requested by inline asm behind the
+    current tile's last readers, waited for granule by granule.  Its waits count the vector-memory operations in flight, so
+    nothing else may issue one inside the loop: no scratch access (two register sets spilled 36 registers INTO the loop), no
+    compiler-visible load, no full wait."""
+    k = Kernel(asm["vq_prefilter"], r"k_pass_preILi37ELi6ELi512ELb1E")
+    assert k.count("v_mfma_f32_32x32x16_f16") == 90  # tile 0, the loop's tile, the last tile: 3 x 2 jobs x 15 k-steps
+    inner = [lp for lp in k.loops() if lp[2] == 30]
+    assert inner, [lp for lp in k.loops() if lp[2]]
+    first, last, _mf, full_waits = min(inner, key=lambda lp: lp[1] - lp[0])
+    # (one full wait is the loop's own: the granule requested last is waited for with vmcnt(NU - 1 - rank) = vmcnt(0))
+    assert full_waits == 1
+    body = k.body[first:last]
+    assert not any(l.strip().startswith(("scratch_", "buffer_load", "buffer_store")) for l in body)
+    loads = [b for b in k.asm_blocks() if any("global_load_dwordx4" in x for x in b)]
+    assert len(loads) == 27  # tile 0 (requested whole) + the two loading jobs x 9 unique granules
     assert all(b[0].startswith("s_nop 4") for b in loads)
     assert not any(l.strip().startswith("global_load_dwordx4") for l in body
                    if not any(l.strip() in b for b in loads)), "a compiler-visible load inside the tile loop"

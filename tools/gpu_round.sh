@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised driver for the GPU-box steps of a round (replaces the per-call scripts of rounds 4 and 5).
 #   gpurun --timeout 1200 -- 'bash tools/gpu_round.sh <step>...'      every step writes gpurun_out/<tag>_<step>.*
-# steps:  tests | smoke | fuzz[:N[:seed[:mode]]] | bench[:extra args] | flagged | stamps | exp[:modes] | profiles[:tag[:bench args]]
+# steps:  tests | smoke | fuzz[:N[:seed[:pre|gen|hmm]]] | bench[:extra args] | flagged | stamps | exp[:modes] | profiles[:tag[:bench args]]
 #         | quantprof[:tag] | ab:<variant>... (variants built by tools/probe/ab/build_variant.sh; "base" = the product)
 # TAG (environment, default r06) prefixes the output files.  A failing step ends the call (no GPU step is started behind it).
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
@@ -18,8 +18,9 @@ for step in "$@"; do
     smoke)   timeout -k 10 300 python -c 'import __graft_entry__ as g; g.smoke()' > $OUT/${TAG}_smoke.txt 2>&1 || { tail -20 $OUT/${TAG}_smoke.txt; exit 1; }
              tail -1 $OUT/${TAG}_smoke.txt ;;
     fuzz)    IFS=: read -r n seed mode <<< "$arg"
-             timeout -k 10 1100 python tools/fuzz_parity.py ${n:-300} ${seed:-9601} ${mode:-pre} > $OUT/${TAG}_fuzz_${mode:-pre}.txt 2>&1 || { tail -20 $OUT/${TAG}_fuzz_${mode:-pre}.txt; exit 1; }
-             tail -2 $OUT/${TAG}_fuzz_${mode:-pre}.txt ;;
+             mode=${mode:-pre}; marg=$mode; [ "$mode" = gen ] && marg=""   # (gen: the general mode -- random T, M, P; one pass + update + quantize)
+             timeout -k 10 1100 python tools/fuzz_parity.py ${n:-300} ${seed:-9601} $marg > $OUT/${TAG}_fuzz_${mode}.txt 2>&1 || { tail -20 $OUT/${TAG}_fuzz_${mode}.txt; exit 1; }
+             tail -2 $OUT/${TAG}_fuzz_${mode}.txt ;;
     bench)   timeout -k 10 900 python bench.py $arg > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || { tail -20 $OUT/${TAG}_bench.err; exit 1; }
              python tools/bench_digest.py "python bench.py $arg"=$OUT/${TAG}_bench.json | cut -c1-900 ;;
     flagged) timeout -k 10 600 python tools/probe/flagged_probe.py $arg > $OUT/${TAG}_flagged.txt 2>&1 || { tail -20 $OUT/${TAG}_flagged.txt; exit 1; }
