@@ -150,10 +150,14 @@ def small_corpus(e, np, with_cpu):
 
     T, MM = SMALL_CORPUS_T, SMALL_CORPUS_M
     root = tempfile.mkdtemp(prefix="e2small_")
-    out = {"what": f"notes.md:122-153: {T} training vectors, eps 0.05, M = 2 ... {MM}, P = {P}; synthetic frames (seed {SEED})",
+    out = {"what": f"notes.md:122-153: {T} training vectors, eps 0.05, M = 2 ... {MM}, P = {P}; synthetic frames SHAPED like that "
+                   f"corpus (e2vq_synth_frames_kind 1: no classes, reflections on a smooth trajectory around the Levinson recursion of "
+                   f"the vector notes.md:80-85 prints, r[0] = 1/E about 2-3; seed {SEED}) -- rounds 4 and 5 ran these sizes on the "
+                   f"20-class generator, whose ladder is kept as resident_ladder_seconds_class_generator",
            "frames": T, "max_codebook_size": MM}
     try:
-        frames = e.synth.synth_frames(SEED, N_CLASSES, P, 0, T)
+        frames = e.synth.synth_frames_kind(SEED, 1, 6, 0.01, P, 0, T)
+        out["mean_r0"] = float(frames[:, 0].mean())
         prd = os.path.join(root, "data", "predictors", "_", "corpus.prd")
         e.formats.write_prd(prd, "_", frames)
         env = dict(os.environ, ECOZ2_VQ_OUT_ROOT=root, ECOZ2_VQ_MAX_CODEBOOK_SIZE=str(MM), ECOZ2_VQ_QUIET="1")
@@ -237,7 +241,21 @@ def small_corpus(e, np, with_cpu):
             s.synchronize()
             out["resident_ladder_seconds"] = round(time.perf_counter() - t0, 5)
             out["resident_ladder_passes"] = sum(x.passes for x in whole)
+            out["resident_ladder_passes_per_level"] = [x.passes for x in whole]
             out["resident_ladder_us_per_pass"] = round(1e6 * (time.perf_counter() - t0) / max(1, out["resident_ladder_passes"]), 1)
+            out["final_avg_distortion"] = whole[-1].avg_distortion  # (notes.md:150-153: 0.0587 at M = 2048 on the real corpus)
+            out["decided"] = dict(zip(("one_stage_until_M", "plain_sweep_from_M", "uncertified_frames_last_pass"), s.sweep_policy_state()))
+        with e.VqSession(P, device=0) as s:  # the same sizes on the 20-class generator (what rounds 4 and 5 reported)
+            s.set_frames(e.synth.synth_frames(SEED, N_CLASSES, P, 0, T))
+            s.prepare()
+            for rep in range(2):
+                s.init_codebook()
+                s.synchronize()
+                t0 = time.perf_counter()
+                wc = s.learn(0.05, MM)
+                s.synchronize()
+                out["resident_ladder_seconds_class_generator"] = round(time.perf_counter() - t0, 5)
+                out["resident_ladder_passes_class_generator"] = sum(x.passes for x in wc)
         out["levels"] = levels
         if with_cpu:
             from tests import oracle_lib
