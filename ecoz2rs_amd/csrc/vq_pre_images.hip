@@ -228,7 +228,19 @@ __global__ void k_pre_cmax(const double* __restrict__ cbq, int M, int NC, int NP
     if (threadIdx.x == 0 && smax) atomicMax(&ps->eC_biased, smax);
 }
 
-// ---- codebook image: [tile][unique granule][h*32 + row][8 halves] ------------------------------------------
+// ---- codebook image: [tile][unique granule][h*32 + row][8 halves], then the per-tile table [tile] (c_t, d_t) --------------
+// Round 6: every TILE of 32 codewords takes its limbs at its own scale.  With eC_t = max ilogb(c a) + 1 over the tile's codewords
+// and s_t = min(eC - eC_t, 8) >= 0, the limbs are split from eta' = c a 2^-(eC - s_t) -- 2^s_t times finer than the global
+// scale allows where the tile's codewords are small -- and STORED multiplied by 2^-s_t: an f16 holds L 2^-s exactly (|L| <= 512,
+// s <= 8), the limb products and their f32 sums are the same integers on a 2^-s grid, so every accumulator, and with it the
+// key, comes out in the units of the global scale with no change to any sweep kernel -- but with an error of
+//     |2^36 sum xi eta - key|  <=  2^-s_t 2^8 (g + y'_t + NC + 4)  +  rho |key|,      y'_t = max_m sum_n |eta'_mn|
+// (the proven bound of DESIGN 4.2 applied to eta').  Since 2^-s_t y'_t = sum |eta| <= ymax, the old bound 2^8 (g + ymax + NC
+// + 4) holds for every tile as before: kernels that do not look at the table (the two-stage sweep's coarse rule, the fused
+// sorted pass, k_finish) stay valid unchanged.  The table gives c_t = 2^-s_t and d_t = 2^-s_t (y'_t + NC + 4), both rounded
+// up: a kernel that knows which tile a frame's smallest key came from certifies with 2^8 (c_t g + d_t) for that key and the
+// old bound for all the others (k_pass_pre_lds, fused quantize) -- on data whose distortions are small differences of large
+// terms the typical tile sits 2-3 bits below the global scale (tools/probe/key_precision_model.py).
 template <int NC>
 __global__ __launch_bounds__(256) void k_pre_codebook(const double* __restrict__ cbq, int M, int NPAD,
                                                       const int* __restrict__ ea, PreScalars* __restrict__ ps,
@@ -236,25 +248,55 @@ __global__ __launch_bounds__(256) void k_pre_codebook(const double* __restrict__
 {
     typedef PrePack<NC> PK;
     __shared__ short Y[3][32][PK::NCX];
+    __shared__ int s_et;
+    __shared__ float s_y[32];
     const int tile = blockIdx.x;
+    const int MT = (M + 31) / 32;
     const int eC = ps->eC_biased ? ps->eC_biased - PRE_EBIAS : 0;
+    if (threadIdx.x == 0) s_et = -100000;
+    __syncthreads();
+    {   // the tile's own exponent
+        int mx = -100000;
+        for (int i = threadIdx.x; i < 32 * NC; i += 256) {
+            const int row = i / NC, n = i - row * NC;
+            const int m = tile * 32 + row;
+            const double c = m < M ? cbq[(long)m * NPAD + n] : 0.0;
+            if (c != 0.0) {
+                const int e = ilogb(c) + ea[n] + 1;
+                mx = e > mx ? e : mx;
+            }
+        }
+        if (mx > -100000) atomicMax(&s_et, mx);
+    }
+    __syncthreads();
+    int st = s_et > -100000 ? eC - s_et : 8;  // (an all-zero tile: any scale)
+    st = st < 0 ? 0 : (st > 8 ? 8 : st);
     for (int i = threadIdx.x; i < 32 * PK::NCX; i += 256) {
         const int row = i / PK::NCX, n = i - row * PK::NCX;
         const int m = tile * 32 + row;
         int L[3] = {0, 0, 0};
-        if (n < NC && m < M) pre_split(ldexp(cbq[(long)m * NPAD + n], ea[n] - eC), L);
+        if (n < NC && m < M) pre_split(ldexp(cbq[(long)m * NPAD + n], ea[n] - eC + st), L);
         Y[0][row][n] = (short)L[0];
         Y[1][row][n] = (short)L[1];
         Y[2][row][n] = (short)L[2];
     }
-    if (threadIdx.x < 32) {  // sum_n |eta| of this tile's codewords -> global max (float bits, rounded up)
+    if (threadIdx.x < 32) {  // sum_n |eta| of this tile's codewords -> global max (float bits, rounded up); y'_t at the tile's scale
         const int m = tile * 32 + threadIdx.x;
         double g = 0.0;
         if (m < M)
             for (int n = 0; n < NC; ++n) g += fabs(ldexp(cbq[(long)m * NPAD + n], ea[n] - eC));
         atomicMax(&ps->ymax_bits, __float_as_int((float)g * 1.000001f));
+        s_y[threadIdx.x] = (float)ldexp(g, st) * 1.000001f;
     }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        float y = 0.f;
+        for (int r = 0; r < 32; ++r) y = s_y[r] > y ? s_y[r] : y;
+        const float c = __int_as_float((127 - st) << 23);  // 2^-s_t
+        float2* tab = (float2*)(cimg + (size_t)MT * PK::TILE_E);
+        tab[tile] = make_float2(c, c * (y + (float)(NC + 4)) * 1.000001f);
+    }
+    const float scale = __int_as_float((127 - st) << 23);
     for (int i = threadIdx.x; i < PK::TILE_E; i += 256) {
         h8 out = {0, 0, 0, 0, 0, 0, 0, 0};
         const int u = i >> 6, l = i & 63, hh = l >> 5, row = l & 31;  // unique granule u (PrePack::step_unique)
@@ -262,7 +304,7 @@ __global__ __launch_bounds__(256) void k_pre_codebook(const double* __restrict__
         for (int e = 0; e < 8; ++e) {
             int cl, n;
             PK::unique_slot(u, hh, e, cl, n);
-            if (n >= 0) out[e] = (_Float16)(int)Y[cl][row][n];
+            if (n >= 0) out[e] = (_Float16)((float)(int)Y[cl][row][n] * scale);  // (exact: |L| <= 512, a power of two >= 2^-8)
         }
         cimg[(long)tile * PK::TILE_E + i] = out;
     }
@@ -286,7 +328,8 @@ static bool pre_has_nc(int NC)
     }
 }
 template <int NC> static size_t frame_image_bytes_t(long nb) { return (size_t)nb * 2 * PrePack<NC>::PAIRS * 64 * 16; }
-template <int NC> static size_t codebook_image_bytes_t(int M) { return (size_t)((M + 31) / 32) * PrePack<NC>::TILE_E * 16; }
+// (the tiles' limb images, then the per-tile table of k_pre_codebook: 8 bytes per tile)
+template <int NC> static size_t codebook_image_bytes_t(int M) { return (size_t)((M + 31) / 32) * (PrePack<NC>::TILE_E * 16 + 8); }
 
 // (the codeword index shares the f32 key with the value: at M = 8192 nine mantissa bits are left for the value and 6 % of the
 // frames of the bench data go to the FP64 fallback sweep -- still 2.6 x the plain sweep's rate, profiles/r04_big_codebooks.txt;

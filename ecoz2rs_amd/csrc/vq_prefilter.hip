@@ -339,7 +339,12 @@ __global__ __launch_bounds__(TPBM, 2) void k_pass_pre(const double* __restrict__
             // t1 <= u2 <= w3: the three smallest keys of frame 32 cb + (lane & 31)
             const long t = b * 64 + 32 * cb + (lane & 31);
             const float g = QF ? gq[cb] : (t < T ? fg[t] : 0.f);
-            const float tau = 1.27f * (512.f * (g + ymax1 + (NC + 4.0f)) + relk * t1);
+            float tau = 1.27f * (512.f * (g + ymax1 + (NC + 4.0f)) + relk * t1);
+            if constexpr (QF) {  // (round 6: the smallest key with its tile's own tolerance -- see k_pass_pre_lds)
+                const int tl = (__float_as_int(t1) & ~idxmask) >> 5;
+                const float2 tt = ((const float2*)(cimg + (size_t)MT * PK::TILE_E))[tl < MT ? tl : 0];
+                tau = 1.27f * (256.f * __builtin_fmaf(tt.x, g, tt.y) + 256.f * (g + ymax1 + (NC + 4.0f)) + relk * t1);
+            }
             cert[cb] = t1 >= 1.0e-30f && t1 < 1.0e37f && w3 > t1 + tau;
             amb[cb] = !(u2 > t1 + tau);  // the runner-up is within reach: it needs the exact evaluation too
             c1[cb] = __float_as_int(t1) & ~idxmask;
@@ -710,7 +715,11 @@ __global__ __launch_bounds__(512, 2) void k_pass_pre_lds(const double* __restric
         const long t = b * 64 + ln;
         const bool live = t < T;
         const float g = live ? fgs[ln] : 0.f;
-        const float tau = 1.27f * (512.f * (g + ymax1 + (NC + 4.0f)) + relk * t1);
+        // round 6: the smallest key's own tolerance is its TILE's -- 2^8 (c_t g + d_t) from the table behind the codebook image
+        // (k_pre_codebook: the tile's limbs sit 2^-s_t below the global scale) --, every other key's the old bound
+        const int tl1 = (__float_as_int(t1) & ~idxmask) >> 5;
+        const float2 tt = ((const float2*)(cimg + (size_t)MT * PK::TILE_E))[tl1 < MT ? tl1 : 0];
+        const float tau = 1.27f * (256.f * __builtin_fmaf(tt.x, g, tt.y) + 256.f * (g + ymax1 + (NC + 4.0f)) + relk * t1);
         const bool keyok = t1 >= 1.0e-30f && t1 < 1.0e37f;
         const bool cert2 = keyok && w3 > t1 + tau;
         const bool amb = !(u2 > t1 + tau);  // the runner-up is within reach: it needs the exact evaluation too

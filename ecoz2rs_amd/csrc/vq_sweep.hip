@@ -697,7 +697,12 @@ __global__ __launch_bounds__((FUSE ? SweepLds<NC>::WAVES_FUSE : 8) * 64, 2) void
         const float w3 = med3f(u2, u3, b3);
         const float gfr = h ? gc1 : gc0;
         const unsigned fr = h ? f1 : f0;
-        const float tau = 1.27f * (512.f * (gfr + ymax1 + (NC + 4.0f)) + relk * t1);
+        float tau = 1.27f * (512.f * (gfr + ymax1 + (NC + 4.0f)) + relk * t1);
+        if constexpr (FUSE) {  // (round 6: the smallest key with its tile's own tolerance: k_pre_codebook's table, k_pass_pre_lds)
+            const int tl1 = (__float_as_int(t1) & ~idxmask) >> 5;
+            const float2 tt = ((const float2*)(cimg + (size_t)MT * PK::TILE_E))[tl1 < MT ? tl1 : 0];
+            tau = 1.27f * (256.f * __builtin_fmaf(tt.x, gfr, tt.y) + 256.f * (gfr + ymax1 + (NC + 4.0f)) + relk * t1);
+        }
         const bool cert = t1 >= 1.0e-30f && t1 < 1.0e37f && w3 > t1 + tau;
         const bool amb = !(u2 > t1 + tau);
         const unsigned c1 = (unsigned)(__float_as_int(t1) & ~idxmask), c2 = (unsigned)(__float_as_int(u2) & ~idxmask);

@@ -167,6 +167,81 @@ def test_top_three_certification_never_loses_the_argmin(oracle, kind):
         assert cert2.mean() < 0.97 and cert3.mean() > 0.02  # (0.945 / 0.032 here; the GPU at 2^21 frames: 0.80 / 0.07)
 
 
+@pytest.mark.parametrize("kind", ["plain", "twins", "corpus_like", "wide_scales"])
+def test_per_tile_scaled_images_bound_and_rule(oracle, kind):
+    """Round 6 (k_pre_codebook): every tile of 32 codewords takes its limbs at its own scale -- split from eta 2^s_t, stored
+    times 2^-s_t --, so a key comes out in global units with an error of 2^-s_t 2^8 (g + y'_t + NC + 4) + rho |key|.  Checked
+    on the restated keys: the stored limbs are exact in f16 and the partial sums exact in f32; the per-tile bound holds; the old
+    global bound still holds for every key (kernels that do not look at the table stay valid); and the rule of
+    k_pass_pre_lds / the fused quantize -- the smallest key with its tile's tolerance, all others with the global one --
+    never certifies a frame whose argmin is outside the candidates, and certifies more than the global rule."""
+    rng = np.random.default_rng(23)
+    T, M, bits = 1500, 256, 8
+    if kind == "corpus_like":
+        train = e.synth.synth_frames_kind(20290, 1, 6, 0.01, P, 0, 20000)
+        rc, levels, _cbs = oracle.learn(train, 0.05, M)
+        assert rc == 0
+        refl = levels[-1]["reflections"]
+        ea = (_ilogb(np.abs(train).max(axis=0)) + 1).astype(np.int64)
+        frames = e.synth.synth_frames_kind(20290, 1, 6, 0.01, P, 1_000_000, T)
+    else:
+        frames = e.synth.synth_frames(20260, 6, P, 0, T)
+        refl = _codebook(oracle, e.synth.synth_frames(20261, 5, P, 0, M))
+        if kind == "twins":
+            refl = oracle.grow(refl[: M // 2])
+        if kind == "wide_scales":  # tiles whose codewords differ by many octaves in magnitude (reflections near +-1)
+            refl = refl * rng.choice([0.2, 0.6, 1.0, 1.35], size=(M // 32, 1, 1)).repeat(32, axis=1).reshape(M, 1)
+            refl = np.clip(refl, -0.97, 0.97)
+        ea = (_ilogb(np.abs(frames).max(axis=0)) + 1).astype(np.int64)
+    cq = oracle.reflections_to_cq(refl)
+    nz = frames != 0.0
+    eA = np.where(nz, _ilogb(np.where(nz, frames, 1.0)) - ea[None, :] + 1, -100000).max(axis=1)
+    xi = np.ldexp(frames, (-ea[None, :] - eA[:, None]).astype(np.int64))
+    ec = _ilogb(np.where(cq != 0, cq, 1.0)) + ea[None, :] + 1
+    eC = ec[cq != 0].max()
+    st = np.repeat(np.clip(eC - ec.reshape(M // 32, 32, -1).max(axis=(1, 2)), 0, 8), 32)
+    eta_t = np.ldexp(cq, (ea[None, :] - eC + st[:, None]).astype(np.int64))  # the tile's own scale
+    assert np.abs(eta_t).max() < 1.0
+    X, Y = _split(xi), _split(eta_t)
+    Ys = [y * (2.0 ** -st)[:, None] for y in Y]  # as stored
+    for y in Ys:
+        assert np.array_equal(y.astype(np.float16).astype(np.float64), y), "a stored limb is not exact in f16"
+    W0, W1 = X[0] @ Ys[0].T, X[0] @ Ys[1].T + X[1] @ Ys[0].T
+    W2 = X[0] @ Ys[2].T + X[1] @ Ys[1].T + X[2] @ Ys[0].T
+    for W in (W0, W1, W2):  # integers on a 2^-s grid below 2^24 grid steps: exact in f32 in any summation order
+        Wi = W * (2.0 ** st)[None, :]
+        assert np.array_equal(Wi, np.rint(Wi)) and np.abs(Wi).max() < 2 ** 24
+    v1 = (W1 * 512.0 + W2).astype(np.float32).astype(np.float64)
+    v = (W0 * 262144.0 + v1).astype(np.float32)
+    mask = np.uint32(~((1 << bits) - 1) & 0xFFFFFFFF)
+    key = ((v.view(np.uint32) & mask) | np.arange(M, dtype=np.uint32)[None, :]).view(np.float32).astype(np.float64)
+    eta_g = np.ldexp(cq, (ea[None, :] - eC).astype(np.int64))
+    exact = (xi @ eta_g.T) * 2.0 ** 36
+    g = np.abs(xi).sum(axis=1)
+    y_t = np.repeat(np.abs(eta_t).sum(axis=1).reshape(M // 32, 32).max(axis=1), 32)
+    ymax = np.abs(eta_g).sum(axis=1).max()
+    rho = 2.0 ** -(22 - bits)
+    B_t = 256.0 * (g[:, None] + y_t[None, :] + 41.0) * (2.0 ** -st)[None, :]
+    assert (np.abs(exact - key) <= B_t + rho * np.abs(key)).all(), "the per-tile bound does not hold"
+    B_g = 256.0 * (g + ymax + 41.0)
+    assert (B_t <= B_g[:, None] * (1 + 1e-12)).all(), "a tile's bound exceeds the global one"
+    order = np.argsort(key, axis=1, kind="stable")
+    k = np.take_along_axis(key, order[:, :3], axis=1)
+    B1 = B_t[np.arange(T), order[:, 0]]
+    tau_old = 1.27 * (2.0 * B_g + 2.0 * rho * k[:, 0])
+    tau_new = 1.27 * (B1 + B_g + 2.0 * rho * k[:, 0])
+    ok = k[:, 0] >= 1e-30
+    cert_old, cert_new = ok & (k[:, 2] > k[:, 0] + tau_old), ok & (k[:, 2] > k[:, 0] + tau_new)
+    best = (frames @ cq.T).argmin(axis=1)
+    in2 = (best == order[:, 0]) | (best == order[:, 1])
+    assert in2[cert_new].all(), "a certified frame lost its argmin"
+    assert (cert_new | ~cert_old).all() and cert_new.sum() >= cert_old.sum()
+    if kind == "wide_scales":
+        assert st.max() - st.min() >= 2  # (the case is about tiles at different scales)
+    if kind == "corpus_like":
+        assert cert_new.mean() > cert_old.mean() + 0.01, (cert_old.mean(), cert_new.mean())
+
+
 def test_synthetic_generators_are_deterministic_and_shaped():
     """e2vq_synth_frames_kind: kind 0 at noise 0.05 IS e2vq_synth_frames (the golden fixtures hang on that stream); kind 1 (a
     continuum without classes) has r[0] = 1 / E around 2-3 like the reference's whale-song file (notes.md:80-85), is counter
