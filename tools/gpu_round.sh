@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised driver for the GPU-box steps of a round (replaces the per-call scripts of rounds 4 and 5).
 #   gpurun --timeout 1200 -- 'bash tools/gpu_round.sh <step>...'      every step writes gpurun_out/<tag>_<step>.*
-# steps:  tests | smoke | fuzz[:N[:seed[:pre|gen|hmm]]] | bench[:extra args] | flagged | stamps | exp[:modes] | profiles[:tag[:bench args]]
+# steps:  tests | smoke | fuzz[:N[:seed[:pre|gen|hmm]]] | bench[:extra args] | flagged | fallback | scale | stamps | exp[:modes] | profiles[:tag[:bench args]]
 #         | quantprof[:tag] | ab:<variant>... (variants built by tools/probe/ab/build_variant.sh; "base" = the product)
 # TAG (environment, default r06) prefixes the output files.  A failing step ends the call (no GPU step is started behind it).
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
@@ -27,6 +27,8 @@ for step in "$@"; do
              cut -c1-400 $OUT/${TAG}_flagged.txt ;;
     fallback) timeout -k 10 600 python tools/probe/fallback_probe.py $arg > $OUT/${TAG}_fallback.txt 2>&1 || { tail -20 $OUT/${TAG}_fallback.txt; exit 1; }
              cut -c1-400 $OUT/${TAG}_fallback.txt ;;
+    scale)   timeout -k 10 900 python tools/probe/scale_check.py $arg > $OUT/${TAG}_scale_check.txt 2>&1 || { tail -20 $OUT/${TAG}_scale_check.txt; exit 1; }
+             cut -c1-300 $OUT/${TAG}_scale_check.txt ;;
     stamps)  ECOZ2VQ_LIB=tools/probe/ab/stamp/libecoz2vq.so timeout -k 10 400 python tools/probe/sweep_stamps.py > $OUT/${TAG}_stamps.txt 2>&1 || { tail -20 $OUT/${TAG}_stamps.txt; exit 1; }
              grep -v "pass 1" $OUT/${TAG}_stamps.txt | cut -c1-420 ;;
     exp)     EXP_MODES=${arg:-0,1,2,3,0} ECOZ2VQ_LIB=tools/probe/ab/stamp/libecoz2vq.so timeout -k 10 400 python tools/probe/sweep_exp.py > $OUT/${TAG}_exp.txt 2>&1 || { tail -20 $OUT/${TAG}_exp.txt; exit 1; }

@@ -32,7 +32,7 @@ f = re.sub(r"final sources \([0-9a-f]{16}\)", f"final sources ({H})", f)
 f = re.sub(r"\d+ passed, \d+ skipped, \d+ deselected in [^\n]*", open(f"gpurun_out/{TAG}_tests.log").read().strip().split("\n")[-1], f)
 for mode, head in (("pre", "prefilter fuzz done"), ("gen", "fuzz done"), ("hmm", "hmm fuzz done")):
     last = open(f"gpurun_out/{TAG}_fuzz_{mode}.txt").read().strip().split("\n")[-1]
-    f = re.sub(r"^" + head + r"[^\n]*$", last, f, flags=re.M)
+    f = re.sub(r"^" + head + r"[^\n]*$", last, f, count=1, flags=re.M)  # (the first call's line; the "more of it" section is edited by hand)
 open(f"profiles/{TAG}_fuzz.txt", "w").write(f)
 for p in ("profiles/README.md",):
     x = open(p).read()
