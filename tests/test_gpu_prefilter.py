@@ -176,6 +176,73 @@ def test_badly_scaled_zero_and_negative_frames(oracle, monkeypatch):
     _check(oracle, frames, refl, monkeypatch)
 
 
+@pytest.mark.parametrize("wild,bits", [((0.5, 0.8), 12), ((0.3, 0.6), 4)])
+@pytest.mark.parametrize("accumulate", ["sorted", "records", "quantize"])
+def test_codeword_tiles_of_very_different_scales(oracle, monkeypatch, accumulate, wild, bits):
+    """Round 6: the limbs of a 32-codeword tile are split from the codewords scaled by the tile's own power of two (clamped
+    to 2^8) and the smallest key is certified with its tile's tolerance.  A codebook whose tiles sit far apart: one tile of
+    random large reflections (autocorrelations up to 2^19 resp. 2^10: it sets the codebook-wide scale, 14 resp. 5 bits
+    above the ordinary tiles -- beyond resp. within the clamp), one of all-zero reflections (32 identical codewords
+    [1, 0, ...]: the clamp, and exact ties), one of damped codewords, the rest ordinary -- through the fused sorted pass,
+    round 4's kernel and the fused quantize kernel; the oracle's bits every time."""
+    frames = _frames(20256, 6000)
+    refl = _codebook(oracle, frames, 256, seed=11)
+    rng = np.random.default_rng(11)
+    refl[0:32, 1:] = rng.choice([-1.0, 1.0], size=(32, P)) * rng.uniform(wild[0], wild[1], size=(32, P))
+    refl[32:64, 1:] = 0.0
+    refl[160:192, 1:] *= 0.03
+    cq = oracle.reflections_to_cq(refl)
+    spread = np.log2(np.abs(cq).reshape(8, -1).max(axis=1))
+    assert spread[0] - np.median(spread) > bits
+    if accumulate == "quantize":
+        T = frames.shape[0]
+        buf = _DeviceBuffer(frames.nbytes)
+        buf.from_host(frames)
+        sym, dmin = _DeviceBuffer(2 * T), _DeviceBuffer(8 * T)
+        with e.VqSession(P) as s:
+            s.set_frames(frames)
+            s.prepare()
+            s.set_codebook(refl)
+            s.quantize_device(buf.ptr.value, T, sym.ptr.value, dmin.ptr.value)
+            s.synchronize()
+        sym_o, dmin_o = oracle.quantize(cq, frames)
+        assert np.array_equal(sym.to_host(np.uint16), sym_o)
+        assert np.array_equal(dmin.to_host(np.float64).view(np.uint64), dmin_o.view(np.uint64))
+        for b in (buf, sym, dmin):
+            b.free()
+        return
+    # three passes with updates in between (the fused sorted kernel serves from the second pass of a codebook size on; cells
+    # nobody falls into keep their codewords, so the wild tile stays)
+    monkeypatch.setenv("ECOZ2_VQ_ACCUMULATE", accumulate)
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER", "1")
+    monkeypatch.setenv("ECOZ2_VQ_PREFILTER_MIN_M", "64")
+    rc, st = oracle.data_stats(frames)
+    sh_r, _ = oracle.shifts(st.maxabs)
+    shares, kinds = [], []
+    with e.VqSession(P) as s:
+        s.set_frames(frames)
+        s.prepare()
+        s.set_codebook(refl)
+        s.set_sweep_policy(-1.0, 1.0)  # (the prefiltered kernels whatever they leave uncertified)
+        for it in range(3):
+            cq = oracle.reflections_to_cq(refl)
+            Ed = oracle.dist_exponent(cq, st.maxabs)
+            _sym, _dmin, rows_o = oracle.run_pass(cq, frames, sh_r, Ed)
+            refl, _ = oracle.update(rows_o, P, sh_r, refl)
+            s.run_pass()
+            used, nfb = s.last_pass_info()
+            assert used
+            shares.append(nfb / frames.shape[0])
+            kinds.append(s.last_pass_sweep()[0])
+            assert oracle_lib.rows_match(s.get_rows(), rows_o, P), it
+            s.pass_stats()
+            s.update()
+            assert np.array_equal(s.get_codebook().view(np.uint64), refl.view(np.uint64)), it
+    print(f"{accumulate}: kernel kinds {kinds}, uncertified shares {[round(x, 4) for x in shares]}")
+    if accumulate == "sorted":
+        assert kinds[1] == 3 and kinds[2] == 3  # the fused pass over frames grouped by cell
+
+
 def test_identical_frames_and_constant_codebook(oracle, monkeypatch):
     """One frame repeated against a codebook whose codewords differ in the last reflection coefficient only."""
     one = _frames(20255, 1)
