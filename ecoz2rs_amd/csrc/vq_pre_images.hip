@@ -236,10 +236,10 @@ __global__ void k_pre_cmax(const double* __restrict__ cbq, int M, int NC, int NP
 // key, comes out in the units of the global scale with no change to any sweep kernel -- but with an error of
 //     |2^36 sum xi eta - key|  <=  2^-s_t 2^8 (g + y'_t + NC + 4)  +  rho |key|,      y'_t = max_m sum_n |eta'_mn|
 // (the proven bound of DESIGN 4.2 applied to eta').  Since 2^-s_t y'_t = sum |eta| <= ymax, the old bound 2^8 (g + ymax + NC
-// + 4) holds for every tile as before: kernels that do not look at the table (the two-stage sweep's coarse rule, the fused
-// sorted pass, k_finish) stay valid unchanged.  The table gives c_t = 2^-s_t and d_t = 2^-s_t (y'_t + NC + 4), both rounded
+// + 4) holds for every tile as before: rules that do not look at the table (the two-stage sweep's coarse rule, k_finish)
+// stay valid unchanged.  The table gives c_t = 2^-s_t and d_t = 2^-s_t (y'_t + NC + 4), both rounded
 // up: a kernel that knows which tile a frame's smallest key came from certifies with 2^8 (c_t g + d_t) for that key and the
-// old bound for all the others (k_pass_pre_lds, fused quantize) -- on data whose distortions are small differences of large
+// old bound for all the others (k_pass_pre_lds, fused quantize, the fused sorted pass) -- on data whose distortions are small differences of large
 // terms the typical tile sits 2-3 bits below the global scale (tools/probe/key_precision_model.py).
 template <int NC>
 __global__ __launch_bounds__(256) void k_pre_codebook(const double* __restrict__ cbq, int M, int NPAD,
@@ -255,30 +255,45 @@ __global__ __launch_bounds__(256) void k_pre_codebook(const double* __restrict__
     const int eC = ps->eC_biased ? ps->eC_biased - PRE_EBIAS : 0;
     if (threadIdx.x == 0) s_et = -100000;
     __syncthreads();
-    {   // the tile's own exponent
+    // the tile's own exponent; every thread keeps the codeword elements it will split (one trip to memory, not two)
+    constexpr int KPT = (32 * PK::NCX + 255) / 256;
+    double cv[KPT];
+    int en[KPT];
+    {
         int mx = -100000;
-        for (int i = threadIdx.x; i < 32 * NC; i += 256) {
-            const int row = i / NC, n = i - row * NC;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            const int row = i / PK::NCX, n = i - row * PK::NCX;
             const int m = tile * 32 + row;
-            const double c = m < M ? cbq[(long)m * NPAD + n] : 0.0;
-            if (c != 0.0) {
-                const int e = ilogb(c) + ea[n] + 1;
+            const bool live = i < 32 * PK::NCX && n < NC && m < M;
+            cv[k] = live ? cbq[(long)m * NPAD + n] : 0.0;
+            en[k] = live ? ea[n] : 0;
+            if (cv[k] != 0.0) {
+                const int e = ilogb(cv[k]) + en[k] + 1;
                 mx = e > mx ? e : mx;
             }
         }
-        if (mx > -100000) atomicMax(&s_et, mx);
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int o = __shfl_xor(mx, d, 64);
+            mx = o > mx ? o : mx;
+        }
+        if ((threadIdx.x & 63) == 0 && mx > -100000) atomicMax(&s_et, mx);
     }
     __syncthreads();
     int st = s_et > -100000 ? eC - s_et : 8;  // (an all-zero tile: any scale)
     st = st < 0 ? 0 : (st > 8 ? 8 : st);
-    for (int i = threadIdx.x; i < 32 * PK::NCX; i += 256) {
-        const int row = i / PK::NCX, n = i - row * PK::NCX;
-        const int m = tile * 32 + row;
-        int L[3] = {0, 0, 0};
-        if (n < NC && m < M) pre_split(ldexp(cbq[(long)m * NPAD + n], ea[n] - eC + st), L);
-        Y[0][row][n] = (short)L[0];
-        Y[1][row][n] = (short)L[1];
-        Y[2][row][n] = (short)L[2];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < 32 * PK::NCX) {
+            const int row = i / PK::NCX, n = i - row * PK::NCX;
+            int L[3] = {0, 0, 0};
+            if (cv[k] != 0.0) pre_split(ldexp(cv[k], en[k] - eC + st), L);
+            Y[0][row][n] = (short)L[0];
+            Y[1][row][n] = (short)L[1];
+            Y[2][row][n] = (short)L[2];
+        }
     }
     if (threadIdx.x < 32) {  // sum_n |eta| of this tile's codewords -> global max (float bits, rounded up); y'_t at the tile's scale
         const int m = tile * 32 + threadIdx.x;
