@@ -697,7 +697,7 @@ int e2vq_pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_faile
     if (fused) {  // (the publisher copied the pass's fallback count along)
         s->last_fb = s->last_prefiltered ? (i64)s->h_stats->fb : -1;
         // (a level's first pass runs on twins -- every codeword next to its sibling -- and certifies fewer frames than the
-        // passes behind it: 0.47 against 0.27 on the continuum data of bench.py; it is given half as much rope again)
+        // passes behind it: 0.27 against 0.09 on the continuum data of bench.py; it is given half as much rope again)
         const double limit = s->last_first_of_level ? std::min(1.0, 1.5 * s->pre_max_uncertified) : s->pre_max_uncertified;
         if (s->last_fb >= 0 && s->T > 0 && (double)s->last_fb > limit * (double)s->T &&
             (!s->pre_off_from_M || s->M < s->pre_off_from_M))
