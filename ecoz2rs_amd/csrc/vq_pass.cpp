@@ -508,20 +508,26 @@ extern "C" int e2vq_last_pass_kernel_ms(e2vq_session* s, float* ms)
 // event recorded behind the kernel (a kernel that has finished without storing it: stream synchronisation, then an error)
 // or a failed query; the publishing workgroup's own spin is bounded, so the kernel always ends, and the word it raises
 // when a flag never arrived becomes an error here.
-static int spin_for_sequence(e2vq_session* s, volatile u64* word, const char* what)
+// expect_s (optional): in -- how long the same wait took for the previous pass; out -- how long this one took.  A wait of more
+// than a few milliseconds sleeps between polls, but not through its end when that is known: a sleeping thread wakes 50-100 us
+// late (later on a busy host), once per pass -- 1-2 % of a 5.5 ms pass over 2^24 frames.  From 0.85 of the expected time on
+// the word is polled again (back to sleeping when the wait turns out much longer: a level's first pass, a larger codebook).
+static int spin_for_sequence(e2vq_session* s, volatile u64* word, const char* what, double* expect_s = nullptr)
 {
     // No wall-clock limit by default (the wait also covers the sweep queued ahead, which may legitimately take minutes);
     // ECOZ2_VQ_STATS_TIMEOUT_S sets one -- for hosts whose all-reduce hook can leave a collective pending for ever (a peer
     // process that died).  A rank of an in-process group also gives up as soon as the group has failed.
     static const double limit_s = getenv("ECOZ2_VQ_STATS_TIMEOUT_S") ? atof(getenv("ECOZ2_VQ_STATS_TIMEOUT_S")) : 0.0;
     const auto t_start = std::chrono::steady_clock::now();
+    const double expect = expect_s ? *expect_s : 0.0;
     bool slow = false;  // after a few milliseconds: sleep between polls instead of burning a core
     for (unsigned long spins = 0; *word != s->stats_seq; ++spins) {
         if (slow) std::this_thread::sleep_for(std::chrono::microseconds(50));
         if ((spins & 0xfff) == 0xfff || slow) {
             if (s->group_failed && *s->group_failed) return e2vq_set_error("%s: another rank of the in-process group failed", what);
             const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-            slow = waited > 5e-3;
+            const bool near_end = expect > 0.0 && waited > 0.85 * expect - 1e-4 && waited < 1.5 * expect + 5e-3;
+            slow = waited > 5e-3 && !near_end;
             if (limit_s > 0.0 && waited > limit_s)
                 return e2vq_set_error("%s: no statistics after %.1f s (ECOZ2_VQ_STATS_TIMEOUT_S)", what, waited);
             // (the safety net: the stream has drained and the number never came.  A stream query, not an event recorded
@@ -542,6 +548,7 @@ static int spin_for_sequence(e2vq_session* s, volatile u64* word, const char* wh
             return e2vq_set_error("%s finished without publishing sequence %llu", what, (unsigned long long)s->stats_seq);
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    if (expect_s) *expect_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     if (s->h_stats->err == s->stats_seq)
         return e2vq_set_error("%s: the publishing workgroup gave up waiting for a cell's flag (sequence %llu)", what,
                               (unsigned long long)s->stats_seq);
@@ -689,7 +696,7 @@ int e2vq_pass_stats_impl(e2vq_session* s, e2vq_level_stats* out, bool wait_faile
     HIPCHK(hipGetLastError());
     s->spec_valid = true;
     // spin on the sequence number (microseconds); the event is the safety net should the kernel never get there
-    if (spin_for_sequence(s, &s->h_stats->seq, "statistics kernel")) return 1;
+    if (spin_for_sequence(s, &s->h_stats->seq, "statistics kernel", &s->stats_wait_s)) return 1;
     if (s->rec_pending) {  // (stored by the reduce kernel, which ran ahead of the statistics kernel on the same queue)
         s->rec_last_total = s->h_stats->rec_total;
         s->rec_pending = false;

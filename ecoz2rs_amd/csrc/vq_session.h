@@ -78,6 +78,7 @@ struct e2vq_session {
     bool failed_pending = false;              // the failed-recursion count of stats_seq has not been read yet (seq2)
     e2vq_level_stats* failed_patch = nullptr;  // e2vq_learn: the level record that still waits for that count
     u64 stats_seq = 0;
+    double stats_wait_s = 0.0;                // how long the host waited for the last pass's statistics (spin_for_sequence)
     double* h_within = nullptr;                                      // pinned, M_cap doubles
     // statistics
     DevScalars* d_sc = nullptr;
